@@ -1,0 +1,129 @@
+/*
+ * pymasc_amd.h -- C ABI of the MI355X (gfx950) strand cross-correlation library (libpymasc_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of PyMaSC: the per-chromosome shifted strand
+ * cross-correlation of the BitArray calculator.  Each entry point names the reference interface it
+ * replaces (paths relative to the PyMaSC source tree).  A maintainer binds these with ctypes
+ * (see INTEGRATION.md); no C++/torch types cross the ABI.
+ *
+ * Bit-vector layout = the reference's BIT_ARRAY (PyMaSC/core/bitarray/bitarray.pxd:13-17):
+ * bit i lives in words[i >> 6] at (i & 63), i is the 1-based genomic position (bit 0 unused),
+ * nwords = ceil(nbits / 64), bits at index >= nbits must be zero.
+ * For a chromosome of length G:  nbits = G + read_len + max_shift + 100
+ * (PyMaSC/core/bitarray/mscc.pyx:117,134,165-167,340-341).
+ *
+ * Conventions: every function returns PMX_OK (0) or a negative PMX_ERR_* code; the message of the
+ * last failure on the calling thread is returned by pmx_last_error().  Pointers named d_* are
+ * DEVICE pointers (HBM) of the context's GPU, h_* are host pointers.  All work is enqueued on the
+ * context's HIP stream; *_dev functions are asynchronous (call pmx_ctx_sync, or order later work
+ * on the same stream), functions taking host output pointers synchronise before returning.
+ * A context is used by one thread at a time (the reference's calculator is single-threaded too:
+ * one calculator per worker process, PyMaSC/handler/worker.py:198-204).
+ */
+#ifndef PYMASC_AMD_H
+#define PYMASC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMX_OK            0
+#define PMX_ERR_INVALID  -1   /* bad argument */
+#define PMX_ERR_HIP      -2   /* HIP runtime / kernel launch failure */
+#define PMX_ERR_NOMEM    -3   /* host or device allocation failure */
+#define PMX_ERR_NODEVICE -4   /* no usable gfx950 device */
+
+/* Rows of the result block written by pmx_cc_dev / pmx_calc_correlation.
+ * The block is PMX_NROWS rows of `stride = max_shift + 1` uint64 each, indexed by shift d. */
+#define PMX_ROW_NCC_CCBINS  0  /* sum_j F[j] & R[j+d]                      mscc.pyx:314        */
+#define PMX_ROW_MSCC_FSUM   1  /* sum_j F[j] & D_d[j]                      mscc.pyx:300,303    */
+#define PMX_ROW_MSCC_RSUM   2  /* sum_j R[j+d] & D_d[j]                    mscc.pyx:301,304    */
+#define PMX_ROW_MSCC_CCBINS 3  /* sum_j F[j] & R[j+d] & D_d[j]             mscc.pyx:305        */
+#define PMX_ROW_MLEN        4  /* popcount(D_d), D_d[j]=M[j]&M[j+L-1-d]    mscc.pyx:291-298    */
+#define PMX_ROW_SCALARS     5  /* [0]=popcount(F) [1]=popcount(R)          mscc.pyx:236-237
+                                  [2]=popcount(M) [3]=kernel path actually used (PMX_PATH_*)    */
+#define PMX_NROWS           6
+
+/* flags for pmx_cc_dev / pmx_calc_correlation */
+#define PMX_FLAG_SKIP_NCC     1u  /* skip_ncc=True (mscc.pyx:235,313): row 0 and scalars 0,1 left zero */
+#define PMX_FLAG_FORCE_DENSE  2u  /* always use the dense word-parallel kernels                */
+#define PMX_FLAG_FORCE_SPARSE 4u  /* always use the set-bit driven window kernels             */
+
+#define PMX_PATH_DENSE  1
+#define PMX_PATH_SPARSE 2
+
+typedef struct pmx_ctx pmx_ctx;
+
+/* ---- library / context ------------------------------------------------------------------- */
+const char *pmx_last_error(void);
+int pmx_version(void);
+int pmx_device_count(int *n);
+
+/* One context per worker process / per GPU (replaces nothing in the reference: it owns the HIP
+ * stream, scratch memory and kernel timers).  `hip_stream` may be NULL (the context creates its
+ * own stream) or an existing hipStream_t, e.g. torch.cuda.current_stream().cuda_stream. */
+int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out);
+int pmx_ctx_destroy(pmx_ctx *ctx);
+int pmx_ctx_sync(pmx_ctx *ctx);
+
+/* ---- device bit-vectors: replace bit_array_create/free/clear_all/set_bit/set_region/num_bits_set
+ *      (bitarray.pxd:20-36; bitarray.pyx:40-50,72-107) ------------------------------------ */
+int pmx_bits_alloc(pmx_ctx *ctx, uint64_t nbits, uint64_t **d_words);      /* zero-filled */
+int pmx_bits_free(pmx_ctx *ctx, uint64_t *d_words);
+int pmx_bits_clear(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits);
+int pmx_bits_upload(pmx_ctx *ctx, uint64_t *d_words, const uint64_t *h_words, uint64_t nbits);
+int pmx_bits_download(pmx_ctx *ctx, const uint64_t *d_words, uint64_t *h_words, uint64_t nbits);
+/* bitarray[pos] = 1 for every pos (feed_forward_read mscc.pyx:393, feed_reverse_read :416-417);
+ * positions are bit indices, duplicates allowed; any pos >= nbits or < 0 -> PMX_ERR_INVALID. */
+int pmx_bits_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits,
+                           const int64_t *h_pos, uint64_t n);
+int pmx_bits_set_positions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits,
+                               const int64_t *d_pos, uint64_t n);
+/* bitarray.set(from, to), both ends inclusive (bitarray.pyx:88-95); the mappability loader calls
+ * it as set(begin + 1, end) per BigWig interval (mscc.pyx:343-344).  Intervals with to < from are
+ * ignored; to >= nbits -> PMX_ERR_INVALID (host variant) / clipped (dev variant). */
+int pmx_bits_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits,
+                         const int64_t *h_from, const int64_t *h_to, uint64_t n);
+int pmx_bits_set_regions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits,
+                             const int64_t *d_from, const int64_t *d_to, uint64_t n);
+/* bit_array_num_bits_set (bitarray.pyx:101-107) */
+int pmx_bits_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, uint64_t *h_count);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* CCBitArrayCalculator._calc_correlation for one chromosome (mscc.pyx:217-325), inputs resident in
+ * HBM.  d_M may be NULL (no mappability: rows 1-4 left zero).  d_out: PMX_NROWS * (max_shift+1)
+ * uint64 in device memory, overwritten.  Inputs are NOT modified (the reference destroys R in
+ * place, mscc.pyx:316; nothing reads it afterwards).  Asynchronous. */
+int pmx_cc_dev(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
+               uint64_t nbits, uint32_t max_shift, uint32_t read_len, uint32_t flags,
+               uint64_t *d_out);
+/* Same with host buffers: uploads F, R (and M), runs, downloads the result block. Synchronous. */
+int pmx_calc_correlation(pmx_ctx *ctx, const uint64_t *h_F, const uint64_t *h_R, const uint64_t *h_M,
+                         uint64_t nbits, uint32_t max_shift, uint32_t read_len, uint32_t flags,
+                         uint64_t *h_out);
+/* CCBitArrayCalculator._fill_result's loop for chromosomes without reads (mscc.pyx:207-215):
+ * out[k] = sum_j M[j] & M[j+k], k = 0..max_shift.  d_out / h_out: (max_shift+1) uint64. */
+int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_shift,
+                         uint32_t flags, uint64_t *d_out);
+int pmx_mappable_len(pmx_ctx *ctx, const uint64_t *h_M, uint64_t nbits, uint32_t max_shift,
+                     uint32_t flags, uint64_t *h_out);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* With profiling on, every launch of a hot-path kernel is bracketed by HIP events on the context's
+ * stream.  pmx_ctx_kernel_time synchronises and returns the summed duration and launch count of
+ * kernel `kernel_id` since the last reset. */
+#define PMX_KERNEL_CC_DENSE     0
+#define PMX_KERNEL_CC_SPARSE    1
+#define PMX_KERNEL_AUTOCORR     2
+#define PMX_KERNEL_COUNT_       3
+int pmx_ctx_set_profiling(pmx_ctx *ctx, int on);
+int pmx_ctx_reset_kernel_times(pmx_ctx *ctx);
+int pmx_ctx_kernel_time(pmx_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
+const char *pmx_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYMASC_AMD_H */

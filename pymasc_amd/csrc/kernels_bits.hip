@@ -1,0 +1,95 @@
+// Device bit-vector builders: the MI355X counterparts of bit_array_set_bit / bit_array_set_region /
+// bit_array_num_bits_set (PyMaSC/core/bitarray/bitarray.pxd:26-31, bitarray.pyx:72-107).
+#include "pmx_common.h"
+
+// bitarray[pos] = 1 (mscc.pyx:393, :416-417). One lane per read; 64-bit atomic OR because many
+// reads share a word.  Out-of-range positions are dropped (the host entry point validates first).
+__global__ void __launch_bounds__(256) k_set_positions(u64 *__restrict__ words, uint64_t nbits,
+                                                       const int64_t *__restrict__ pos, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t p = pos[i];
+        if (p >= 0 && (uint64_t)p < nbits) atomicOr(&words[p >> 6], 1ull << (p & 63));
+    }
+}
+
+// bitarray.set(from, to), inclusive (bitarray.pyx:88-95). One wavefront per interval: the two edge
+// words are OR-ed atomically, interior words are stored whole, lanes striding over the interval.
+__global__ void __launch_bounds__(256) k_set_regions(u64 *__restrict__ words, uint64_t nbits,
+                                                     const int64_t *__restrict__ from,
+                                                     const int64_t *__restrict__ to, uint64_t n)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < n; i += nwaves) {
+        int64_t a = from[i], b = to[i];
+        if (a < 0) a = 0;
+        if (b >= (int64_t)nbits) b = (int64_t)nbits - 1;
+        if (b < a) continue;
+        const uint64_t wa = (uint64_t)a >> 6, wb = (uint64_t)b >> 6;
+        const u64 lo_mask = ~0ull << (a & 63);
+        const u64 hi_mask = ~0ull >> (63 - (b & 63));
+        if (wa == wb) {
+            if (lane == 0) atomicOr(&words[wa], lo_mask & hi_mask);
+            continue;
+        }
+        if (lane == 0) atomicOr(&words[wa], lo_mask);
+        if (lane == 1) atomicOr(&words[wb], hi_mask);
+        for (uint64_t w = wa + 1 + lane; w < wb; w += 64) words[w] = ~0ull;
+    }
+}
+
+// bit_array_num_bits_set: grid-stride popcount, wave reduce by DPP-free shuffles, one atomic per wave.
+__global__ void __launch_bounds__(256) k_count(const u64 *__restrict__ words, uint64_t nwords,
+                                               uint64_t nbits, u64 *__restrict__ out)
+{
+    u64 acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        u64 w = words[i];
+        if (i == nwords - 1 && (nbits & 63)) w &= ~0ull >> (64 - (nbits & 63));
+        acc += (u64)__popcll(w);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+static int grid_for(pmx_ctx *ctx, uint64_t items, int per_block)
+{
+    uint64_t blocks = (items + per_block - 1) / per_block;
+    uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int pmx_launch_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_pos, uint64_t n)
+{
+    if (n == 0) return PMX_OK;
+    hipLaunchKernelGGL(k_set_positions, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream,
+                       (u64 *)d_words, nbits, d_pos, n);
+    PMX_CHECK_LAUNCH("k_set_positions");
+    return PMX_OK;
+}
+
+int pmx_launch_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_from,
+                           const int64_t *d_to, uint64_t n)
+{
+    if (n == 0) return PMX_OK;
+    hipLaunchKernelGGL(k_set_regions, dim3(grid_for(ctx, n, 4)), dim3(256), 0, ctx->stream,
+                       (u64 *)d_words, nbits, d_from, d_to, n);
+    PMX_CHECK_LAUNCH("k_set_regions");
+    return PMX_OK;
+}
+
+int pmx_launch_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, u64 *d_count)
+{
+    const uint64_t nwords = (nbits + 63) / 64;
+    if (nwords == 0) return PMX_OK;
+    hipLaunchKernelGGL(k_count, dim3(grid_for(ctx, nwords, 256 * 8)), dim3(256), 0, ctx->stream,
+                       (const u64 *)d_words, nwords, nbits, d_count);
+    PMX_CHECK_LAUNCH("k_count");
+    return PMX_OK;
+}

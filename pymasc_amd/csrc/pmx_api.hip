@@ -1,0 +1,506 @@
+// extern "C" surface of libpymasc_hip.so -- see include/pymasc_amd.h for the contract and the
+// reference interfaces each entry point replaces.
+#include "pmx_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void pmx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+#define REQUIRE(cond, msg)              \
+    do {                                \
+        if (!(cond)) {                  \
+            pmx_set_error("%s", msg);   \
+            return PMX_ERR_INVALID;     \
+        }                               \
+    } while (0)
+
+static inline uint64_t words_for(uint64_t nbits) { return (nbits + 63) / 64; }
+
+extern "C" {
+
+const char *pmx_last_error(void) { return g_err; }
+int pmx_version(void) { return 100; }
+
+int pmx_device_count(int *n)
+{
+    REQUIRE(n, "pmx_device_count: n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        c = 0;
+        (void)hipGetLastError();
+    }
+    *n = c;
+    return PMX_OK;
+}
+
+int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
+{
+    REQUIRE(out, "pmx_ctx_create: out is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        pmx_set_error("pmx_ctx_create: no HIP device visible (this library has no CPU fallback)");
+        return PMX_ERR_NODEVICE;
+    }
+    REQUIRE(device >= 0 && device < ndev, "pmx_ctx_create: device index out of range");
+    PMX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PMX_HIP(hipGetDeviceProperties(&prop, device));
+    pmx_ctx *ctx = new (std::nothrow) pmx_ctx();
+    if (!ctx) {
+        pmx_set_error("pmx_ctx_create: out of host memory");
+        return PMX_ERR_NOMEM;
+    }
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->profiling = false;
+    ctx->d_scratch = nullptr;
+    ctx->scratch_words = 0;
+    ctx->d_out_stage = nullptr;
+    ctx->out_stage_words = 0;
+    for (int i = 0; i < 3; i++) {
+        ctx->d_stage[i] = nullptr;
+        ctx->stage_words[i] = 0;
+    }
+    for (int i = 0; i < PMX_KERNEL_COUNT_; i++) {
+        ctx->total_ms[i] = 0;
+        ctx->launches[i] = 0;
+    }
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            pmx_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return PMX_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return PMX_OK;
+}
+
+int pmx_ctx_sync(pmx_ctx *ctx)
+{
+    REQUIRE(ctx, "pmx_ctx_sync: ctx is NULL");
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+int pmx_ctx_destroy(pmx_ctx *ctx)
+{
+    if (!ctx) return PMX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &tl : ctx->timed) {
+        (void)hipEventDestroy(tl.start);
+        (void)hipEventDestroy(tl.stop);
+    }
+    for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_out_stage) (void)hipFree(ctx->d_out_stage);
+    for (int i = 0; i < 3; i++)
+        if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PMX_OK;
+}
+
+}   // extern "C"
+
+// ---- internal helpers ---------------------------------------------------------------------------
+
+int pmx_ensure_scratch(pmx_ctx *ctx, size_t words)
+{
+    if (ctx->scratch_words >= words) return PMX_OK;
+    if (ctx->d_scratch) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_words = 0;
+    }
+    size_t want = words < 4096 ? 4096 : words;
+    PMX_HIP(hipMalloc((void **)&ctx->d_scratch, want * sizeof(u64)));
+    ctx->scratch_words = want;
+    return PMX_OK;
+}
+
+static int ensure_stage(pmx_ctx *ctx, int slot, size_t words)
+{
+    if (ctx->stage_words[slot] >= words) return PMX_OK;
+    if (ctx->d_stage[slot]) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(ctx->d_stage[slot]));
+        ctx->d_stage[slot] = nullptr;
+        ctx->stage_words[slot] = 0;
+    }
+    PMX_HIP(hipMalloc((void **)&ctx->d_stage[slot], (words ? words : 1) * sizeof(uint64_t)));
+    ctx->stage_words[slot] = words ? words : 1;
+    return PMX_OK;
+}
+
+static int ensure_out_stage(pmx_ctx *ctx, size_t words)
+{
+    if (ctx->out_stage_words >= words) return PMX_OK;
+    if (ctx->d_out_stage) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(ctx->d_out_stage));
+        ctx->d_out_stage = nullptr;
+    }
+    PMX_HIP(hipMalloc((void **)&ctx->d_out_stage, words * sizeof(u64)));
+    ctx->out_stage_words = words;
+    return PMX_OK;
+}
+
+static int get_event(pmx_ctx *ctx, hipEvent_t *ev)
+{
+    if (!ctx->event_pool.empty()) {
+        *ev = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return PMX_OK;
+    }
+    PMX_HIP(hipEventCreate(ev));
+    return PMX_OK;
+}
+
+int pmx_prof_begin(pmx_ctx *ctx, int kernel_id, pmx_timed_launch *tl)
+{
+    tl->kernel_id = kernel_id;
+    if (!ctx->profiling) return PMX_OK;
+    int rc = get_event(ctx, &tl->start);
+    if (rc) return rc;
+    rc = get_event(ctx, &tl->stop);
+    if (rc) return rc;
+    PMX_HIP(hipEventRecord(tl->start, ctx->stream));
+    return PMX_OK;
+}
+
+int pmx_prof_end(pmx_ctx *ctx, pmx_timed_launch *tl)
+{
+    if (!ctx->profiling) return PMX_OK;
+    PMX_HIP(hipEventRecord(tl->stop, ctx->stream));
+    ctx->timed.push_back(*tl);
+    return PMX_OK;
+}
+
+static int fold_timed(pmx_ctx *ctx)
+{
+    if (ctx->timed.empty()) return PMX_OK;
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &tl : ctx->timed) {
+        float ms = 0.f;
+        PMX_HIP(hipEventElapsedTime(&ms, tl.start, tl.stop));
+        ctx->total_ms[tl.kernel_id] += (double)ms;
+        ctx->launches[tl.kernel_id] += 1;
+        ctx->event_pool.push_back(tl.start);
+        ctx->event_pool.push_back(tl.stop);
+    }
+    ctx->timed.clear();
+    return PMX_OK;
+}
+
+extern "C" {
+
+// ---- measurement ---------------------------------------------------------------------------------
+
+int pmx_ctx_set_profiling(pmx_ctx *ctx, int on)
+{
+    REQUIRE(ctx, "pmx_ctx_set_profiling: ctx is NULL");
+    int rc = fold_timed(ctx);
+    if (rc) return rc;
+    ctx->profiling = on != 0;
+    return PMX_OK;
+}
+
+int pmx_ctx_reset_kernel_times(pmx_ctx *ctx)
+{
+    REQUIRE(ctx, "pmx_ctx_reset_kernel_times: ctx is NULL");
+    int rc = fold_timed(ctx);
+    if (rc) return rc;
+    for (int i = 0; i < PMX_KERNEL_COUNT_; i++) {
+        ctx->total_ms[i] = 0;
+        ctx->launches[i] = 0;
+    }
+    return PMX_OK;
+}
+
+int pmx_ctx_kernel_time(pmx_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches)
+{
+    REQUIRE(ctx, "pmx_ctx_kernel_time: ctx is NULL");
+    REQUIRE(kernel_id >= 0 && kernel_id < PMX_KERNEL_COUNT_, "pmx_ctx_kernel_time: bad kernel_id");
+    int rc = fold_timed(ctx);
+    if (rc) return rc;
+    if (total_ms) *total_ms = ctx->total_ms[kernel_id];
+    if (launches) *launches = ctx->launches[kernel_id];
+    return PMX_OK;
+}
+
+const char *pmx_kernel_name(int kernel_id)
+{
+    switch (kernel_id) {
+    case PMX_KERNEL_CC_DENSE: return "k_cc_dense";
+    case PMX_KERNEL_CC_SPARSE: return "k_cc_sparse";
+    case PMX_KERNEL_AUTOCORR: return "k_cc_dense(autocorr)";
+    default: return "?";
+    }
+}
+
+// ---- device bit-vectors ---------------------------------------------------------------------------
+
+int pmx_bits_alloc(pmx_ctx *ctx, uint64_t nbits, uint64_t **d_words)
+{
+    REQUIRE(ctx && d_words, "pmx_bits_alloc: NULL argument");
+    PMX_HIP(hipSetDevice(ctx->device));
+    const uint64_t nw = words_for(nbits);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (nw ? nw : 1) * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pmx_set_error("pmx_bits_alloc: hipMalloc of %llu bytes failed: %s", (unsigned long long)(nw * 8),
+                      hipGetErrorString(e));
+        return PMX_ERR_NOMEM;
+    }
+    PMX_HIP(hipMemsetAsync(p, 0, (nw ? nw : 1) * sizeof(uint64_t), ctx->stream));
+    *d_words = (uint64_t *)p;
+    return PMX_OK;
+}
+
+int pmx_bits_free(pmx_ctx *ctx, uint64_t *d_words)
+{
+    REQUIRE(ctx, "pmx_bits_free: ctx is NULL");
+    if (!d_words) return PMX_OK;
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    PMX_HIP(hipFree(d_words));
+    return PMX_OK;
+}
+
+int pmx_bits_clear(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits)
+{
+    REQUIRE(ctx && d_words, "pmx_bits_clear: NULL argument");
+    PMX_HIP(hipMemsetAsync(d_words, 0, words_for(nbits) * sizeof(uint64_t), ctx->stream));
+    return PMX_OK;
+}
+
+int pmx_bits_upload(pmx_ctx *ctx, uint64_t *d_words, const uint64_t *h_words, uint64_t nbits)
+{
+    REQUIRE(ctx && d_words && h_words, "pmx_bits_upload: NULL argument");
+    PMX_HIP(hipMemcpyAsync(d_words, h_words, words_for(nbits) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                           ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+int pmx_bits_download(pmx_ctx *ctx, const uint64_t *d_words, uint64_t *h_words, uint64_t nbits)
+{
+    REQUIRE(ctx && d_words && h_words, "pmx_bits_download: NULL argument");
+    PMX_HIP(hipMemcpyAsync(h_words, d_words, words_for(nbits) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+int pmx_bits_set_positions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_pos, uint64_t n)
+{
+    REQUIRE(ctx && d_words && (d_pos || n == 0), "pmx_bits_set_positions_dev: NULL argument");
+    return pmx_launch_set_positions(ctx, d_words, nbits, d_pos, n);
+}
+
+int pmx_bits_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *h_pos, uint64_t n)
+{
+    REQUIRE(ctx && d_words && (h_pos || n == 0), "pmx_bits_set_positions: NULL argument");
+    if (n == 0) return PMX_OK;
+    for (uint64_t i = 0; i < n; i++)
+        if (h_pos[i] < 0 || (uint64_t)h_pos[i] >= nbits) {
+            pmx_set_error("pmx_bits_set_positions: position %lld at index %llu outside [0, %llu)",
+                          (long long)h_pos[i], (unsigned long long)i, (unsigned long long)nbits);
+            return PMX_ERR_INVALID;
+        }
+    int rc = ensure_stage(ctx, 0, n);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(ctx->d_stage[0], h_pos, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_set_positions(ctx, d_words, nbits, (const int64_t *)ctx->d_stage[0], n);
+    if (rc) return rc;
+    PMX_HIP(hipStreamSynchronize(ctx->stream));   // h_pos and the staging buffer may be reused by the caller
+    return PMX_OK;
+}
+
+int pmx_bits_set_regions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_from,
+                             const int64_t *d_to, uint64_t n)
+{
+    REQUIRE(ctx && d_words && ((d_from && d_to) || n == 0), "pmx_bits_set_regions_dev: NULL argument");
+    return pmx_launch_set_regions(ctx, d_words, nbits, d_from, d_to, n);
+}
+
+int pmx_bits_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *h_from,
+                         const int64_t *h_to, uint64_t n)
+{
+    REQUIRE(ctx && d_words && ((h_from && h_to) || n == 0), "pmx_bits_set_regions: NULL argument");
+    if (n == 0) return PMX_OK;
+    for (uint64_t i = 0; i < n; i++) {
+        if (h_to[i] < h_from[i]) continue;
+        if (h_from[i] < 0 || (uint64_t)h_to[i] >= nbits) {
+            pmx_set_error("pmx_bits_set_regions: interval [%lld, %lld] at index %llu outside [0, %llu)",
+                          (long long)h_from[i], (long long)h_to[i], (unsigned long long)i,
+                          (unsigned long long)nbits);
+            return PMX_ERR_INVALID;
+        }
+    }
+    int rc = ensure_stage(ctx, 0, n);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, 1, n);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(ctx->d_stage[0], h_from, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(ctx->d_stage[1], h_to, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_set_regions(ctx, d_words, nbits, (const int64_t *)ctx->d_stage[0],
+                                (const int64_t *)ctx->d_stage[1], n);
+    if (rc) return rc;
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+int pmx_bits_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, uint64_t *h_count)
+{
+    REQUIRE(ctx && d_words && h_count, "pmx_bits_count: NULL argument");
+    int rc = pmx_ensure_scratch(ctx, 4096);
+    if (rc) return rc;
+    PMX_HIP(hipMemsetAsync(ctx->d_scratch, 0, sizeof(u64), ctx->stream));
+    rc = pmx_launch_count(ctx, d_words, nbits, ctx->d_scratch);
+    if (rc) return rc;
+    u64 v = 0;
+    PMX_HIP(hipMemcpyAsync(&v, ctx->d_scratch, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    *h_count = (uint64_t)v;
+    return PMX_OK;
+}
+
+// ---- hot path -------------------------------------------------------------------------------------
+
+static int check_shift_args(uint64_t nbits, uint32_t max_shift, const char *who)
+{
+    if (nbits == 0 || nbits >= (1ull << 40)) {
+        pmx_set_error("%s: nbits must be in [1, 2^40)", who);
+        return PMX_ERR_INVALID;
+    }
+    if (max_shift > 65535) {
+        pmx_set_error("%s: max_shift must be <= 65535", who);
+        return PMX_ERR_INVALID;
+    }
+    return PMX_OK;
+}
+
+int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_shift, uint32_t flags,
+                         uint64_t *d_out)
+{
+    REQUIRE(ctx && d_M && d_out, "pmx_mappable_len_dev: NULL argument");
+    int rc = check_shift_args(nbits, max_shift, "pmx_mappable_len_dev");
+    if (rc) return rc;
+    (void)flags;
+    PMX_HIP(hipMemsetAsync(d_out, 0, ((size_t)max_shift + 1) * sizeof(u64), ctx->stream));
+    return pmx_launch_autocorr_dense(ctx, d_M, nbits, max_shift, (u64 *)d_out);
+}
+
+int pmx_cc_dev(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M, uint64_t nbits,
+               uint32_t max_shift, uint32_t read_len, uint32_t flags, uint64_t *d_out)
+{
+    REQUIRE(ctx && d_F && d_R && d_out, "pmx_cc_dev: NULL argument");
+    int rc = check_shift_args(nbits, max_shift, "pmx_cc_dev");
+    if (rc) return rc;
+    REQUIRE(read_len >= 1 && read_len <= 65535, "pmx_cc_dev: read_len must be in [1, 65535]");
+    REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
+            "pmx_cc_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
+    const bool do_ncc = !(flags & PMX_FLAG_SKIP_NCC);
+    const uint32_t stride = max_shift + 1;
+    u64 *out = (u64 *)d_out;
+    PMX_HIP(hipMemsetAsync(out, 0, (size_t)PMX_NROWS * stride * sizeof(u64), ctx->stream));
+
+    u64 *scal = out + (size_t)PMX_ROW_SCALARS * stride;   // stride >= 1; scalars beyond it live in scratch
+    // the scalar row has max_shift+1 slots; with max_shift < 3 keep extra scalars in scratch instead
+    REQUIRE(stride >= 4, "pmx_cc_dev: max_shift must be >= 3");
+    if (do_ncc) {
+        rc = pmx_launch_count(ctx, d_F, nbits, scal + 0);
+        if (rc) return rc;
+        rc = pmx_launch_count(ctx, d_R, nbits, scal + 1);
+        if (rc) return rc;
+    }
+    if (d_M) {
+        rc = pmx_launch_count(ctx, d_M, nbits, scal + 2);
+        if (rc) return rc;
+    }
+    PMX_HIP(hipMemsetD32Async((hipDeviceptr_t)(scal + 3), PMX_PATH_DENSE, 1, ctx->stream));
+
+    rc = pmx_launch_cc_dense(ctx, d_F, d_R, d_M, nbits, max_shift, read_len, do_ncc, out, stride);
+    if (rc) return rc;
+    if (d_M) {
+        const uint32_t c = read_len - 1;
+        const uint32_t far = max_shift > c ? max_shift - c : 0;   // lags |c - d| over d in [0, max_shift]
+        const uint32_t max_lag = c > far ? c : far;
+        rc = pmx_ensure_scratch(ctx, (size_t)max_lag + 1 + 16);
+        if (rc) return rc;
+        PMX_HIP(hipMemsetAsync(ctx->d_scratch, 0, ((size_t)max_lag + 1) * sizeof(u64), ctx->stream));
+        rc = pmx_launch_autocorr_dense(ctx, d_M, nbits, max_lag, ctx->d_scratch);
+        if (rc) return rc;
+        rc = pmx_launch_mlen_map(ctx, ctx->d_scratch, max_shift, read_len, out + (size_t)PMX_ROW_MLEN * stride);
+        if (rc) return rc;
+    }
+    return PMX_OK;
+}
+
+int pmx_calc_correlation(pmx_ctx *ctx, const uint64_t *h_F, const uint64_t *h_R, const uint64_t *h_M,
+                         uint64_t nbits, uint32_t max_shift, uint32_t read_len, uint32_t flags, uint64_t *h_out)
+{
+    REQUIRE(ctx && h_F && h_R && h_out, "pmx_calc_correlation: NULL argument");
+    int rc = check_shift_args(nbits, max_shift, "pmx_calc_correlation");
+    if (rc) return rc;
+    const uint64_t nw = words_for(nbits);
+    const uint64_t *src[3] = {h_F, h_R, h_M};
+    for (int i = 0; i < 3; i++) {
+        if (!src[i]) continue;
+        rc = ensure_stage(ctx, i, nw);
+        if (rc) return rc;
+        PMX_HIP(hipMemcpyAsync(ctx->d_stage[i], src[i], nw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const size_t out_words = (size_t)PMX_NROWS * (max_shift + 1);
+    rc = ensure_out_stage(ctx, out_words);
+    if (rc) return rc;
+    rc = pmx_cc_dev(ctx, ctx->d_stage[0], ctx->d_stage[1], h_M ? ctx->d_stage[2] : nullptr, nbits, max_shift,
+                    read_len, flags, (uint64_t *)ctx->d_out_stage);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(h_out, ctx->d_out_stage, out_words * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+int pmx_mappable_len(pmx_ctx *ctx, const uint64_t *h_M, uint64_t nbits, uint32_t max_shift, uint32_t flags,
+                     uint64_t *h_out)
+{
+    REQUIRE(ctx && h_M && h_out, "pmx_mappable_len: NULL argument");
+    int rc = check_shift_args(nbits, max_shift, "pmx_mappable_len");
+    if (rc) return rc;
+    const uint64_t nw = words_for(nbits);
+    rc = ensure_stage(ctx, 2, nw);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(ctx->d_stage[2], h_M, nw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = ensure_out_stage(ctx, (size_t)max_shift + 1);
+    if (rc) return rc;
+    rc = pmx_mappable_len_dev(ctx, ctx->d_stage[2], nbits, max_shift, flags, (uint64_t *)ctx->d_out_stage);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(h_out, ctx->d_out_stage, ((size_t)max_shift + 1) * sizeof(u64), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+}   // extern "C"

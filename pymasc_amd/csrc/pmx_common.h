@@ -1,0 +1,80 @@
+// Internal declarations shared by the HIP translation units of libpymasc_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pymasc_amd.h"
+
+typedef unsigned long long u64;   // what atomicAdd(unsigned long long*) wants; same size as uint64_t
+typedef unsigned int u32;
+
+void pmx_set_error(const char *fmt, ...);
+
+#define PMX_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            pmx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                          __LINE__);                                                        \
+            return PMX_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+#define PMX_CHECK_LAUNCH(name)                                                              \
+    do {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                 \
+        if (e__ != hipSuccess) {                                                            \
+            pmx_set_error("launch of %s failed: %s", name, hipGetErrorString(e__));         \
+            return PMX_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+struct pmx_timed_launch {
+    int kernel_id;
+    hipEvent_t start, stop;
+};
+
+struct pmx_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    int num_cus;
+    bool profiling;
+    std::vector<pmx_timed_launch> timed;       // launches not yet folded into the totals
+    std::vector<hipEvent_t> event_pool;
+    double total_ms[PMX_KERNEL_COUNT_];
+    uint64_t launches[PMX_KERNEL_COUNT_];
+    // scratch (device): autocorrelation row + small flags
+    u64 *d_scratch;
+    size_t scratch_words;
+    // staging for the host-pointer entry points
+    uint64_t *d_stage[3];
+    size_t stage_words[3];
+    u64 *d_out_stage;
+    size_t out_stage_words;
+};
+
+// profiling helpers (pmx_api.hip)
+int pmx_prof_begin(pmx_ctx *ctx, int kernel_id, pmx_timed_launch *tl);
+int pmx_prof_end(pmx_ctx *ctx, pmx_timed_launch *tl);
+int pmx_ensure_scratch(pmx_ctx *ctx, size_t words);
+
+// ---- launchers implemented next to their kernels --------------------------------------------
+// bits (kernels_bits.hip)
+int pmx_launch_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_pos, uint64_t n);
+int pmx_launch_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_from,
+                           const int64_t *d_to, uint64_t n);
+int pmx_launch_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, u64 *d_count /* += */);
+
+// dense cross-correlation (kernels_dense.hip)
+// rows of d_out (stride = out_stride) receive += partial sums; caller zeroes d_out first.
+int pmx_launch_cc_dense(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
+                        uint64_t nbits, uint32_t max_shift, uint32_t read_len, bool do_ncc,
+                        u64 *d_out, uint32_t out_stride);
+// out[k] += sum_j M[j] & M[j+k], k = 0..max_lag
+int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_out);
+// mlen_by_shift[d] = autocorr[|read_len - 1 - d|], d = 0..max_shift
+int pmx_launch_mlen_map(pmx_ctx *ctx, const u64 *d_autocorr, uint32_t max_shift, uint32_t read_len, u64 *d_mlen);

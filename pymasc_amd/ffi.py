@@ -1,0 +1,249 @@
+"""ctypes binding of libpymasc_hip.so (include/pymasc_amd.h).
+
+There is NO CPU fallback: if the library is missing it is built with hipcc, and if no MI355X is
+visible ``Context()`` raises ``PmxError`` -- the product path fails loudly instead of computing on
+the host.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+
+PMX_ROW_NCC_CCBINS = 0
+PMX_ROW_MSCC_FSUM = 1
+PMX_ROW_MSCC_RSUM = 2
+PMX_ROW_MSCC_CCBINS = 3
+PMX_ROW_MLEN = 4
+PMX_ROW_SCALARS = 5
+PMX_NROWS = 6
+
+PMX_FLAG_SKIP_NCC = 1
+PMX_FLAG_FORCE_DENSE = 2
+PMX_FLAG_FORCE_SPARSE = 4
+
+PMX_PATH_DENSE = 1
+PMX_PATH_SPARSE = 2
+
+PMX_KERNEL_CC_DENSE = 0
+PMX_KERNEL_CC_SPARSE = 1
+PMX_KERNEL_AUTOCORR = 2
+PMX_KERNEL_COUNT = 3
+
+# every symbol include/pymasc_amd.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "pmx_last_error", "pmx_version", "pmx_device_count",
+    "pmx_ctx_create", "pmx_ctx_destroy", "pmx_ctx_sync",
+    "pmx_bits_alloc", "pmx_bits_free", "pmx_bits_clear", "pmx_bits_upload", "pmx_bits_download",
+    "pmx_bits_set_positions", "pmx_bits_set_positions_dev", "pmx_bits_set_regions", "pmx_bits_set_regions_dev",
+    "pmx_bits_count",
+    "pmx_cc_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
+    "pmx_ctx_set_profiling", "pmx_ctx_reset_kernel_times", "pmx_ctx_kernel_time", "pmx_kernel_name",
+]
+
+
+class PmxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pymasc_amd HIP library error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the C-ABI library (building it in-tree first if needed) and declare prototypes."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("PYMASC_AMD_LIB") or _build.LIB
+    if path is None and not os.environ.get("PYMASC_AMD_LIB"):
+        _build.build()
+    L = ctypes.CDLL(p)
+    vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    L.pmx_last_error.restype = ctypes.c_char_p
+    L.pmx_last_error.argtypes = []
+    L.pmx_version.restype = i32
+    L.pmx_device_count.argtypes = [ctypes.POINTER(i32)]
+    L.pmx_ctx_create.argtypes = [i32, vp, ctypes.POINTER(vp)]
+    L.pmx_ctx_destroy.argtypes = [vp]
+    L.pmx_ctx_sync.argtypes = [vp]
+    L.pmx_bits_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
+    L.pmx_bits_free.argtypes = [vp, vp]
+    L.pmx_bits_clear.argtypes = [vp, vp, u64]
+    L.pmx_bits_upload.argtypes = [vp, vp, vp, u64]
+    L.pmx_bits_download.argtypes = [vp, vp, vp, u64]
+    L.pmx_bits_set_positions.argtypes = [vp, vp, u64, vp, u64]
+    L.pmx_bits_set_positions_dev.argtypes = [vp, vp, u64, vp, u64]
+    L.pmx_bits_set_regions.argtypes = [vp, vp, u64, vp, vp, u64]
+    L.pmx_bits_set_regions_dev.argtypes = [vp, vp, u64, vp, vp, u64]
+    L.pmx_bits_count.argtypes = [vp, vp, u64, ctypes.POINTER(u64)]
+    L.pmx_cc_dev.argtypes = [vp, vp, vp, vp, u64, u32, u32, u32, vp]
+    L.pmx_calc_correlation.argtypes = [vp, vp, vp, vp, u64, u32, u32, u32, vp]
+    L.pmx_mappable_len_dev.argtypes = [vp, vp, u64, u32, u32, vp]
+    L.pmx_mappable_len.argtypes = [vp, vp, u64, u32, u32, vp]
+    L.pmx_ctx_set_profiling.argtypes = [vp, i32]
+    L.pmx_ctx_reset_kernel_times.argtypes = [vp]
+    L.pmx_ctx_kernel_time.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
+    L.pmx_kernel_name.restype = ctypes.c_char_p
+    L.pmx_kernel_name.argtypes = [i32]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int and name not in ("pmx_version",):
+            fn.restype = i32
+    if path is None:
+        _lib = L
+    return L
+
+
+def _check(L, rc: int):
+    if rc != 0:
+        raise PmxError(rc, L.pmx_last_error().decode("utf-8", "replace"))
+
+
+def nwords(nbits: int) -> int:
+    return (int(nbits) + 63) // 64
+
+
+def _np_ptr(a: Optional[np.ndarray], dtype) -> Optional[int]:
+    if a is None:
+        return None
+    if a.dtype != dtype or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError(f"expected C-contiguous {np.dtype(dtype).name} array")
+    return a.ctypes.data
+
+
+class Context:
+    """One per worker process / GPU. Thin object wrapper over the pmx_ctx handle."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._L = load_library()
+        h = ctypes.c_void_p()
+        _check(self._L, self._L.pmx_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None,
+                                               ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pmx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        _check(self._L, self._L.pmx_ctx_sync(self._h))
+
+    # -- device bit-vectors (raw device pointers as ints)
+    def bits_alloc(self, nbits: int) -> int:
+        p = ctypes.c_void_p()
+        _check(self._L, self._L.pmx_bits_alloc(self._h, int(nbits), ctypes.byref(p)))
+        return p.value
+
+    def bits_free(self, d_words: int):
+        _check(self._L, self._L.pmx_bits_free(self._h, ctypes.c_void_p(d_words)))
+
+    def bits_clear(self, d_words: int, nbits: int):
+        _check(self._L, self._L.pmx_bits_clear(self._h, ctypes.c_void_p(d_words), int(nbits)))
+
+    def bits_upload(self, d_words: int, h_words: np.ndarray, nbits: int):
+        assert h_words.size >= nwords(nbits)
+        _check(self._L, self._L.pmx_bits_upload(self._h, ctypes.c_void_p(d_words), _np_ptr(h_words, np.uint64),
+                                                int(nbits)))
+
+    def bits_download(self, d_words: int, nbits: int) -> np.ndarray:
+        out = np.empty(nwords(nbits), dtype=np.uint64)
+        _check(self._L, self._L.pmx_bits_download(self._h, ctypes.c_void_p(d_words), out.ctypes.data, int(nbits)))
+        return out
+
+    def bits_set_positions(self, d_words: int, nbits: int, pos: np.ndarray):
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        _check(self._L, self._L.pmx_bits_set_positions(self._h, ctypes.c_void_p(d_words), int(nbits),
+                                                       pos.ctypes.data, pos.size))
+
+    def bits_set_positions_dev(self, d_words: int, nbits: int, d_pos: int, n: int):
+        _check(self._L, self._L.pmx_bits_set_positions_dev(self._h, ctypes.c_void_p(d_words), int(nbits),
+                                                           ctypes.c_void_p(d_pos), int(n)))
+
+    def bits_set_regions(self, d_words: int, nbits: int, first: np.ndarray, last: np.ndarray):
+        first = np.ascontiguousarray(first, dtype=np.int64)
+        last = np.ascontiguousarray(last, dtype=np.int64)
+        assert first.size == last.size
+        _check(self._L, self._L.pmx_bits_set_regions(self._h, ctypes.c_void_p(d_words), int(nbits),
+                                                     first.ctypes.data, last.ctypes.data, first.size))
+
+    def bits_set_regions_dev(self, d_words: int, nbits: int, d_first: int, d_last: int, n: int):
+        _check(self._L, self._L.pmx_bits_set_regions_dev(self._h, ctypes.c_void_p(d_words), int(nbits),
+                                                         ctypes.c_void_p(d_first), ctypes.c_void_p(d_last), int(n)))
+
+    def bits_count(self, d_words: int, nbits: int) -> int:
+        out = ctypes.c_uint64()
+        _check(self._L, self._L.pmx_bits_count(self._h, ctypes.c_void_p(d_words), int(nbits), ctypes.byref(out)))
+        return int(out.value)
+
+    # -- hot path
+    def cc_dev(self, d_F: int, d_R: int, d_M: Optional[int], nbits: int, max_shift: int, read_len: int,
+               flags: int, d_out: int):
+        _check(self._L, self._L.pmx_cc_dev(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R),
+                                           ctypes.c_void_p(d_M) if d_M else None, int(nbits), int(max_shift),
+                                           int(read_len), int(flags), ctypes.c_void_p(d_out)))
+
+    def calc_correlation(self, F: np.ndarray, R: np.ndarray, M: Optional[np.ndarray], nbits: int, max_shift: int,
+                         read_len: int, flags: int = 0) -> np.ndarray:
+        """Host buffers in, result block [PMX_NROWS, max_shift+1] uint64 out."""
+        nw = nwords(nbits)
+        assert F.size >= nw and R.size >= nw and (M is None or M.size >= nw)
+        out = np.zeros((PMX_NROWS, int(max_shift) + 1), dtype=np.uint64)
+        _check(self._L, self._L.pmx_calc_correlation(self._h, _np_ptr(F, np.uint64), _np_ptr(R, np.uint64),
+                                                     _np_ptr(M, np.uint64), int(nbits), int(max_shift),
+                                                     int(read_len), int(flags), out.ctypes.data))
+        return out
+
+    def mappable_len_dev(self, d_M: int, nbits: int, max_shift: int, flags: int, d_out: int):
+        _check(self._L, self._L.pmx_mappable_len_dev(self._h, ctypes.c_void_p(d_M), int(nbits), int(max_shift),
+                                                     int(flags), ctypes.c_void_p(d_out)))
+
+    def mappable_len(self, M: np.ndarray, nbits: int, max_shift: int, flags: int = 0) -> np.ndarray:
+        assert M.size >= nwords(nbits)
+        out = np.zeros(int(max_shift) + 1, dtype=np.uint64)
+        _check(self._L, self._L.pmx_mappable_len(self._h, _np_ptr(M, np.uint64), int(nbits), int(max_shift),
+                                                 int(flags), out.ctypes.data))
+        return out
+
+    # -- measurement
+    def set_profiling(self, on: bool):
+        _check(self._L, self._L.pmx_ctx_set_profiling(self._h, int(bool(on))))
+
+    def reset_kernel_times(self):
+        _check(self._L, self._L.pmx_ctx_reset_kernel_times(self._h))
+
+    def kernel_time(self, kernel_id: int):
+        ms = ctypes.c_double()
+        n = ctypes.c_uint64()
+        _check(self._L, self._L.pmx_ctx_kernel_time(self._h, int(kernel_id), ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def kernel_name(self, kernel_id: int) -> str:
+        return self._L.pmx_kernel_name(int(kernel_id)).decode()
+
+
+def device_count() -> int:
+    L = load_library()
+    n = ctypes.c_int()
+    _check(L, L.pmx_device_count(ctypes.byref(n)))
+    return int(n.value)
