@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: shifts x genome-bp / sec of the per-chromosome strand cross-correlation
+(NCC + MaSC) on synthetic hg38-shaped bit-vectors, max_shift = 1000 (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (pmx_cc_dev per chromosome) over a batch of N synthetic
+samples x 24 hg38-length chromosomes whose F/R/M bit-vectors are already resident in HBM, the
+chromosome jobs LPT-sharded over the N ranks (one sample's worth of work per GPU: weak scaling),
+followed by the result exchange (all-gather of per-chromosome rows + all-reduce of totals over RCCL).
+Rank 0 prints ONE JSON line.  ENCFF000VPI.bam (BASELINE configs 2-3) is not available offline, so the
+same-shape synthetic workload stands in, as BASELINE.md section 4 prescribes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--max-shift", type=int, default=1000)
+    ap.add_argument("--read-len", type=int, default=36)
+    ap.add_argument("--density", type=float, default=0.005, help="read start density per strand (BASELINE.md config 4)")
+    ap.add_argument("--mode", choices=["both", "ncc"], default="both",
+                    help="both = NCC + MaSC with mappability (config 4); ncc = naive CC only (config 2 shape)")
+    ap.add_argument("--path", choices=["auto", "dense", "sparse"], default="auto")
+    ap.add_argument("--chroms", type=int, default=24, help="use only the first K hg38 chromosomes (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mbp", type=float, default=16.0, help="bp per CPU-baseline slice, in Mbp")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(ctx, vecs, S, L, with_m, sample_bp, threads):
+    """Times the oracle (C restatement of the reference's per-shift full-vector passes) on host cores:
+    one chromosome slice per thread, like `pymasc -p <threads>`.  kind = "port"."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import model as oracle
+    oracle.lib()
+    slices = []
+    for i in range(threads):
+        v = vecs[i % len(vecs)]
+        nb = int(min(v.length, sample_bp)) + L + S + 100
+        nw = (nb + 63) // 64
+        F = ctx.bits_download(v.F.data_ptr(), nb)[:nw].copy()
+        R = ctx.bits_download(v.R.data_ptr(), nb)[:nw].copy()
+        M = ctx.bits_download(v.M.data_ptr(), nb)[:nw].copy() if with_m else None
+        top = nb & 63
+        if top:
+            mask = np.uint64((1 << top) - 1)
+            F[-1] &= mask
+            R[-1] &= mask
+            if M is not None:
+                M[-1] &= mask
+        slices.append((F, R, M, nb, nb - (L + S + 100)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda s: oracle.calc_correlation(s[0], s[1], s[2], s[3], S, L), slices))
+    dt = time.perf_counter() - t0
+    work = (S + 1) * sum(s[4] for s in slices)
+    return {"value": work / dt, "unit": "shifts*bp/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} slices x {slices[0][4] / 1e6:.1f} Mbp of the same synthetic chromosomes, "
+                      f"{'NCC+MSCC' if with_m else 'NCC'}, max_shift={S}, one slice per thread, {dt:.1f}s wall",
+            "seconds": dt}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from pymasc_amd import ffi, sharding, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    S, L = args.max_shift, args.read_len
+    with_m = args.mode == "both"
+    flags = {"auto": 0, "dense": ffi.PMX_FLAG_FORCE_DENSE, "sparse": ffi.PMX_FLAG_FORCE_SPARSE}[args.path]
+    ctx = ffi.Context(local_rank)
+
+    chroms = synth.HG38[:args.chroms]
+    # batch = `world` samples x chromosomes; LPT over ranks (identical on every rank)
+    jobs = [(s, i) for s in range(world) for i in range(len(chroms))]
+    costs = [chroms[i][1] for (_s, i) in jobs]
+    assignment = sharding.lpt_assign(costs, world)
+    mine = assignment[rank]
+    max_slots = max(len(a) for a in assignment)
+
+    t_gen = time.perf_counter()
+    vecs = []
+    for j in mine:
+        s, i = jobs[j]
+        name, length = chroms[i]
+        vecs.append(synth.make_chromosome(ctx, device, f"{name}.s{s}", length, S, L, 0xC0FFEE + i + 1000 * s,
+                                          density=args.density, with_m=with_m))
+    t_gen = time.perf_counter() - t_gen
+    local_bp = sum(v.length for v in vecs)
+    total_bp = sum(costs)
+
+    stride = S + 1
+    d_rows = torch.zeros((max_slots, ffi.PMX_NROWS, stride), dtype=torch.int64, device=device)
+
+    def step():
+        for slot, v in enumerate(vecs):
+            ctx.cc_dev(v.F.data_ptr(), v.R.data_ptr(), v.M.data_ptr() if with_m else None, v.nbits, S, L, flags,
+                       d_rows[slot].data_ptr())
+        ctx.sync()
+        return sharding.exchange_results(d_rows, assignment, len(jobs))
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(True)
+    ctx.reset_kernel_times()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows, totals = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # consistency of the exchange: all-reduced totals == sum of gathered rows (integers, exact)
+    assert torch.equal(rows.sum(dim=0), totals), "result exchange mismatch"
+
+    # dominant kernel + roofline from the live HIP-event timings on this rank's stream
+    ktimes = {k: ctx.kernel_time(k) for k in range(ffi.PMX_KERNEL_COUNT)}
+    dom = max(ktimes, key=lambda k: ktimes[k][0])
+    dom_ms, dom_n = ktimes[dom]
+    vec_bytes = sum((v.nbits + 7) // 8 for v in vecs)
+    out_bytes = 8 * stride
+    per_pass = {
+        ffi.PMX_KERNEL_CC_DENSE: (3 if with_m else 2) * vec_bytes + (4 if with_m else 1) * out_bytes * len(vecs),
+        ffi.PMX_KERNEL_CC_SPARSE: (3 if with_m else 2) * vec_bytes + (4 if with_m else 1) * out_bytes * len(vecs),
+        ffi.PMX_KERNEL_AUTOCORR: vec_bytes + out_bytes * len(vecs),
+    }[dom]
+    alg_bytes_per_launch = per_pass * args.steps / max(dom_n, 1)
+    avg_ms = dom_ms / max(dom_n, 1)
+    achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    kernel_ms_per_step = {ctx.kernel_name(k): round(ktimes[k][0] / args.steps, 4) for k in ktimes if ktimes[k][1]}
+
+    work_per_step = (S + 1) * total_bp
+    value = work_per_step * args.steps / elapsed
+
+    result = {
+        "metric": "shifts*genome-bp/sec (whole node), hg38 max_shift=1000; HBM-BW fraction",
+        "value": value,
+        "unit": "shifts*bp/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE config 4: synthetic hg38-shaped F/R"
+                         + ("+mappability" if with_m else "") + f" bit-vectors, {len(chroms)} chromosomes x "
+                         f"{world} sample(s), {total_bp / 1e9:.3f} Gbp total, max_shift={S}, read_len={L}, "
+                         f"read density {args.density}/strand, "
+                         + ("NCC+MSCC" if with_m else "NCC only")
+                         + "; stands in for ENCFF000VPI.bam (configs 2-3), which is not available offline"),
+            "mode": args.mode,
+            "kernel_path": args.path,
+            "parallelism": f"chromosome jobs LPT-sharded over {world} GPU(s); all-gather rows + all-reduce totals",
+            "inputs_resident_in_hbm": True,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": ctx.kernel_name(dom),
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "avg_launch_ms": avg_ms,
+            "launches": dom_n,
+            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+        },
+        "kernel_ms_per_step": kernel_ms_per_step,
+        "gen_seconds": round(t_gen, 2),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+        result["cpu_baseline"] = cpu_baseline(ctx, vecs, S, L, with_m, args.cpu_sample_mbp * 1e6, threads)
+        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+    else:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+"""Result payloads of the calculator boundary.
+
+Field-for-field value-equal to the reference's dataclasses (PyMaSC/result.py:68-118 per-chromosome,
+:121-126 BothChromResult, :144-257 empty placeholders, :260-298 genome-wide) so that the callers
+(PyMaSC/handler/calc.py:159-161, handler/worker.py:226-234, stats.py:424-451) can consume them
+unchanged; all are plain picklable dataclasses (they cross a multiprocessing.Queue, worker.py:234).
+
+The integer fields come from the GPU; ``calc_cc`` turns them into float64 on the host with the SAME
+operation order as PyMaSC/result.py:42-65 (binomial-variance normalisation), which is what holds the
+reference's decimal=15 table tolerance.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+
+def normalised_cc(forward_sum, reverse_sum, ccbins, totlen, denom) -> np.ndarray:
+    """(ccbins/denom - f*r) / sqrt(f(1-f) r(1-r)) with f = forward_sum/totlen, r = reverse_sum/totlen.
+
+    Mirrors PyMaSC/result.py:42-65 including the all-zero -> all-NaN rule (:54-55)."""
+    bins = np.array(ccbins, dtype=np.int64)
+    if bins.sum() == 0:
+        return np.full_like(bins, np.nan, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fmean = forward_sum / totlen
+        rmean = reverse_sum / totlen
+        fvar = fmean * (1 - fmean)
+        rvar = rmean * (1 - rmean)
+        prod = fmean * rmean
+        geo = (fvar * rvar) ** 0.5
+        return (bins / denom - prod) / geo
+
+
+@dataclass
+class NCCResult:
+    """Naive cross-correlation of one chromosome (reference: result.py:68-89)."""
+    max_shift: int
+    read_len: int
+    genomelen: int
+    forward_sum: int
+    reverse_sum: int
+    forward_read_len_sum: int
+    reverse_read_len_sum: int
+    ccbins: Union[List[float], np.ndarray]
+    cc: np.ndarray = field(init=False, default=None)
+
+    def calc_cc(self) -> None:
+        denom = self.genomelen - np.array(range(self.max_shift + 1), dtype=np.float64)
+        self.cc = normalised_cc(float(self.forward_sum), float(self.reverse_sum),
+                                self.ccbins[:self.max_shift + 1], self.genomelen, denom)
+
+
+@dataclass
+class MSCCResult:
+    """Mappability-sensitive cross-correlation of one chromosome (reference: result.py:92-118).
+
+    ``mappable_len`` is indexed by LAG like the reference's list (mscc.pyx:271,292-298)."""
+    max_shift: int
+    read_len: int
+    genomelen: int
+    forward_sum: Union[List[int], np.ndarray]
+    reverse_sum: Union[List[int], np.ndarray]
+    forward_read_len_sum: Optional[int]
+    reverse_read_len_sum: Optional[int]
+    ccbins: Union[List[float], np.ndarray]
+    mappable_len: Optional[Union[Tuple[int, ...], List[Optional[int]]]]
+    cc: np.ndarray = field(init=False, default=None)
+
+    def calc_cc(self) -> None:
+        assert self.mappable_len is not None, "mappable_len must be set before calculating CC."
+        lag = np.array(self.mappable_len, dtype=np.float64)
+        # lag table -> per-shift denominator T[d] = mappable_len[|d - (L-1)|]  (result.py:107-110)
+        totlen = np.concatenate((lag[:self.read_len][::-1], lag[1:]))[:self.max_shift + 1]
+        self.cc = normalised_cc(np.array(self.forward_sum[:self.max_shift + 1], dtype=np.float64),
+                                np.array(self.reverse_sum[:self.max_shift + 1], dtype=np.float64),
+                                self.ccbins[:self.max_shift + 1], totlen, totlen)
+
+
+@dataclass
+class BothChromResult:
+    """What a worker reports per chromosome (reference: result.py:121-126, mscc.pyx:441-447)."""
+    chrom: Optional[NCCResult]
+    mappable_chrom: Optional[MSCCResult]
+
+
+class EmptyResult:
+    """Marker base of placeholders for chromosomes without reads (reference: result.py:129-141)."""
+
+
+@dataclass
+class EmptyNCCResult(EmptyResult, NCCResult):
+    @classmethod
+    def create_empty(cls, genome_length: int, max_shift: int, read_len: int) -> "EmptyNCCResult":
+        res = cls(max_shift=max_shift, read_len=read_len, genomelen=genome_length, forward_sum=0, reverse_sum=0,
+                  forward_read_len_sum=0, reverse_read_len_sum=0, ccbins=[0.0] * (max_shift + 1))
+        res.calc_cc()
+        return res
+
+
+@dataclass
+class EmptyMSCCResult(EmptyResult, MSCCResult):
+    @classmethod
+    def create_empty(cls, genome_length: int, max_shift: int, read_len: int) -> "EmptyMSCCResult":
+        res = cls(max_shift=max_shift, read_len=read_len, genomelen=genome_length,
+                  forward_sum=np.zeros(max_shift + 1, dtype=np.int64),
+                  reverse_sum=np.zeros(max_shift + 1, dtype=np.int64),
+                  forward_read_len_sum=0, reverse_read_len_sum=0, ccbins=[0.0] * (max_shift + 1),
+                  mappable_len=tuple([0] * (max_shift + 1)))
+        res.calc_cc()
+        return res
+
+
+@dataclass
+class EmptyBothChromResult(EmptyResult, BothChromResult):
+    @classmethod
+    def create_empty(cls, genome_length: int, max_shift: int, read_len: int) -> "EmptyBothChromResult":
+        return cls(chrom=EmptyNCCResult.create_empty(genome_length, max_shift, read_len),
+                   mappable_chrom=EmptyMSCCResult.create_empty(genome_length, max_shift, read_len))
+
+
+@dataclass
+class NCCGenomeWideResult:
+    genomelen: int
+    forward_read_len_sum: int
+    reverse_read_len_sum: int
+    forward_sum: int
+    reverse_sum: int
+    chroms: Dict[str, NCCResult]
+
+
+@dataclass
+class MSCCGenomeWideResult:
+    genomelen: int
+    forward_read_len_sum: int
+    reverse_read_len_sum: int
+    chroms: Dict[str, MSCCResult]
+
+
+@dataclass
+class BothGenomeWideResult:
+    genomelen: int
+    forward_read_len_sum: int
+    reverse_read_len_sum: int
+    forward_sum: int
+    reverse_sum: int
+    chroms: Dict[str, NCCResult]
+    mappable_chroms: Dict[str, MSCCResult]
+
+
+GenomeWideResult = Union[NCCGenomeWideResult, MSCCGenomeWideResult, BothGenomeWideResult]
+
+
+def _sum_ncc(results: Mapping[str, NCCResult]) -> NCCGenomeWideResult:
+    vals = list(results.values())
+    return NCCGenomeWideResult(
+        genomelen=sum(r.genomelen for r in vals),
+        forward_read_len_sum=sum(r.forward_read_len_sum for r in vals),
+        reverse_read_len_sum=sum(r.reverse_read_len_sum for r in vals),
+        forward_sum=sum(r.forward_sum for r in vals),
+        reverse_sum=sum(r.reverse_sum for r in vals),
+        chroms=dict(results))
+
+
+def _sum_mscc(results: Mapping[str, MSCCResult]) -> MSCCGenomeWideResult:
+    vals = list(results.values())
+    return MSCCGenomeWideResult(
+        genomelen=sum(r.genomelen for r in vals),
+        forward_read_len_sum=sum(r.forward_read_len_sum for r in vals),
+        reverse_read_len_sum=sum(r.reverse_read_len_sum for r in vals),
+        chroms=dict(results))
+
+
+def aggregate_results(results: Mapping[str, Any]) -> GenomeWideResult:
+    """Per-chromosome worker results -> genome-wide result (reference: result.py:301-356,360-464).
+
+    Integer totals are summed; the per-chromosome rows are KEPT because the reference's genome-wide
+    curve is a Fisher-z merge of per-chromosome cc (utils/calc.py:172-241), not a ratio of summed bins."""
+    if not results:
+        raise ValueError("Cannot aggregate empty results dictionary")
+    first = next(iter(results.values()))
+    if isinstance(first, BothChromResult):
+        real = [r for r in results.values() if not isinstance(r, EmptyResult)]
+        if all(r.chrom is None for r in real):
+            return _sum_mscc({c: r.mappable_chrom for c, r in results.items()})
+        if all(r.mappable_chrom is None for r in real):
+            return _sum_ncc({c: r.chrom for c, r in results.items()})
+        ncc = _sum_ncc({c: r.chrom for c, r in results.items()})
+        mscc = _sum_mscc({c: r.mappable_chrom for c, r in results.items()})
+        return BothGenomeWideResult(genomelen=ncc.genomelen, forward_read_len_sum=ncc.forward_read_len_sum,
+                                    reverse_read_len_sum=ncc.reverse_read_len_sum, forward_sum=ncc.forward_sum,
+                                    reverse_sum=ncc.reverse_sum, chroms=ncc.chroms, mappable_chroms=mscc.chroms)
+    if isinstance(first, NCCResult):
+        return _sum_ncc(results)
+    if isinstance(first, MSCCResult):
+        return _sum_mscc(results)
+    raise TypeError(f"Unknown result type: {type(first)}")

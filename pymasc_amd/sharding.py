@@ -1,0 +1,61 @@
+"""Multi-GPU layer: chromosome jobs -> ranks, and the result exchange.
+
+The reference parallelises over chromosomes with one worker process per chromosome task
+(PyMaSC/handler/calc.py:163-235, utils/calc.py:95-145) and ships each per-chromosome result to the
+parent over a multiprocessing.Queue (handler/worker.py:234).  Here: one process per GPU, chromosome
+jobs assigned longest-processing-time-first, no collective on the data path, and ONE exchange at the
+end: an all-gather of the per-chromosome result rows (the genome-wide curve is a Fisher-z merge of
+per-chromosome cc, PyMaSC/utils/calc.py:172-241, so the rows must be kept) plus an all-reduce(sum)
+of the genome-wide integer totals (mscc.pyx:238-239, stats.py:515-517).  Backend "nccl" is RCCL over
+xGMI on the GPU box; the same code runs on "gloo" with CPU tensors in the tests.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def lpt_assign(costs: Sequence[float], world_size: int) -> List[List[int]]:
+    """Longest-processing-time-first: job indices per rank, deterministic on every rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world_size
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        out[r].append(i)
+        loads[r] += costs[i]
+    return out
+
+
+def owner_table(assignment: List[List[int]], njobs: int) -> List[Tuple[int, int]]:
+    """job -> (rank, slot on that rank)."""
+    table = [(-1, -1)] * njobs
+    for r, jobs in enumerate(assignment):
+        for s, j in enumerate(jobs):
+            table[j] = (r, s)
+    return table
+
+
+def exchange_results(local_rows: torch.Tensor, assignment: List[List[int]], njobs: int,
+                     group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """local_rows: int64 [max_slots, nrows, stride], this rank's jobs in slot order (unused slots zero).
+
+    Returns (rows[njobs, nrows, stride] in job order on every rank, totals[nrows, stride] = sum over
+    all jobs, computed by all-reduce so it can be cross-checked against rows.sum(0))."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    max_slots = max(len(a) for a in assignment)
+    assert local_rows.shape[0] == max_slots
+    totals = local_rows.sum(dim=0)
+    if world == 1:
+        gathered = local_rows.unsqueeze(0)
+    else:
+        gathered = torch.empty((world,) + tuple(local_rows.shape), dtype=local_rows.dtype, device=local_rows.device)
+        dist.all_gather_into_tensor(gathered, local_rows.contiguous(), group=group)
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM, group=group)
+    table = owner_table(assignment, njobs)
+    idx_r = torch.tensor([t[0] for t in table], device=local_rows.device)
+    idx_s = torch.tensor([t[1] for t in table], device=local_rows.device)
+    rows = gathered[idx_r, idx_s]
+    return rows, totals

@@ -1,0 +1,171 @@
+"""Host logic of CCHipCalculator (feed / dedup / sortedness / flush / lag re-indexing / results) on
+CPU, with tests/fake_context.py standing in for the device, compared with the oracle's restatement of
+CCBitArrayCalculator and with the reference-generated vectors."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import model as oracle
+from pymasc_amd.calculator import CCHipCalculator
+from pymasc_amd.exceptions import ReadUnsortedError
+from pymasc_amd import result as R
+from . import fixtures as fx
+from .fake_context import FakeContext
+from .helpers import DictFeeder, assert_matches_oracle, feed_all
+
+CASES = json.load(open(os.path.join(fx.GOLDEN, "ref_successive_ncc.json")))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_ncc_against_reference_vectors(case):
+    names = [n for n, _ in case["chroms"]]
+    lens = [l for _, l in case["chroms"]]
+    calc = CCHipCalculator(case["max_shift"], 36, names, lens, context=FakeContext())
+    for name, pos, rev, rl in case["reads"]:
+        (calc.feed_reverse_read if rev else calc.feed_forward_read)(name, pos, rl)
+    calc.finishup_calculation()
+    whole = calc.get_whole_result()
+    exp = case["expected"]
+    assert isinstance(whole, R.NCCGenomeWideResult)
+    assert (whole.genomelen, whole.forward_sum, whole.reverse_sum) == (exp["genomelen"], exp["forward_sum"],
+                                                                       exp["reverse_sum"])
+    assert set(whole.chroms) == set(exp["chroms"])
+    for ch, e in exp["chroms"].items():
+        r = whole.chroms[ch]
+        assert (r.forward_sum, r.reverse_sum) == (e["forward_sum"], e["reverse_sum"])
+        assert (r.forward_read_len_sum, r.reverse_read_len_sum) == (e["forward_read_len_sum"],
+                                                                    e["reverse_read_len_sum"])
+        assert [int(x) for x in r.ccbins] == e["ccbins"]
+        ecc = np.array([np.nan if x is None else x for x in e["cc"]])
+        m = ~np.isnan(ecc)
+        assert np.array_equal(np.isnan(r.cc), ~m)
+        np.testing.assert_allclose(r.cc[m], ecc[m], rtol=0, atol=1e-15)
+
+
+def _small_mscc_setup(seed=3, skip_ncc=False):
+    rng = np.random.default_rng(seed)
+    chroms = [("a", 20000), ("b", 12000), ("c", 9000), ("d", 4000)]
+    tracks = {}
+    for name, ln in chroms[:3]:      # "d" has no mappability track -> KeyError path
+        iv, p = [], int(rng.integers(0, 50))
+        while p < ln - 400:
+            on = int(rng.integers(1, 300))
+            iv.append((p, p + on, float(rng.choice([0.5, 1.0, 1.0, 1.0]))))
+            p += on + int(rng.integers(1, 120))
+        tracks[name] = iv
+    reads = []
+    for name, ln in [chroms[0], chroms[2], chroms[3]]:   # "b" gets no reads
+        n = 1500
+        pos = np.sort(rng.integers(1, ln - 80, size=n))
+        pos[rng.integers(0, n, 100)] = pos[rng.integers(0, n, 100)]
+        pos.sort()
+        for p, rv, rl in zip(pos.tolist(), (rng.random(n) < 0.5).tolist(), rng.choice([30, 36, 50], n).tolist()):
+            reads.append((rv, name, p, rl))
+    names = [n for n, _ in chroms]
+    lens = [l for _, l in chroms]
+    return names, lens, tracks, reads
+
+
+@pytest.mark.parametrize("skip_ncc", [False, True])
+def test_both_against_oracle_calculator(skip_ncc):
+    names, lens, tracks, reads = _small_mscc_setup(skip_ncc=skip_ncc)
+    S, L = 120, 36
+    calc = CCHipCalculator(S, L, names, lens, bwfeeder=DictFeeder(tracks), skip_ncc=skip_ncc, context=FakeContext())
+    ocalc = oracle.OracleCalculator(S, L, names, lens, mappability={
+        c: [x for x in iv if np.float32(x[2]) >= 1] for c, iv in tracks.items()}, skip_ncc=skip_ncc)
+    feed_all(calc, reads)
+    feed_all(ocalc, reads)
+    calc.finishup_calculation()
+    ocalc.finishup_calculation()
+    assert_matches_oracle(calc, ocalc, names)
+    whole = calc.get_whole_result()
+    assert isinstance(whole, R.BothGenomeWideResult)
+    assert set(whole.chroms) == set(names) and set(whole.mappable_chroms) == set(names)
+    # read-less chromosome with a track: lag table of length S+1 (mscc.pyx:207-215); without: zeros
+    assert len(whole.mappable_chroms["b"].mappable_len) == S + 1 and sum(whole.mappable_chroms["b"].mappable_len) > 0
+    assert isinstance(whole.mappable_chroms["b"], R.EmptyMSCCResult)
+    # chromosome with reads but no track: NCC only (mscc.pyx:254-259), placeholder MSCC from _fill_result
+    assert isinstance(whole.mappable_chroms["d"], R.EmptyMSCCResult)
+    assert np.isnan(whole.mappable_chroms["d"].cc).all()
+    # results must survive the worker -> parent queue (handler/worker.py:234)
+    back = pickle.loads(pickle.dumps(calc.get_result("a")))
+    assert back.mappable_chrom.ccbins == calc.get_result("a").mappable_chrom.ccbins
+
+
+def test_worker_style_flush_per_chromosome():
+    """handler/worker.py:217-234: feed one chromosome, flush(chrom), get_result(chrom); a chromosome
+    without reads is flushed too and must come back as placeholders."""
+    names, lens, tracks, reads = _small_mscc_setup(seed=9)
+    S, L = 64, 36
+    calc = CCHipCalculator(S, L, names, lens, bwfeeder=DictFeeder(tracks), context=FakeContext())
+    ocalc = oracle.OracleCalculator(S, L, names, lens, mappability={
+        c: [x for x in iv if np.float32(x[2]) >= 1] for c, iv in tracks.items()})
+    for chrom in names:
+        mine = [r for r in reads if r[1] == chrom]
+        feed_all(calc, mine)
+        feed_all(ocalc, mine)
+        calc.flush(chrom)
+        ocalc.flush(chrom)
+        res = calc.get_result(chrom)
+        assert res.chrom is not None
+    assert_matches_oracle(calc, ocalc, names)
+    agg = R.aggregate_results({c: calc.get_result(c) for c in names})
+    assert isinstance(agg, R.BothGenomeWideResult)
+    assert agg.genomelen == sum(lens)
+    assert agg.forward_sum == calc.forward_sum and agg.reverse_sum == calc.reverse_sum
+
+
+def test_unsorted_reads_raise():
+    calc = CCHipCalculator(50, 36, ["a", "b"], [5000, 5000], context=FakeContext())
+    calc.feed_forward_read("a", 100, 36)
+    with pytest.raises(ReadUnsortedError):
+        calc.feed_reverse_read("a", 99, 36)
+    calc = CCHipCalculator(50, 36, ["a", "b"], [5000, 5000], context=FakeContext())
+    calc.feed_forward_read("a", 100, 36)
+    calc.feed_forward_read("b", 10, 36)
+    with pytest.raises(ReadUnsortedError):      # a finished chromosome reappears (mscc.pyx:354-355)
+        calc.feed_forward_read("a", 200, 36)
+    assert issubclass(ReadUnsortedError, IndexError)
+
+
+def test_get_result_unknown_chrom_is_keyerror():
+    calc = CCHipCalculator(50, 36, ["a"], [5000], context=FakeContext())
+    with pytest.raises(KeyError):
+        calc.get_result("zzz")
+
+
+def test_bulk_feed_equals_per_read_feed():
+    names, lens, tracks, reads = _small_mscc_setup(seed=21)
+    S, L = 80, 36
+    one = CCHipCalculator(S, L, names, lens, bwfeeder=DictFeeder(tracks), context=FakeContext())
+    two = CCHipCalculator(S, L, names, lens, bwfeeder=DictFeeder(tracks), context=FakeContext())
+    feed_all(one, reads)
+    for chrom in names:
+        mine = [r for r in reads if r[1] == chrom]
+        if mine:
+            two.feed_reads(chrom, np.array([r[2] for r in mine]), np.array([r[3] for r in mine]),
+                           np.array([r[0] for r in mine]))
+    one.finishup_calculation()
+    two.finishup_calculation()
+    for c in names:
+        a, b = one.get_result(c), two.get_result(c)
+        assert a.chrom.ccbins == b.chrom.ccbins and a.chrom.forward_read_len_sum == b.chrom.forward_read_len_sum
+        assert list(a.mappable_chrom.ccbins) == list(b.mappable_chrom.ccbins)
+
+
+def test_calc_cc_formulas():
+    r = R.NCCResult(max_shift=3, read_len=5, genomelen=1000, forward_sum=40, reverse_sum=50,
+                    forward_read_len_sum=0, reverse_read_len_sum=0, ccbins=[5, 4, 3, 2])
+    r.calc_cc()
+    np.testing.assert_array_equal(r.cc, oracle.ncc_cc(40, 50, [5, 4, 3, 2], 1000, 3))
+    e = R.EmptyNCCResult.create_empty(1000, 3, 5)
+    assert np.isnan(e.cc).all() and e.ccbins == [0.0] * 4
+    m = R.MSCCResult(max_shift=5, read_len=3, genomelen=1000, forward_sum=[9, 8, 7, 6, 5, 4],
+                     reverse_sum=[5, 6, 7, 8, 9, 9], forward_read_len_sum=0, reverse_read_len_sum=0,
+                     ccbins=[1, 2, 3, 2, 1, 0], mappable_len=[500, 490, 480, 470])
+    m.calc_cc()
+    np.testing.assert_array_equal(m.cc, oracle.mscc_cc([9, 8, 7, 6, 5, 4], [5, 6, 7, 8, 9, 9],
+                                                       [1, 2, 3, 2, 1, 0], [500, 490, 480, 470], 5, 3))
