@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--path", choices=["auto", "dense", "sparse"], default="auto")
     ap.add_argument("--chroms", type=int, default=24, help="use only the first K hg38 chromosomes (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mbp", type=float, default=16.0, help="bp per CPU-baseline slice, in Mbp")
+    ap.add_argument("--cpu-sample-mbp", type=float, default=128.0, help="bp per CPU-baseline slice, in Mbp")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 
