@@ -47,9 +47,10 @@ extern "C" {
 #define PMX_NROWS           6
 
 /* flags for pmx_cc_dev / pmx_calc_correlation */
-#define PMX_FLAG_SKIP_NCC     1u  /* skip_ncc=True (mscc.pyx:235,313): row 0 and scalars 0,1 left zero */
-#define PMX_FLAG_FORCE_DENSE  2u  /* always use the dense word-parallel kernels                */
-#define PMX_FLAG_FORCE_SPARSE 4u  /* always use the set-bit driven window kernels             */
+#define PMX_FLAG_SKIP_NCC     1u  /* skip_ncc=True (mscc.pyx:235,313): row 0 left zero (popcounts still reported) */
+#define PMX_FLAG_FORCE_DENSE  2u  /* use the dense word-parallel kernels (one lane per shift)          */
+#define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven window kernels (error if unsupported) */
+/* default (neither): set-bit kernels when 3 <= max_shift <= 1023, dense kernels otherwise */
 
 #define PMX_PATH_DENSE  1
 #define PMX_PATH_SPARSE 2

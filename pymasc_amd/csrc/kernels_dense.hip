@@ -42,8 +42,17 @@ template <bool HAS_M, bool DO_NCC>
 __global__ void __launch_bounds__(256) k_cc_dense(const u64 *__restrict__ F, const u64 *__restrict__ R,
                                                   const u64 *__restrict__ M, uint64_t nbits, uint64_t nwords,
                                                   u32 max_shift, int32_t c, u32 ntiles, u64 *__restrict__ out,
-                                                  u32 out_stride)
+                                                  u32 out_stride, const u64 *__restrict__ select, u32 select_mode)
 {
+    // select_mode 1: run only when the occupancy vectors are NOT sparse (the set-bit kernel takes the other
+    // case); select[0..1] = popcount(F), popcount(R) written earlier on this stream.  2: mark the path taken.
+    if (select_mode == 1) {
+        const u64 nset = select[0] + select[1];
+        if (nset * 8 <= nbits) return;
+    }
+    if (select_mode && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        out[(size_t)PMX_ROW_SCALARS * out_stride + 3] = PMX_PATH_DENSE;
+
     __shared__ u64 sF[DENSE_TW];
     __shared__ u64 sM[HAS_M ? DENSE_TW : 1];
     __shared__ u64 sR[DENSE_TW + DENSE_PAD];
@@ -132,7 +141,7 @@ static void dense_grid(pmx_ctx *ctx, uint64_t nwords, u32 max_shift, u32 *ntiles
 
 int pmx_launch_cc_dense(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
                         uint64_t nbits, uint32_t max_shift, uint32_t read_len, bool do_ncc,
-                        u64 *d_out, uint32_t out_stride)
+                        u64 *d_out, uint32_t out_stride, const u64 *d_select, uint32_t select_mode)
 {
     const uint64_t nwords = (nbits + 63) / 64;
     u32 ntiles;
@@ -146,13 +155,13 @@ int pmx_launch_cc_dense(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, 
     if (rc) return rc;
     if (d_M && do_ncc)
         hipLaunchKernelGGL((k_cc_dense<true, true>), grid, dim3(256), 0, ctx->stream, F, R, M, nbits, nwords,
-                           max_shift, c, ntiles, d_out, out_stride);
+                           max_shift, c, ntiles, d_out, out_stride, d_select, select_mode);
     else if (d_M)
         hipLaunchKernelGGL((k_cc_dense<true, false>), grid, dim3(256), 0, ctx->stream, F, R, M, nbits, nwords,
-                           max_shift, c, ntiles, d_out, out_stride);
+                           max_shift, c, ntiles, d_out, out_stride, d_select, select_mode);
     else
         hipLaunchKernelGGL((k_cc_dense<false, true>), grid, dim3(256), 0, ctx->stream, F, R, M, nbits, nwords,
-                           max_shift, c, ntiles, d_out, out_stride);
+                           max_shift, c, ntiles, d_out, out_stride, d_select, select_mode);
     PMX_CHECK_LAUNCH("k_cc_dense");
     return pmx_prof_end(ctx, &tl);
 }
@@ -169,7 +178,7 @@ int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits,
     if (rc) return rc;
     // row PMX_ROW_NCC_CCBINS (= 0) of an out block with stride 0 offset: out[k] += sum_j M[j] & M[j+k]
     hipLaunchKernelGGL((k_cc_dense<false, true>), grid, dim3(256), 0, ctx->stream, M, M, (const u64 *)nullptr,
-                       nbits, nwords, max_lag, 0, ntiles, d_out, max_lag + 1);
+                       nbits, nwords, max_lag, 0, ntiles, d_out, max_lag + 1, (const u64 *)nullptr, 0u);
     PMX_CHECK_LAUNCH("k_cc_dense(autocorr)");
     return pmx_prof_end(ctx, &tl);
 }

@@ -67,6 +67,8 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->profiling = false;
     ctx->d_scratch = nullptr;
     ctx->scratch_words = 0;
+    ctx->d_slab = nullptr;
+    ctx->slab_words = 0;
     ctx->d_out_stage = nullptr;
     ctx->out_stage_words = 0;
     for (int i = 0; i < 3; i++) {
@@ -111,6 +113,7 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     }
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_slab) (void)hipFree(ctx->d_slab);
     if (ctx->d_out_stage) (void)hipFree(ctx->d_out_stage);
     for (int i = 0; i < 3; i++)
         if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
@@ -135,6 +138,20 @@ int pmx_ensure_scratch(pmx_ctx *ctx, size_t words)
     size_t want = words < 4096 ? 4096 : words;
     PMX_HIP(hipMalloc((void **)&ctx->d_scratch, want * sizeof(u64)));
     ctx->scratch_words = want;
+    return PMX_OK;
+}
+
+int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words)
+{
+    if (ctx->slab_words >= u32_words) return PMX_OK;
+    if (ctx->d_slab) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(ctx->d_slab));
+        ctx->d_slab = nullptr;
+        ctx->slab_words = 0;
+    }
+    PMX_HIP(hipMalloc((void **)&ctx->d_slab, u32_words * sizeof(u32)));
+    ctx->slab_words = u32_words;
     return PMX_OK;
 }
 
@@ -407,7 +424,14 @@ int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint
     REQUIRE(ctx && d_M && d_out, "pmx_mappable_len_dev: NULL argument");
     int rc = check_shift_args(nbits, max_shift, "pmx_mappable_len_dev");
     if (rc) return rc;
-    (void)flags;
+    REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
+            "pmx_mappable_len_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
+    if (!(flags & PMX_FLAG_FORCE_DENSE) && pmx_sparse_supported(max_shift, 1)) {
+        rc = pmx_ensure_scratch(ctx, 4096);
+        if (rc) return rc;
+        return pmx_launch_autocorr_edges(ctx, d_M, nbits, max_shift, ctx->d_scratch, 0, 1, max_shift, (u64 *)d_out,
+                                         nullptr);
+    }
     PMX_HIP(hipMemsetAsync(d_out, 0, ((size_t)max_shift + 1) * sizeof(u64), ctx->stream));
     return pmx_launch_autocorr_dense(ctx, d_M, nbits, max_shift, (u64 *)d_out);
 }
@@ -421,39 +445,53 @@ int pmx_cc_dev(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uin
     REQUIRE(read_len >= 1 && read_len <= 65535, "pmx_cc_dev: read_len must be in [1, 65535]");
     REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
             "pmx_cc_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
+    REQUIRE(max_shift >= 3, "pmx_cc_dev: max_shift must be >= 3");
     const bool do_ncc = !(flags & PMX_FLAG_SKIP_NCC);
     const uint32_t stride = max_shift + 1;
     u64 *out = (u64 *)d_out;
     PMX_HIP(hipMemsetAsync(out, 0, (size_t)PMX_NROWS * stride * sizeof(u64), ctx->stream));
+    u64 *scal = out + (size_t)PMX_ROW_SCALARS * stride;
 
-    u64 *scal = out + (size_t)PMX_ROW_SCALARS * stride;   // stride >= 1; scalars beyond it live in scratch
-    // the scalar row has max_shift+1 slots; with max_shift < 3 keep extra scalars in scratch instead
-    REQUIRE(stride >= 4, "pmx_cc_dev: max_shift must be >= 3");
-    if (do_ncc) {
+    // The set-bit kernels are correct for any input and faster than the dense ones unless the occupancy
+    // vectors are pathologically dense, so they are the default wherever the geometry is supported.
+    const uint32_t c = read_len - 1;
+    const uint32_t far = max_shift > c ? max_shift - c : 0;   // lags |c - d| over d in [0, max_shift]
+    const uint32_t max_lag = c > far ? c : far;
+    const bool sparse_ok = pmx_sparse_supported(max_shift, read_len) != 0;
+    const bool use_sparse = sparse_ok && !(flags & PMX_FLAG_FORCE_DENSE);
+    if ((flags & PMX_FLAG_FORCE_SPARSE) && !sparse_ok) {
+        pmx_set_error("pmx_cc_dev: PMX_FLAG_FORCE_SPARSE needs 3 <= max_shift <= 1023 and read_len <= 4096");
+        return PMX_ERR_INVALID;
+    }
+    if (use_sparse) {
+        rc = pmx_launch_cc_sparse(ctx, d_F, d_R, d_M, nbits, max_shift, read_len, do_ncc, out, stride);
+        if (rc) return rc;
+    } else {
         rc = pmx_launch_count(ctx, d_F, nbits, scal + 0);
         if (rc) return rc;
         rc = pmx_launch_count(ctx, d_R, nbits, scal + 1);
         if (rc) return rc;
-    }
-    if (d_M) {
-        rc = pmx_launch_count(ctx, d_M, nbits, scal + 2);
+        rc = pmx_launch_cc_dense(ctx, d_F, d_R, d_M, nbits, max_shift, read_len, do_ncc, out, stride, scal, 2);
         if (rc) return rc;
     }
-    PMX_HIP(hipMemsetD32Async((hipDeviceptr_t)(scal + 3), PMX_PATH_DENSE, 1, ctx->stream));
-
-    rc = pmx_launch_cc_dense(ctx, d_F, d_R, d_M, nbits, max_shift, read_len, do_ncc, out, stride);
-    if (rc) return rc;
     if (d_M) {
-        const uint32_t c = read_len - 1;
-        const uint32_t far = max_shift > c ? max_shift - c : 0;   // lags |c - d| over d in [0, max_shift]
-        const uint32_t max_lag = c > far ? c : far;
-        rc = pmx_ensure_scratch(ctx, (size_t)max_lag + 1 + 16);
-        if (rc) return rc;
-        PMX_HIP(hipMemsetAsync(ctx->d_scratch, 0, ((size_t)max_lag + 1) * sizeof(u64), ctx->stream));
-        rc = pmx_launch_autocorr_dense(ctx, d_M, nbits, max_lag, ctx->d_scratch);
-        if (rc) return rc;
-        rc = pmx_launch_mlen_map(ctx, ctx->d_scratch, max_shift, read_len, out + (size_t)PMX_ROW_MLEN * stride);
-        if (rc) return rc;
+        if (use_sparse && max_lag <= 1023) {
+            rc = pmx_ensure_scratch(ctx, 4096);
+            if (rc) return rc;
+            rc = pmx_launch_autocorr_edges(ctx, d_M, nbits, max_lag, ctx->d_scratch, 1, read_len, max_shift,
+                                           out + (size_t)PMX_ROW_MLEN * stride, scal + 2);
+            if (rc) return rc;
+        } else {
+            rc = pmx_launch_count(ctx, d_M, nbits, scal + 2);
+            if (rc) return rc;
+            rc = pmx_ensure_scratch(ctx, (size_t)max_lag + 1 + 16);
+            if (rc) return rc;
+            PMX_HIP(hipMemsetAsync(ctx->d_scratch, 0, ((size_t)max_lag + 1) * sizeof(u64), ctx->stream));
+            rc = pmx_launch_autocorr_dense(ctx, d_M, nbits, max_lag, ctx->d_scratch);
+            if (rc) return rc;
+            rc = pmx_launch_mlen_map(ctx, ctx->d_scratch, max_shift, read_len, out + (size_t)PMX_ROW_MLEN * stride);
+            if (rc) return rc;
+        }
     }
     return PMX_OK;
 }

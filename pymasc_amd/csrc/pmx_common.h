@@ -50,6 +50,9 @@ struct pmx_ctx {
     // scratch (device): autocorrelation row + small flags
     u64 *d_scratch;
     size_t scratch_words;
+    // per-workgroup partial result slabs of the set-bit kernels (u32)
+    u32 *d_slab;
+    size_t slab_words;
     // staging for the host-pointer entry points
     uint64_t *d_stage[3];
     size_t stage_words[3];
@@ -73,7 +76,19 @@ int pmx_launch_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, u64 
 // rows of d_out (stride = out_stride) receive += partial sums; caller zeroes d_out first.
 int pmx_launch_cc_dense(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
                         uint64_t nbits, uint32_t max_shift, uint32_t read_len, bool do_ncc,
-                        u64 *d_out, uint32_t out_stride);
+                        u64 *d_out, uint32_t out_stride, const u64 *d_select, uint32_t select_mode);
+// set-bit driven cross-correlation (kernels_sparse.hip); same contract as pmx_launch_cc_dense.
+// select_mode: 0 = always run, 1 = run only if popcount(F)+popcount(R) (d_select[0..1]) is sparse
+// (the dense launcher takes the complementary case), so auto-selection needs no host round trip.
+int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len);
+int pmx_launch_cc_sparse(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
+                         uint64_t nbits, uint32_t max_shift, uint32_t read_len, bool do_ncc, u64 *d_out,
+                         uint32_t out_stride);
+int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words);
+// run-edge autocorrelation (kernels_sparse.hip). d_tmp: >= 2064 u64 of scratch. mode 0: d_out[k] = A(k), k <= max_lag;
+// mode 1: d_out[d] = A(|read_len - 1 - d|), d <= max_shift. d_popcount_out (nullable) receives popcount(M).
+int pmx_launch_autocorr_edges(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_tmp,
+                              uint32_t mode, uint32_t read_len, uint32_t max_shift, u64 *d_out, u64 *d_popcount_out);
 // out[k] += sum_j M[j] & M[j+k], k = 0..max_lag
 int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_out);
 // mlen_by_shift[d] = autocorr[|read_len - 1 - d|], d = 0..max_shift

@@ -50,6 +50,11 @@ def test_calc_correlation_matches_oracle(ctx, case, flags):
     ref = oracle.calc_correlation(F, R, M, nbits, S, L)
     out = ctx.calc_correlation(F, R, M, nbits, S, L, flags)
     check_block(out, ref, S, with_m)
+    # the path that actually ran is reported, so a silent fallback cannot pass for the other kernel
+    want = ffi.PMX_PATH_DENSE if flags == ffi.PMX_FLAG_FORCE_DENSE else ffi.PMX_PATH_SPARSE
+    assert int(out[ffi.PMX_ROW_SCALARS, 3]) == want
+    if with_m:
+        assert int(out[ffi.PMX_ROW_SCALARS, 2]) == int(oracle.lib().pmo_count(oracle._p(M), M.size))
 
 
 def test_skip_ncc(ctx):
