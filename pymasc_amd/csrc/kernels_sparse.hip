@@ -156,6 +156,10 @@ __device__ __forceinline__ u32 planes_value(const Planes &c, u32 quadcnt, u32 i)
 // counters -> integers added into acc[i * 32 + l] (LDS), then cleared
 __device__ __forceinline__ void planes_flush_lds(Planes &c, u32 quadcnt, u32 *acc, u32 l)
 {
+#ifdef SP_ABL_NOFLUSH
+    planes_zero(c);
+    return;
+#endif
 #pragma unroll 1
     for (u32 i = 0; i < 32; i++) {
         const u32 v = planes_value(c, quadcnt, i);
@@ -252,7 +256,9 @@ __device__ __forceinline__ void tile_store(const TileRegs &tr, u32 *lds, u32 tid
     reinterpret_cast<uint4 *>(lds + SP_OFF_R)[tid] = tr.r;
     if (HAS_M) {
         reinterpret_cast<uint4 *>(lds + SP_OFF_M + SP_MLO)[tid] = tr.m;
+#ifndef SP_ABL_NODEC
         decimate_quad(tr.m, lds + SP_OFF_E, lds + SP_OFF_O, SP_MLO + 4 * tid);
+#endif
         if (tid < 17) {
             reinterpret_cast<uint4 *>(lds + SP_OFF_M)[tid] = tr.h;
             decimate_quad(tr.h, lds + SP_OFF_E, lds + SP_OFF_O, 4 * tid);
@@ -441,10 +447,16 @@ k_cc_sparse(const u32 *__restrict__ F, const u32 *__restrict__ R, const u32 *__r
         const EmitState eF = emit_reserve(wf, &cursor[0]);
         EmitState eR;
         if (HAS_M) eR = emit_reserve(wr, &cursor[1]);
+#ifndef SP_ABL_NOEMIT
         emit_write<HAS_M>(eF, 0, listF, sM, SP_HALO_M, tid);
         if (HAS_M) emit_write<false>(eR, 0, listR, nullptr, 0, tid);
+#endif
         __syncthreads();   // cursors final, first round written
+#ifdef SP_ABL_NOPROC
+        const u32 nF = 0, nR = 0;
+#else
         const u32 nF = cursor[0], nR = HAS_M ? cursor[1] : 0u;
+#endif
         totF += nF;
         totR += nR;
         const u32 nmax = nF > nR ? nF : nR;
