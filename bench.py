@@ -123,10 +123,15 @@ def main():
     stride = S + 1
     d_rows = torch.zeros((max_slots, ffi.PMX_NROWS, stride), dtype=torch.int64, device=device)
 
+    pF = [v.F.data_ptr() for v in vecs]
+    pR = [v.R.data_ptr() for v in vecs]
+    pM = [v.M.data_ptr() for v in vecs] if with_m else None
+    pN = [v.nbits for v in vecs]
+    pO = [d_rows[slot].data_ptr() for slot in range(len(vecs))]
+
     def step():
-        for slot, v in enumerate(vecs):
-            ctx.cc_dev(v.F.data_ptr(), v.R.data_ptr(), v.M.data_ptr() if with_m else None, v.nbits, S, L, flags,
-                       d_rows[slot].data_ptr())
+        # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev), then the exchange
+        ctx.cc_batch_dev(pF, pR, pM, pN, S, L, flags, pO)
         ctx.sync()
         return sharding.exchange_results(d_rows, assignment, len(jobs))
 

@@ -100,7 +100,15 @@ int pmx_bits_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, uint64
 int pmx_cc_dev(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
                uint64_t nbits, uint32_t max_shift, uint32_t read_len, uint32_t flags,
                uint64_t *d_out);
-/* Same with host buffers: uploads F, R (and M), runs, downloads the result block. Synchronous. */
+/* The same for a BATCH of chromosomes in one pass of the kernels -- what a worker that owns several
+ * chromosomes (PyMaSC/handler/worker.py:68-104 pulls them one by one) should call: the batch shares
+ * max_shift / read_len / flags; d_F, d_R, d_M, nbits, d_out are HOST arrays of njobs entries (device
+ * pointers / sizes); d_M is NULL or has a non-NULL entry for every job.  Asynchronous; the arrays
+ * may be reused as soon as the call returns. */
+int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, const uint64_t *const *d_R,
+                     const uint64_t *const *d_M, const uint64_t *nbits, uint32_t max_shift,
+                     uint32_t read_len, uint32_t flags, uint64_t *const *d_out);
+/* Same as pmx_cc_dev with host buffers: uploads F, R (and M), runs, downloads the result block. Synchronous. */
 int pmx_calc_correlation(pmx_ctx *ctx, const uint64_t *h_F, const uint64_t *h_R, const uint64_t *h_M,
                          uint64_t nbits, uint32_t max_shift, uint32_t read_len, uint32_t flags,
                          uint64_t *h_out);

@@ -12,16 +12,23 @@
 // position-wise with bit-sliced carry-save counters: lane l of a slot owns shifts 32l..32l+31 as ONE 32-bit
 // word per counter bit plane, so adding a window costs ~2 VALU ops (v_bitop3) per 32 shifts, not 32 adds.
 //
-// Work layout: persistent workgroups of 4 wavefronts walk 32-Kbit tiles.  Per tile the F / R / M words (+ halos
-// of S bits) are fetched with 16-byte coalesced loads into REGISTERS one tile ahead (software pipeline) and
-// then stored to LDS; the tile's set bits are compacted into LDS lists with LDS atomic cursors (order is
-// irrelevant for a sum); each SLOT (G lanes, G = 2^k >= (S+1)/32; 64/G slots per wave) pulls list entries,
-// fetches its window words from LDS (ds_read2_b32 + v_alignbit, v_bfrev for descending windows) and feeds them
-// to its counters four at a time: 3 static carry-save adders, then a binary-counter style insertion selected
-// by one wave-uniform switch.  The stride-2 window of rsum reads even/odd decimated copies of the M tile built
-// once per tile.  Counters become integers only when they could overflow or when the workgroup retires; they
-// go to a PRIVATE per-workgroup slab (no cross-workgroup atomics) that k_reduce_slab sums afterwards.
+// Work layout.  One launch covers a BATCH of chromosomes (jobs): the tiles (32 Kbit) of all jobs form one
+// global sequence that is cut into equal contiguous ranges, one per persistent workgroup of 4 wavefronts.
+// Per tile: the F / R / M words (+ halos of S bits) are fetched with 16-byte coalesced loads into REGISTERS
+// one tile ahead (software pipeline); R and M go to LDS, M also as even/odd decimated copies (the stride-2
+// window of rsum); the set bits of F and R are turned into 16-byte RECORDS in LDS lists (LDS atomic cursor;
+// order is irrelevant for a sum) that already hold the LDS byte addresses and shift amounts of the windows,
+// so the 32 lanes of a slot add only their lane offset; entries that must contribute nothing (padding,
+// unmappable forward reads) point at a zeroed LDS region instead of being masked.  Each SLOT (G lanes,
+// G = 2^k >= (S+1)/32; 64/G slots per wave) consumes its share of the records four at a time: 3 static
+// carry-save adders + a binary-counter style carry insertion behind wave-uniform branches.
+// Counters are hierarchical: 10 planes + parked carries in registers per slot -> (rarely) folded, combined
+// across slots with bit-sliced adders and added into 24-plane workgroup accumulators in LDS -> converted to
+// integers only when the workgroup leaves a job, into a private slab segment that k_reduce_segments sums.
+// No global atomics anywhere.
 #include "pmx_common.h"
+
+#include <string.h>
 
 #define SP_TB 32768u                 // driver bits per tile
 #define SP_TBW 1024u                 // dwords per tile
@@ -30,24 +37,46 @@
 #define SP_MHI 36u                   // M dwords staged above the tile (read_len - 1 + 64 bits)
 #define SP_MW (SP_MLO + SP_TBW + SP_MHI)   // 1128 dwords of M per tile
 #define SP_HALO_M (SP_MLO * 32u)     // 2176 bits
-#define SP_CAP 1024u                 // list entries per round
-#define SP_NP 10                     // counter bit planes P[0..9]; parked carries Q[2..10]
+#define SP_CAP 512u                  // records per list round
+#define SP_NP 10                     // register counter: planes P[0..9], parked carries Q[2..10]
 #define SP_NQ 11
-#define SP_QLIMIT 511u               // quads a counter may absorb between flushes (count < 2048)
+#define SP_QLIMIT 511u               // quads a register counter may absorb between flushes (count < 2048)
 #define SP_QSOFT 256u                // flush at a tile boundary once this many quads are pending
-#define SP_VALID 0x20000u            // list entry: bit 17 = real entry, bit 16 = flag, bits 0..14 = position
-#define SP_SLAB_ROWS 5               // per-workgroup partial rows of 1024 u32: ncc, fsum, ccbins(mscc), rsum, scalars
+#define SP_NS 16                     // planes of a slot-combined number handed to the LDS accumulator
+#define SP_NL 24                     // planes of the workgroup accumulator in LDS
+#define SP_L2LIMIT (1u << 21)        // counts folded into the LDS accumulator before it is converted (< 2^24)
+#define SP_MAXJOBS 32u               // jobs per launch (job table travels in the kernel arguments)
+#define SP_SEG_ROWS 5u               // slab segment rows of 1024 u32: ncc, fsum, ccbins(mscc), rsum, scalars
 
-// LDS layout (dwords).  The flush accumulators (4 x 1024 u32) alias the tile buffers between tiles.
-#define SP_OFF_F 0u
-#define SP_OFF_R (SP_OFF_F + SP_TBW)
-#define SP_OFF_M (SP_OFF_R + SP_TBW + SP_RHI)
-#define SP_OFF_E (SP_OFF_M + SP_MW)
-#define SP_OFF_O (SP_OFF_E + SP_MW / 2)
-#define SP_OFF_LF (SP_OFF_O + SP_MW / 2)
-#define SP_OFF_LR (SP_OFF_LF + SP_CAP + 256)
-#define SP_OFF_MISC (SP_OFF_LR + SP_CAP + 256)
-#define SP_LDS_DWORDS (SP_OFF_MISC + 16)
+struct SpJobDev {
+    const u32 *F, *R, *M;
+    u64 nbits;
+    u32 tile0, ntiles;     // position in the global tile sequence
+    u32 aligned16, wg_first, wg_last, pad;
+    u64 *out;              // result block of the job
+    u64 *out2;             // autocorrelation: per-job scratch (P, N, scalars)
+};
+
+struct SpJobTable {
+    SpJobDev j[SP_MAXJOBS];
+};
+
+// ---- LDS layouts (dwords) ----------------------------------------------------------------------------------
+template <bool HAS_M>
+struct SpLds {
+    static constexpr u32 ZERO = 0;                                   // 40 zero dwords: target of no-op windows
+    static constexpr u32 R = 40;
+    static constexpr u32 M = R + SP_TBW + SP_RHI;
+    static constexpr u32 E = M + (HAS_M ? SP_MW : 0);
+    static constexpr u32 O = E + (HAS_M ? SP_MW / 2 : 0);
+    static constexpr u32 LF = O + (HAS_M ? SP_MW / 2 : 0);          // F records (4 dwords each)
+    static constexpr u32 LR = LF + 4 * SP_CAP;
+    static constexpr u32 ACC = LR + (HAS_M ? 4 * SP_CAP : 0);       // [counter][plane][32]
+    static constexpr u32 NCOUNTERS = HAS_M ? 4 : 1;
+    static constexpr u32 STAGE = ACC + NCOUNTERS * SP_NL * 32;      // [wave][plane][32]
+    static constexpr u32 MISC = STAGE + 4 * SP_NS * 32;
+    static constexpr u32 TOTAL = MISC + 16;
+};
 
 struct Planes {
     u32 P[SP_NP];
@@ -73,20 +102,25 @@ __device__ __forceinline__ void csa(u32 &acc, u32 a, u32 b, u32 &carry)
 
 // add four 32-shift window words; quadcnt = quads this counter absorbed since its last flush (wave-uniform).
 // The weight-4 carry is inserted like an increment of a binary counter: levels whose quadcnt bit is set hold a
-// parked carry -> CSA and pass the carry up; the first level with a clear bit parks it.  One wave-uniform
-// switch on the number of trailing one bits selects straight-line code (indices must stay compile-time
-// constants or the planes leave the register file).
+// parked carry -> CSA and pass the carry up; the first level with a clear bit parks it.  Nested wave-uniform
+// branches on the number of trailing one bits; plane indices must stay compile-time constants or the planes
+// leave the register file (the asm markers keep the per-level stores from being merged into one indexed store).
 __device__ __forceinline__ void add_quad(Planes &c, u32 w0, u32 w1, u32 w2, u32 w3, u32 quadcnt)
 {
     u32 c1a, c1b, c2;
     csa(c.P[0], w0, w1, c1a);
     csa(c.P[0], w2, w3, c1b);
     csa(c.P[1], c1a, c1b, c2);
-#define SP_CSA(L)                              \
-    {                                          \
-        u32 nx_;                               \
-        csa(c.P[L], c.Q[L], c2, nx_);          \
-        c2 = nx_;                              \
+#define SP_CSA(L)                     \
+    {                                 \
+        u32 nx_;                      \
+        csa(c.P[L], c.Q[L], c2, nx_); \
+        c2 = nx_;                     \
+    }
+#define SP_PARK(L)                    \
+    {                                 \
+        c.Q[L] = c2;                  \
+        asm volatile("; park " #L);   \
     }
     const u32 tz = __builtin_ctz(~quadcnt);
     if (tz > 0u) {
@@ -106,78 +140,98 @@ __device__ __forceinline__ void add_quad(Planes &c, u32 w0, u32 w1, u32 w2, u32 
                                 if (tz > 7u) {
                                     SP_CSA(9);
                                     c.Q[10] = c2;
-                                } else {
-                                    c.Q[9] = c2;
-                                    asm volatile("; park 9");   // keeps the per-level stores from being merged into one indexed store
-                                }
-                            } else {
-                                c.Q[8] = c2;
-                                asm volatile("; park 8");   // keeps the per-level stores from being merged into one indexed store
-                            }
-                        } else {
-                            c.Q[7] = c2;
-                            asm volatile("; park 7");   // keeps the per-level stores from being merged into one indexed store
-                        }
-                    } else {
-                        c.Q[6] = c2;
-                        asm volatile("; park 6");   // keeps the per-level stores from being merged into one indexed store
-                    }
-                } else {
-                    c.Q[5] = c2;
-                    asm volatile("; park 5");   // keeps the per-level stores from being merged into one indexed store
-                }
-            } else {
-                c.Q[4] = c2;
-                asm volatile("; park 4");   // keeps the per-level stores from being merged into one indexed store
-            }
-        } else {
-            c.Q[3] = c2;
-            asm volatile("; park 3");   // keeps the per-level stores from being merged into one indexed store
-        }
-    } else {
-        c.Q[2] = c2;
-        asm volatile("; park 2");   // keeps the per-level stores from being merged into one indexed store
-    }
+                                } else SP_PARK(9)
+                            } else SP_PARK(8)
+                        } else SP_PARK(7)
+                    } else SP_PARK(6)
+                } else SP_PARK(5)
+            } else SP_PARK(4)
+        } else SP_PARK(3)
+    } else SP_PARK(2)
 #undef SP_CSA
+#undef SP_PARK
 }
 
-// integer count at bit i of this lane's 32 shifts
-__device__ __forceinline__ u32 planes_value(const Planes &c, u32 quadcnt, u32 i)
+// full adder on bit planes
+__device__ __forceinline__ void fa(u32 a, u32 b, u32 cin, u32 &s, u32 &cout)
 {
-    u32 v = 0;
-#pragma unroll
-    for (int k = 0; k < SP_NP; k++) v += ((c.P[k] >> i) & 1u) << k;
-#pragma unroll
-    for (int k = 2; k < SP_NQ; k++)
-        if ((quadcnt >> (k - 2)) & 1u) v += ((c.Q[k] >> i) & 1u) << k;
-    return v;
+    s = __builtin_amdgcn_bitop3_b32(a, b, cin, 0x96);
+    cout = __builtin_amdgcn_bitop3_b32(a, b, cin, 0xE8);
 }
 
-// counters -> integers added into acc[i * 32 + l] (LDS), then cleared
-__device__ __forceinline__ void planes_flush_lds(Planes &c, u32 quadcnt, u32 *acc, u32 l)
+// Register counter -> workgroup accumulator in LDS (all 256 threads call this together):
+//   1. fold the parked carries into the planes (bit-sliced add inside the lane)          -> 11 planes
+//   2. add the slots of a wave together with cross-lane bit-sliced adds (xor shuffles)    -> <= 15 planes
+//   3. stage the per-wave numbers in LDS, barrier
+//   4. lanes 0..G-1 of wave 0 add the 4 staged numbers into acc[plane][l] (24 planes), barrier
+// The counter is cleared.  Costs a few hundred instructions; runs once per ~40 tiles at typical densities.
+__device__ __forceinline__ void counter_to_lds(Planes &c, u32 quadcnt, u32 lgG, u32 tid, u32 *stage, u32 *acc)
 {
 #ifdef SP_ABL_NOFLUSH
     planes_zero(c);
     return;
 #endif
-#pragma unroll 1
-    for (u32 i = 0; i < 32; i++) {
-        const u32 v = planes_value(c, quadcnt, i);
-        if (v) atomicAdd(&acc[i * 32 + l], v);
+    u32 n[SP_NS];
+    // 1. fold
+    {
+        n[0] = c.P[0];
+        n[1] = c.P[1];
+        u32 carry = 0;
+#pragma unroll
+        for (int k = 2; k < SP_NP; k++) {
+            const u32 qv = ((quadcnt >> (k - 2)) & 1u) ? c.Q[k] : 0u;
+            u32 s, co;
+            fa(c.P[k], qv, carry, s, co);
+            n[k] = s;
+            carry = co;
+        }
+        const u32 q10 = ((quadcnt >> 8) & 1u) ? c.Q[10] : 0u;
+        n[10] = q10 ^ carry;   // count < 2048: no carry out of plane 10
+#pragma unroll
+        for (int k = 11; k < SP_NS; k++) n[k] = 0;
     }
     planes_zero(c);
-}
-
-// same, straight into this workgroup's slab row with (uncontended) global atomics: used mid-tile, when the LDS
-// tile buffers are live and a counter is about to overflow (only tiles with thousands of set bits get here)
-__device__ __forceinline__ void planes_flush_slab(Planes &c, u32 quadcnt, u32 *__restrict__ row, u32 l)
-{
-#pragma unroll 1
-    for (u32 i = 0; i < 32; i++) {
-        const u32 v = planes_value(c, quadcnt, i);
-        if (v) atomicAdd(&row[32 * l + i], v);
+    // 2. combine the slots of this wave: lanes ^ G, ^ 2G, ... hold the same shifts of other slots
+    for (u32 step = 1u << lgG; step < 64; step <<= 1) {
+        u32 carry = 0;
+#pragma unroll
+        for (int k = 0; k < SP_NS; k++) {
+            const u32 o = __shfl_xor(n[k], step, 64);
+            u32 s, co;
+            fa(n[k], o, carry, s, co);
+            n[k] = s;
+            carry = co;
+        }
     }
-    planes_zero(c);
+    // 3. stage (first slot of each wave)
+    const u32 lane = tid & 63, wave = tid >> 6;
+    const u32 G = 1u << lgG;
+    if (lane < G) {
+#pragma unroll
+        for (int k = 0; k < SP_NS; k++) stage[(wave * SP_NS + k) * 32 + lane] = n[k];
+    }
+    __syncthreads();
+    // 4. accumulate
+    if (tid < G) {
+        u32 a[SP_NL];
+#pragma unroll
+        for (int k = 0; k < SP_NL; k++) a[k] = acc[k * 32 + tid];
+#pragma unroll
+        for (u32 w = 0; w < 4; w++) {
+            u32 carry = 0;
+#pragma unroll
+            for (int k = 0; k < SP_NL; k++) {
+                const u32 o = k < SP_NS ? stage[(w * SP_NS + k) * 32 + tid] : 0u;
+                u32 s, co;
+                fa(a[k], o, carry, s, co);
+                a[k] = s;
+                carry = co;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SP_NL; k++) acc[k * 32 + tid] = a[k];
+    }
+    __syncthreads();
 }
 
 // ---- tile staging --------------------------------------------------------------------------------------
@@ -228,6 +282,18 @@ __device__ __forceinline__ void tile_fetch(TileRegs &tr, const u32 *__restrict__
         tr.h = ld_quad<GUARD>(R, d0 + SP_TBW + 4 * (int64_t)(tid - 26), nbits);
 }
 
+template <bool HAS_M>
+__device__ __forceinline__ void tile_fetch_job(TileRegs &tr, const SpJobDev &jb, u32 local_tile, u32 tid)
+{
+    // edge tiles (or unaligned vectors) take the guarded loader
+    const uint64_t hi = (uint64_t)local_tile * SP_TBW + SP_TBW + SP_MHI;   // one past the highest dword touched
+    const bool interior = jb.aligned16 && local_tile > 0 && hi + 2 <= jb.nbits / 32;
+    if (interior)
+        tile_fetch<HAS_M, false>(tr, jb.F, jb.R, jb.M, (int64_t)local_tile * SP_TBW, jb.nbits, tid);
+    else
+        tile_fetch<HAS_M, true>(tr, jb.F, jb.R, jb.M, (int64_t)local_tile * SP_TBW, jb.nbits, tid);
+}
+
 // 16 even bits of each of two dwords -> one dword (lo's bits in the low half)
 __device__ __forceinline__ u32 even16x2(u32 lo, u32 hi)
 {
@@ -252,77 +318,28 @@ __device__ __forceinline__ void decimate_quad(const uint4 m, u32 *sE, u32 *sO, u
 template <bool HAS_M>
 __device__ __forceinline__ void tile_store(const TileRegs &tr, u32 *lds, u32 tid)
 {
-    reinterpret_cast<uint4 *>(lds + SP_OFF_F)[tid] = tr.f;
-    reinterpret_cast<uint4 *>(lds + SP_OFF_R)[tid] = tr.r;
+    typedef SpLds<HAS_M> L;
+    reinterpret_cast<uint4 *>(lds + L::R)[tid] = tr.r;
     if (HAS_M) {
-        reinterpret_cast<uint4 *>(lds + SP_OFF_M + SP_MLO)[tid] = tr.m;
+        reinterpret_cast<uint4 *>(lds + L::M + SP_MLO)[tid] = tr.m;
 #ifndef SP_ABL_NODEC
-        decimate_quad(tr.m, lds + SP_OFF_E, lds + SP_OFF_O, SP_MLO + 4 * tid);
+        decimate_quad(tr.m, lds + L::E, lds + L::O, SP_MLO + 4 * tid);
 #endif
         if (tid < 17) {
-            reinterpret_cast<uint4 *>(lds + SP_OFF_M)[tid] = tr.h;
-            decimate_quad(tr.h, lds + SP_OFF_E, lds + SP_OFF_O, 4 * tid);
+            reinterpret_cast<uint4 *>(lds + L::M)[tid] = tr.h;
+            decimate_quad(tr.h, lds + L::E, lds + L::O, 4 * tid);
         } else if (tid < 26) {
-            reinterpret_cast<uint4 *>(lds + SP_OFF_M + SP_MLO + SP_TBW)[tid - 17] = tr.h;
-            decimate_quad(tr.h, lds + SP_OFF_E, lds + SP_OFF_O, SP_MLO + SP_TBW + 4 * (tid - 17));
+            reinterpret_cast<uint4 *>(lds + L::M + SP_MLO + SP_TBW)[tid - 17] = tr.h;
+            decimate_quad(tr.h, lds + L::E, lds + L::O, SP_MLO + SP_TBW + 4 * (tid - 17));
         }
     }
-    if (tid >= 26 && tid < 35) reinterpret_cast<uint4 *>(lds + SP_OFF_R + SP_TBW)[tid - 26] = tr.h;
+    if (tid >= 26 && tid < 35) reinterpret_cast<uint4 *>(lds + L::R + SP_TBW)[tid - 26] = tr.h;
 }
 
-// ---- set-bit lists -----------------------------------------------------------------------------------------
-
-struct EmitState {
-    uint4 w;      // this thread's 4 driver dwords
-    u32 idx0;     // first list index of this thread (whole tile, not per round)
-};
-
-// reserves list slots for this thread's set bits with one LDS atomic (order across threads is irrelevant)
-__device__ __forceinline__ EmitState emit_reserve(const uint4 w, u32 *cursor)
-{
-    EmitState st;
-    st.w = w;
-    const u32 n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
-    st.idx0 = n ? atomicAdd(cursor, n) : 0u;
-    return st;
-}
-
-// writes the entries whose index falls in [round_lo, round_lo + SP_CAP)
-template <bool WITH_FLAG>
-__device__ __forceinline__ void emit_write(const EmitState &st, u32 round_lo, u32 *list, const u32 *sFlag, u32 flag_off,
-                                           u32 tid)
-{
-    u32 id = st.idx0 - round_lo;   // unsigned: entries before the round wrap to huge values
-    const u32 ws[4] = {st.w.x, st.w.y, st.w.z, st.w.w};
-#pragma unroll
-    for (u32 k = 0; k < 4; k++) {
-        u32 ww = ws[k];
-        while (ww) {
-            const u32 b = __builtin_ctz(ww);
-            ww &= ww - 1;
-            if (id < SP_CAP) {
-                const u32 pos = 128u * tid + 32u * k + b;
-                u32 e = pos | SP_VALID;
-                if (WITH_FLAG) {
-                    const u32 fa = flag_off + pos;
-                    e |= ((sFlag[fa >> 5] >> (fa & 31)) & 1u) << 16;
-                }
-                list[id] = e;
-            }
-            id++;
-        }
-    }
-}
-
-// pads the list to a multiple of pad_to (<= 256) entries with invalid entries (position 0, no flags)
-__device__ __forceinline__ void emit_pad(u32 *list, u32 nround, u32 pad_to, u32 tid)
-{
-    const u32 npad = (nround + pad_to - 1) / pad_to * pad_to;
-    if (nround + tid < npad) list[nround + tid] = 0u;
-}
+// ---- set-bit records ---------------------------------------------------------------------------------------
 
 struct SlotGeom {
-    u32 total_slots, slot, l, quad_span;
+    u32 total_slots, slot, l4, quad_span;
 };
 
 __device__ __forceinline__ SlotGeom slot_geom(u32 lgG, u32 tid)
@@ -332,99 +349,195 @@ __device__ __forceinline__ SlotGeom slot_geom(u32 lgG, u32 tid)
     const u32 spw = 64u >> lgG;
     g.total_slots = 4 * spw;
     g.slot = wave * spw + (lane >> lgG);
-    g.l = lane & ((1u << lgG) - 1);
+    g.l4 = 4u * (lane & ((1u << lgG) - 1));
     g.quad_span = g.total_slots * 4;
     return g;
+}
+
+// reserves list slots for this thread's set bits with one LDS atomic (order across threads is irrelevant)
+__device__ __forceinline__ u32 emit_reserve(const uint4 w, u32 *cursor)
+{
+    const u32 n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+    return n ? atomicAdd(cursor, n) : 0u;
+}
+
+// Forward-read records: {shift word for the R window, R window byte address (lane adds 4l),
+//                        M window byte address (lane subtracts 4l; the zero region if M[x] = 0), shift word for M}
+template <bool HAS_M>
+__device__ __forceinline__ void emit_forward(const uint4 w, u32 idx0, u32 round_lo, u32 *lds, int32_t c, u32 tid)
+{
+    typedef SpLds<HAS_M> L;
+    uint4 *list = reinterpret_cast<uint4 *>(lds + L::LF);
+    const u32 *sM = lds + L::M;
+    u32 id = idx0 - round_lo;   // unsigned: entries before the round wrap to huge values
+    const u32 ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        u32 ww = ws[k];
+        while (ww) {
+            const u32 b = __builtin_ctz(ww);
+            ww &= ww - 1;
+            if (id < SP_CAP) {
+                const u32 pos = 128u * tid + 32u * k + b;
+                uint4 rec;
+                rec.x = pos;
+                rec.y = (L::R + (pos >> 5)) * 4u;
+                rec.z = (L::ZERO + 32u) * 4u;
+                rec.w = 0;
+                if (HAS_M) {
+                    const u32 fa_ = SP_HALO_M + pos;
+                    const u32 mapped = (sM[fa_ >> 5] >> (fa_ & 31)) & 1u;
+                    const u32 a0 = pos + (u32)c + SP_HALO_M - 31u;
+                    rec.w = a0;
+                    if (mapped) rec.z = (L::M + (a0 >> 5)) * 4u;
+                }
+                list[id] = rec;
+            }
+            id++;
+        }
+    }
+}
+
+// Reverse-read records: {shift word for M[p-d], its byte address (lane subtracts 4l),
+//                        byte address of the decimated copy holding M[p+c-2d] (lane subtracts 4l), its shift word}
+__device__ __forceinline__ void emit_reverse(const uint4 w, u32 idx0, u32 round_lo, u32 *lds, int32_t c, u32 tid)
+{
+    typedef SpLds<true> L;
+    uint4 *list = reinterpret_cast<uint4 *>(lds + L::LR);
+    u32 id = idx0 - round_lo;
+    const u32 ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        u32 ww = ws[k];
+        while (ww) {
+            const u32 b = __builtin_ctz(ww);
+            ww &= ww - 1;
+            if (id < SP_CAP) {
+                const u32 p = 128u * tid + 32u * k + b;
+                const u32 a1 = p + SP_HALO_M - 31u;
+                const u32 bb = p + SP_HALO_M + (u32)c;
+                const u32 a2 = (bb >> 1) - 31u;
+                uint4 rec;
+                rec.x = a1;
+                rec.y = (L::M + (a1 >> 5)) * 4u;
+                rec.z = (((bb & 1u) ? L::O : L::E) + (a2 >> 5)) * 4u;
+                rec.w = a2;
+                list[id] = rec;
+            }
+            id++;
+        }
+    }
+}
+
+// pads a record list up to `npad` (< nround + 256) with records whose windows read the zero region
+__device__ __forceinline__ void emit_pad(uint4 *list, u32 nround, u32 npad, u32 addr_y, u32 addr_z, u32 tid)
+{
+    if (nround + tid < npad) list[nround + tid] = make_uint4(0u, addr_y, addr_z, 0u);
+}
+
+__device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shift_word)
+{
+    const u32 *p = reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(lds) + byte_addr);
+    return __builtin_amdgcn_alignbit(p[1], p[0], shift_word);
 }
 
 // ---- the cross-correlation kernel ---------------------------------------------------------------------------
 
 template <bool HAS_M, bool DO_NCC>
-__device__ __forceinline__ void cc_flush_tile_boundary(Planes &cN, Planes &cF, Planes &cC, Planes &cR, u32 &qF, u32 &qR,
-                                                       u32 *lds, u32 l, u32 tid, u32 *__restrict__ slab)
-{
-    u32 *acc = lds;   // 4 x 1024 u32 over the (dead) tile buffers
-    __syncthreads();
-    for (u32 i = tid; i < 4096; i += 256) acc[i] = 0;
-    __syncthreads();
-    if (DO_NCC) planes_flush_lds(cN, qF, acc, l);
-    if (HAS_M) {
-        planes_flush_lds(cF, qF, acc + 1024, l);
-        planes_flush_lds(cC, qF, acc + 2048, l);
-        planes_flush_lds(cR, qR, acc + 3072, l);
-    }
-    qF = 0;
-    qR = 0;
-    __syncthreads();
-    // every slab update is an L2 atomic (uncontended: the slab is private), so mid-tile spills and these adds
-    // can never read each other's stale L1 lines
-    for (u32 d = tid; d < 1024; d += 256) {
-        const u32 a = (d & 31) * 32 + (d >> 5);
-#pragma unroll
-        for (u32 q = 0; q < 4; q++) {
-            const u32 v = acc[q * 1024 + a];
-            if (v) atomicAdd(&slab[q * 1024 + d], v);
-        }
-    }
-    __syncthreads();
-}
-
-template <bool HAS_M, bool DO_NCC>
 __global__ void __launch_bounds__(256, 2)
-k_cc_sparse(const u32 *__restrict__ F, const u32 *__restrict__ R, const u32 *__restrict__ M, uint64_t nbits, int32_t c,
-            u32 lgG, u32 ntiles, u32 aligned16, u32 *__restrict__ slab_all)
+k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
+            u32 *__restrict__ slab)
 {
-    __shared__ __align__(16) u32 lds[SP_LDS_DWORDS];
-    u32 *const listF = lds + SP_OFF_LF;
-    u32 *const listR = lds + SP_OFF_LR;
-    u32 *const cursor = lds + SP_OFF_MISC;   // [0] = F entries, [1] = R entries of the current tile
-    const u32 *const sR = lds + SP_OFF_R;
-    const u32 *const sM = lds + SP_OFF_M;
-    const u32 *const sE = lds + SP_OFF_E;
+    typedef SpLds<HAS_M> L;
+    __shared__ __align__(16) u32 lds[L::TOTAL];
+    u32 *const cursor = lds + L::MISC;   // [0] = F records, [1] = R records of the current tile
+    u32 *const acc = lds + L::ACC;
+    u32 *const stage = lds + L::STAGE;
 
     const u32 tid = threadIdx.x;
     const SlotGeom sg = slot_geom(lgG, tid);
-    const u32 l = sg.l;
-    u32 *const slab = slab_all + (size_t)blockIdx.x * SP_SLAB_ROWS * 1024;
+    const u32 zero_up = (L::ZERO) * 4u, zero_down = (L::ZERO + 32u) * 4u;
 
-    // the slab is private to this workgroup for the whole launch; the host zeroes it before the launch
+    const u32 g0 = blockIdx.x * tiles_per_wg;
+    const u32 g1 = g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles;
+    if (g0 >= g1) return;
+
+    for (u32 i = tid; i < 40; i += 256) lds[L::ZERO + i] = 0;
+    for (u32 i = tid; i < L::NCOUNTERS * SP_NL * 32; i += 256) acc[i] = 0;
 
     Planes cN, cF, cC, cR;
     planes_zero(cN);
     planes_zero(cF);
     planes_zero(cC);
     planes_zero(cR);
-    u32 qF = 0, qR = 0;           // quads absorbed since the last flush (workgroup-uniform)
-    u32 totF = 0, totR = 0;       // set bits seen by this workgroup (uniform)
+    u32 qF = 0, qR = 0;           // quads in the register counters (workgroup-uniform)
+    u32 q2 = 0;                   // upper bound of the counts folded into the LDS accumulators since conversion
+    u32 totF = 0, totR = 0;       // set bits of the current job seen by this workgroup (uniform)
     u32 cntR_thread = 0;          // NCC-only mode: popcount of R accumulated per thread
+    bool seg_written = false;     // this (workgroup, job) slab segment already holds a partial conversion
 
-    // per-lane window offsets
-    const u32 kM = (u32)c + SP_HALO_M - 32u * l - 31u;   // M[x + c - d], descending
-    const u32 k1 = SP_HALO_M - 32u * l - 31u;            // M[p - d], descending
-    const u32 kB = SP_HALO_M + (u32)c;                   // M[p + c - 2d]: position in the decimated copies
-    const u32 k2 = 32u * l + 31u;
+    // job of the first tile (njobs is small)
+    u32 ji = 0;
+    while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
 
-    // edge tiles (or unaligned vectors) take the guarded loader
-    const uint64_t full_dw = nbits / 32;
-    auto interior = [&](u32 t) -> bool {
-        if (!aligned16 || t == 0) return false;
-        const uint64_t hi = (uint64_t)t * SP_TBW + SP_TBW + SP_MHI;   // one past the highest dword touched
-        return hi + 2 <= full_dw;
+    // registers -> LDS accumulators (uniform call)
+    auto fold_all = [&]() {
+        if (DO_NCC) counter_to_lds(cN, qF, lgG, tid, stage, acc);
+        if (HAS_M) {
+            counter_to_lds(cF, qF, lgG, tid, stage, acc + 1 * SP_NL * 32);
+            counter_to_lds(cC, qF, lgG, tid, stage, acc + 2 * SP_NL * 32);
+            counter_to_lds(cR, qR, lgG, tid, stage, acc + 3 * SP_NL * 32);
+        }
+        q2 += (qF > qR ? qF : qR) * 4u * sg.total_slots;
+        qF = 0;
+        qR = 0;
+    };
+    // LDS accumulators -> integers in this workgroup's slab segment for job `j` (uniform call)
+    auto convert = [&](u32 j, bool final) {
+        u32 *seg = slab + (size_t)(blockIdx.x + j) * SP_SEG_ROWS * 1024;
+        __syncthreads();
+        for (u32 q = 0; q < L::NCOUNTERS; q++) {
+            const u32 *a = acc + q * SP_NL * 32;
+            u32 *row = seg + q * 1024;
+            for (u32 d = tid; d < 1024; d += 256) {
+                const u32 l = d >> 5, i = d & 31;
+                u32 v = seg_written ? row[d] : 0u;   // an earlier partial conversion of this job (same thread)
+#pragma unroll
+                for (int k = 0; k < SP_NL; k++) v += ((a[k * 32 + l] >> i) & 1u) << k;
+                row[d] = v;
+            }
+        }
+        __syncthreads();
+        for (u32 i = tid; i < L::NCOUNTERS * SP_NL * 32; i += 256) acc[i] = 0;
+        q2 = 0;
+        seg_written = true;
+        if (final) {
+            if (!HAS_M) {   // popcount(R) was counted per thread
+                u32 v = cntR_thread;
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if ((tid & 63) == 0) cursor[4 + (tid >> 6)] = v;
+                __syncthreads();
+                totR = cursor[4] + cursor[5] + cursor[6] + cursor[7];
+                cntR_thread = 0;
+            }
+            if (tid == 0) {   // popcount(F), popcount(R): bit_array_num_bits_set of mscc.pyx:236-237
+                seg[4 * 1024 + 0] = totF;
+                seg[4 * 1024 + 1] = totR;
+            }
+            totF = 0;
+            totR = 0;
+            seg_written = false;
+        }
+        __syncthreads();
     };
 
     TileRegs tr;
-    u32 tile = blockIdx.x;
-    if (tile < ntiles) {
-        if (interior(tile))
-            tile_fetch<HAS_M, false>(tr, F, R, M, (int64_t)tile * SP_TBW, nbits, tid);
-        else
-            tile_fetch<HAS_M, true>(tr, F, R, M, (int64_t)tile * SP_TBW, nbits, tid);
-    }
+    tile_fetch_job<HAS_M>(tr, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (u32 g = g0; g < g1; g++) {
         __syncthreads();   // everyone is done with the previous tile's LDS
-        if (qF >= SP_QSOFT || qR >= SP_QSOFT)
-            cc_flush_tile_boundary<HAS_M, DO_NCC>(cN, cF, cC, cR, qF, qR, lds, l, tid, slab);
+        if (qF >= SP_QSOFT || qR >= SP_QSOFT) fold_all();
+        if (q2 >= SP_L2LIMIT) convert(ji, false);
 
         tile_store<HAS_M>(tr, lds, tid);
         if (tid < 2) cursor[tid] = 0;
@@ -433,23 +546,19 @@ k_cc_sparse(const u32 *__restrict__ F, const u32 *__restrict__ R, const u32 *__r
         __syncthreads();   // tile visible
 
         // fetch the next tile into registers now; it is consumed after the next loop-top barrier
-        {
-            const u32 nt = tile + gridDim.x;
-            if (nt < ntiles) {
-                if (interior(nt))
-                    tile_fetch<HAS_M, false>(tr, F, R, M, (int64_t)nt * SP_TBW, nbits, tid);
-                else
-                    tile_fetch<HAS_M, true>(tr, F, R, M, (int64_t)nt * SP_TBW, nbits, tid);
-            }
+        u32 jn = ji;
+        if (g + 1 < g1) {
+            if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
+            tile_fetch_job<HAS_M>(tr, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
         }
 
-        // compact both driver vectors
-        const EmitState eF = emit_reserve(wf, &cursor[0]);
-        EmitState eR;
-        if (HAS_M) eR = emit_reserve(wr, &cursor[1]);
+        // compact both driver vectors into records
+        const u32 iF = emit_reserve(wf, &cursor[0]);
+        u32 iR = 0;
+        if (HAS_M) iR = emit_reserve(wr, &cursor[1]);
 #ifndef SP_ABL_NOEMIT
-        emit_write<HAS_M>(eF, 0, listF, sM, SP_HALO_M, tid);
-        if (HAS_M) emit_write<false>(eR, 0, listR, nullptr, 0, tid);
+        emit_forward<HAS_M>(wf, iF, 0, lds, c, tid);
+        if (HAS_M) emit_reverse(wr, iR, 0, lds, c, tid);
 #endif
         __syncthreads();   // cursors final, first round written
 #ifdef SP_ABL_NOPROC
@@ -464,74 +573,56 @@ k_cc_sparse(const u32 *__restrict__ F, const u32 *__restrict__ R, const u32 *__r
         for (u32 round_lo = 0; round_lo < nmax; round_lo += SP_CAP) {
             if (round_lo) {   // rare: a tile with more than SP_CAP set bits in one vector
                 __syncthreads();
-                emit_write<HAS_M>(eF, round_lo, listF, sM, SP_HALO_M, tid);
-                if (HAS_M) emit_write<false>(eR, round_lo, listR, nullptr, 0, tid);
+                emit_forward<HAS_M>(wf, iF, round_lo, lds, c, tid);
+                if (HAS_M) emit_reverse(wr, iR, round_lo, lds, c, tid);
             }
             const u32 nFr = nF > round_lo ? (nF - round_lo < SP_CAP ? nF - round_lo : SP_CAP) : 0u;
             const u32 nRr = nR > round_lo ? (nR - round_lo < SP_CAP ? nR - round_lo : SP_CAP) : 0u;
-            emit_pad(listF, nFr, sg.quad_span, tid);
-            if (HAS_M) emit_pad(listR, nRr, sg.quad_span, tid);
-            __syncthreads();
-            const u32 nqF = (nFr + sg.quad_span - 1) / sg.quad_span;
+            const u32 nqF = (nFr + sg.quad_span - 1) / sg.quad_span;   // quads per slot
             const u32 nqR = (nRr + sg.quad_span - 1) / sg.quad_span;
+            emit_pad(reinterpret_cast<uint4 *>(lds + L::LF), nFr, nqF * sg.quad_span, zero_up, zero_down, tid);
+            if (HAS_M) emit_pad(reinterpret_cast<uint4 *>(lds + L::LR), nRr, nqR * sg.quad_span, zero_down, zero_down, tid);
+            __syncthreads();
 
-            // a counter must never absorb more than SP_QLIMIT quads: spill to the slab first (dense tiles only)
-            if (qF + nqF > SP_QLIMIT) {
-                if (DO_NCC) planes_flush_slab(cN, qF, slab, l);
-                if (HAS_M) {
-                    planes_flush_slab(cF, qF, slab + 1024, l);
-                    planes_flush_slab(cC, qF, slab + 2048, l);
-                }
-                qF = 0;
-            }
-            if (HAS_M && qR + nqR > SP_QLIMIT) {
-                planes_flush_slab(cR, qR, slab + 3072, l);
-                qR = 0;
-            }
+            // a register counter must never absorb more than SP_QLIMIT quads (only very dense tiles get here)
+            if (qF + nqF > SP_QLIMIT || qR + nqR > SP_QLIMIT) fold_all();
 
             // ---- forward reads drive: ncc, mscc.fsum, mscc.ccbins ----
-            for (u32 q = 0; q < nqF; q++) {
-                u32 wN[4], wF[4], wC[4];
+            {
+                const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LF) + sg.slot * 4 * nqF;
+                for (u32 q = 0; q < nqF; q++) {
+                    u32 wN[4], wF[4], wC[4];
 #pragma unroll
-                for (u32 k = 0; k < 4; k++) {
-                    const u32 e = listF[(q * 4 + k) * sg.total_slots + sg.slot];
-                    const u32 vmask = (u32)__builtin_amdgcn_sbfe(e, 17, 1);   // all ones for a real entry
-                    const u32 ri = ((e >> 5) & 1023u) + l;
-                    const u32 rw = __builtin_amdgcn_alignbit(sR[ri + 1], sR[ri], e) & vmask;
-                    wN[k] = rw;
+                    for (u32 k = 0; k < 4; k++) {
+                        const uint4 rec = recs[q * 4 + k];
+                        const u32 rw = lds_window(lds, rec.y + sg.l4, rec.x);
+                        wN[k] = rw;
+                        if (HAS_M) {
+                            const u32 mw = __builtin_bitreverse32(lds_window(lds, rec.z - sg.l4, rec.w));
+                            wF[k] = mw;
+                            wC[k] = mw & rw;
+                        }
+                    }
+                    const u32 qc = __builtin_amdgcn_readfirstlane(qF + q);
+                    if (DO_NCC) add_quad(cN, wN[0], wN[1], wN[2], wN[3], qc);
                     if (HAS_M) {
-                        const u32 fmask = (u32)__builtin_amdgcn_sbfe(e, 16, 1);   // forward read is mappable
-                        const u32 a = (e & 0x7fffu) + kM;
-                        const u32 mw = __builtin_bitreverse32(__builtin_amdgcn_alignbit(sM[(a >> 5) + 1], sM[a >> 5], a));
-                        wF[k] = mw & fmask;
-                        wC[k] = __builtin_amdgcn_bitop3_b32(mw, rw, fmask, 0x80);   // three-way AND
+                        add_quad(cF, wF[0], wF[1], wF[2], wF[3], qc);
+                        add_quad(cC, wC[0], wC[1], wC[2], wC[3], qc);
                     }
                 }
-                const u32 qc = __builtin_amdgcn_readfirstlane(qF + q);
-                if (DO_NCC) add_quad(cN, wN[0], wN[1], wN[2], wN[3], qc);
-                if (HAS_M) {
-                    add_quad(cF, wF[0], wF[1], wF[2], wF[3], qc);
-                    add_quad(cC, wC[0], wC[1], wC[2], wC[3], qc);
-                }
+                qF += nqF;
             }
-            qF += nqF;
-
             // ---- reverse reads drive: mscc.rsum ----
             if (HAS_M) {
+                const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LR) + sg.slot * 4 * nqR;
                 for (u32 q = 0; q < nqR; q++) {
                     u32 wR[4];
 #pragma unroll
                     for (u32 k = 0; k < 4; k++) {
-                        const u32 e = listR[(q * 4 + k) * sg.total_slots + sg.slot];
-                        const u32 vmask = (u32)__builtin_amdgcn_sbfe(e, 17, 1);
-                        const u32 p = e & 0x7fffu;
-                        const u32 a1 = p + k1;
-                        const u32 w1 = __builtin_amdgcn_alignbit(sM[(a1 >> 5) + 1], sM[a1 >> 5], a1);
-                        const u32 b = p + kB;
-                        const u32 a2 = (b >> 1) - k2;
-                        const u32 *dec = sE + (b & 1u) * (SP_MW / 2);   // even or odd decimated copy
-                        const u32 w2 = __builtin_amdgcn_alignbit(dec[(a2 >> 5) + 1], dec[a2 >> 5], a2);
-                        wR[k] = __builtin_bitreverse32(w1 & w2) & vmask;
+                        const uint4 rec = recs[q * 4 + k];
+                        const u32 w1 = lds_window(lds, rec.y - sg.l4, rec.x);
+                        const u32 w2 = lds_window(lds, rec.z - sg.l4, rec.w);
+                        wR[k] = __builtin_bitreverse32(w1 & w2);
                     }
                     const u32 qc = __builtin_amdgcn_readfirstlane(qR + q);
                     add_quad(cR, wR[0], wR[1], wR[2], wR[3], qc);
@@ -539,61 +630,59 @@ k_cc_sparse(const u32 *__restrict__ F, const u32 *__restrict__ R, const u32 *__r
                 qR += nqR;
             }
         }
-    }
 
-    __syncthreads();
-    cc_flush_tile_boundary<HAS_M, DO_NCC>(cN, cF, cC, cR, qF, qR, lds, l, tid, slab);
-    // popcount(F), popcount(R): bit_array_num_bits_set of mscc.pyx:236-237, for free from the compaction
-    if (!HAS_M) {
-        u32 v = cntR_thread;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((tid & 63) == 0) cursor[4 + (tid >> 6)] = v;
-        __syncthreads();
-        if (tid == 0) totR = cursor[4] + cursor[5] + cursor[6] + cursor[7];
-    }
-    if (tid == 0) {
-        slab[4 * 1024 + 0] = totF;
-        slab[4 * 1024 + 1] = totR;
+        // leaving a job: registers -> LDS accumulators -> this workgroup's segment of that job
+        if (jn != ji || g + 1 == g1) {
+            __syncthreads();
+            fold_all();
+            convert(ji, true);
+            ji = jn;
+        }
     }
 }
 
-// dst[r][i] = sum over workgroups of slab[wg][src_row[r]][i], i < n[r]; blockIdx.y = r
-struct ReduceRows {
-    u64 *dst[5];
+// out[job][row][i] = sum over the workgroups that touched the job of slab[(wg + job)][src_row][i]
+struct ReduceSpec {
+    u32 nrows;
     u32 src_row[5];
-    u32 n[5];
+    u32 dst_row[5];     // row of the result block (PMX_ROW_*), or 1024-u64 row of out2
+    u32 n[5];           // elements that are sums over slab segments
+    u32 nfill[5];       // elements written in total (>= n): the rest of the row is zero-filled
+    u32 out_stride;
+    u32 use_out2;       // autocorrelation: rows go to out2 (per-job scratch) instead of the result block
+    u32 nzero;          // rows of the result block this batch does not produce: written as zeros
+    u32 zero_row[5];
 };
 
-__global__ void __launch_bounds__(256) k_reduce_slab(const u32 *__restrict__ slab, u32 nwg, u32 rows_per_wg, ReduceRows rr)
+__global__ void __launch_bounds__(256)
+k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_rows, ReduceSpec rs)
 {
-    // 32 consecutive elements x 8 workgroup phases per block: every load is a full 128-B line and each thread
-    // keeps 8 independent loads in flight
+    // 32 consecutive elements x 8 workgroup phases per block: every load is a full 128-B line
     __shared__ u64 part[8][32];
-    const u32 r = blockIdx.y;
+    const u32 r = blockIdx.y, job = blockIdx.z;
+    const SpJobDev &jb = jobs.j[job];
     const u32 e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const u32 i = blockIdx.x * 32 + e;
-    const u32 n = rr.n[r];
+    if (r >= rs.nrows) {   // a row this batch leaves empty
+        if (g == 0 && i < rs.out_stride) jb.out[(size_t)rs.zero_row[r - rs.nrows] * rs.out_stride + i] = 0;
+        return;
+    }
+    const u32 n = rs.n[r];
     u64 sum = 0;
     if (i < n) {
-        const size_t stride = (size_t)rows_per_wg * 1024;
-        const u32 *p = slab + (size_t)rr.src_row[r] * 1024 + i;
-        u32 w = g;
-        for (; w + 56 < nwg; w += 64) {
-            u32 v[8];
-#pragma unroll
-            for (u32 k = 0; k < 8; k++) v[k] = p[(size_t)(w + 8 * k) * stride];
-#pragma unroll
-            for (u32 k = 0; k < 8; k++) sum += v[k];
-        }
-        for (; w < nwg; w += 8) sum += p[(size_t)w * stride];
+        const size_t stride = (size_t)seg_rows * 1024;
+        const u32 *p = slab + (size_t)rs.src_row[r] * 1024 + i;
+        for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 8) sum += p[(size_t)(w + job) * stride];
     }
     part[g][e] = sum;
     __syncthreads();
-    if (g == 0 && i < n) {
+    if (g == 0 && i < rs.nfill[r]) {
         u64 t = 0;
 #pragma unroll
         for (u32 k = 0; k < 8; k++) t += part[k][e];
-        rr.dst[r][i] = t;
+        u64 *dst = rs.use_out2 ? jb.out2 + (size_t)rs.dst_row[r] * 1024 : jb.out + (size_t)rs.dst_row[r] * rs.out_stride;
+        if (!rs.use_out2 && rs.dst_row[r] == PMX_ROW_SCALARS && i == 3) t = PMX_PATH_SPARSE;   // the path that ran
+        dst[i] = t;
     }
 }
 
@@ -607,11 +696,17 @@ __global__ void __launch_bounds__(256) k_reduce_slab(const u32 *__restrict__ sla
 // are window sums driven by the edges only (two edges per mappable run), computed with the same set-bit
 // machinery as k_cc_sparse.  k_autocorr_finish runs the integer recurrence.
 #define AC_W (SP_TBW + SP_RHI)       // dwords of U / D per tile
-#define AC_OFF_U 0u
-#define AC_OFF_D (AC_OFF_U + AC_W)
-#define AC_OFF_L (AC_OFF_D + AC_W)
-#define AC_OFF_MISC (AC_OFF_L + SP_CAP + 256)
-#define AC_LDS_DWORDS (AC_OFF_MISC + 16)
+struct AcLds {
+    static constexpr u32 ZERO = 0;
+    static constexpr u32 U = 40;
+    static constexpr u32 D = U + AC_W;
+    static constexpr u32 LST = D + AC_W;                 // records (4 dwords each)
+    static constexpr u32 ACC = LST + 4 * SP_CAP;         // [2][plane][32]
+    static constexpr u32 STAGE = ACC + 2 * SP_NL * 32;
+    static constexpr u32 MISC = STAGE + 4 * SP_NS * 32;
+    static constexpr u32 TOTAL = MISC + 16;
+};
+#define AC_SEG_ROWS 3u               // P, N, scalars
 
 struct AcRegs {
     uint4 m, h;   // main quad + (threads 0..8) the quad above the tile
@@ -634,6 +729,16 @@ __device__ __forceinline__ void ac_fetch(AcRegs &ar, const u32 *__restrict__ M, 
     }
 }
 
+__device__ __forceinline__ void ac_fetch_job(AcRegs &ar, const SpJobDev &jb, u32 local_tile, u32 tid)
+{
+    const uint64_t hi = (uint64_t)local_tile * SP_TBW + SP_TBW + SP_RHI;
+    const bool interior = jb.aligned16 && local_tile > 0 && hi + 2 <= jb.nbits / 32;
+    if (interior)
+        ac_fetch<false>(ar, jb.M, (int64_t)local_tile * SP_TBW, jb.nbits, tid);
+    else
+        ac_fetch<true>(ar, jb.M, (int64_t)local_tile * SP_TBW, jb.nbits, tid);
+}
+
 // rising (U) and falling (D) edge words of a quad; `below` = the dword preceding m.x
 __device__ __forceinline__ void edge_quad(const uint4 m, u32 below, uint4 &U, uint4 &D)
 {
@@ -643,123 +748,159 @@ __device__ __forceinline__ void edge_quad(const uint4 m, u32 below, uint4 &U, ui
     D = make_uint4(~m.x & s0, ~m.y & s1, ~m.z & s2, ~m.w & s3);
 }
 
-__device__ __forceinline__ void ac_flush_boundary(Planes &cP, Planes &cN, u32 &qc, u32 *lds, u32 l, u32 tid,
-                                                  u32 *__restrict__ slab)
+// Edge records: {shift word, byte address of the SAME-sign edge vector window (lane adds 4l),
+//                byte address of the OPPOSITE-sign edge vector window, 0}
+__device__ __forceinline__ void emit_edges(const uint4 w, const uint4 fall, u32 idx0, u32 round_lo, u32 *lds, u32 tid)
 {
-    u32 *acc = lds;
-    __syncthreads();
-    for (u32 i = tid; i < 2048; i += 256) acc[i] = 0;
-    __syncthreads();
-    planes_flush_lds(cP, qc, acc, l);
-    planes_flush_lds(cN, qc, acc + 1024, l);
-    qc = 0;
-    __syncthreads();
-    for (u32 k = tid; k < 1024; k += 256) {
-        const u32 a = (k & 31) * 32 + (k >> 5);
-        const u32 vp = acc[a], vn = acc[1024 + a];
-        if (vp) atomicAdd(&slab[k], vp);
-        if (vn) atomicAdd(&slab[1024 + k], vn);
+    uint4 *list = reinterpret_cast<uint4 *>(lds + AcLds::LST);
+    u32 id = idx0 - round_lo;
+    const u32 ws[4] = {w.x, w.y, w.z, w.w};
+    const u32 fs[4] = {fall.x, fall.y, fall.z, fall.w};
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        u32 ww = ws[k];
+        while (ww) {
+            const u32 b = __builtin_ctz(ww);
+            ww &= ww - 1;
+            if (id < SP_CAP) {
+                const u32 pos = 128u * tid + 32u * k + b;
+                const u32 is_fall = (fs[k] >> b) & 1u;
+                const u32 au = (AcLds::U + (pos >> 5)) * 4u, ad = (AcLds::D + (pos >> 5)) * 4u;
+                list[id] = make_uint4(pos, is_fall ? ad : au, is_fall ? au : ad, 0u);
+            }
+            id++;
+        }
     }
-    __syncthreads();
 }
 
 __global__ void __launch_bounds__(256, 3)
-k_autocorr_edges(const u32 *__restrict__ M, uint64_t nbits, u32 lgG, u32 ntiles, u32 aligned16,
-                 u32 *__restrict__ slab_all)
+k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab)
 {
-    __shared__ __align__(16) u32 lds[AC_LDS_DWORDS];
-    const u32 *const sU = lds + AC_OFF_U;
-    const u32 *const sD = lds + AC_OFF_D;
-    u32 *const list = lds + AC_OFF_L;
-    u32 *const cursor = lds + AC_OFF_MISC;
+    typedef AcLds L;
+    __shared__ __align__(16) u32 lds[L::TOTAL];
+    u32 *const cursor = lds + L::MISC;
+    u32 *const acc = lds + L::ACC;
+    u32 *const stage = lds + L::STAGE;
 
     const u32 tid = threadIdx.x;
     const SlotGeom sg = slot_geom(lgG, tid);
-    const u32 l = sg.l;
-    u32 *const slab = slab_all + (size_t)blockIdx.x * 3 * 1024;   // rows: P, N, scalars
+    const u32 zero_up = L::ZERO * 4u;
+
+    const u32 g0 = blockIdx.x * tiles_per_wg;
+    const u32 g1 = g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles;
+    if (g0 >= g1) return;
+
+    for (u32 i = tid; i < 40; i += 256) lds[L::ZERO + i] = 0;
+    for (u32 i = tid; i < 2 * SP_NL * 32; i += 256) acc[i] = 0;
 
     Planes cP, cN;
     planes_zero(cP);
     planes_zero(cN);
-    u32 qc = 0;
+    u32 qc = 0, q2 = 0;
     u32 cntM = 0, cntU = 0;
+    bool seg_written = false;
 
-    const uint64_t full_dw = nbits / 32;
-    auto interior = [&](u32 t) -> bool {
-        if (!aligned16 || t == 0) return false;
-        const uint64_t hi = (uint64_t)t * SP_TBW + SP_TBW + SP_RHI;
-        return hi + 2 <= full_dw;
+    u32 ji = 0;
+    while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
+
+    auto fold_all = [&]() {
+        counter_to_lds(cP, qc, lgG, tid, stage, acc);
+        counter_to_lds(cN, qc, lgG, tid, stage, acc + SP_NL * 32);
+        q2 += qc * 4u * sg.total_slots;
+        qc = 0;
+    };
+    auto convert = [&](u32 j, bool final) {
+        u32 *seg = slab + (size_t)(blockIdx.x + j) * AC_SEG_ROWS * 1024;
+        __syncthreads();
+        for (u32 q = 0; q < 2; q++) {
+            const u32 *a = acc + q * SP_NL * 32;
+            u32 *row = seg + q * 1024;
+            for (u32 d = tid; d < 1024; d += 256) {
+                const u32 l = d >> 5, i = d & 31;
+                u32 v = seg_written ? row[d] : 0u;
+#pragma unroll
+                for (int k = 0; k < SP_NL; k++) v += ((a[k * 32 + l] >> i) & 1u) << k;
+                row[d] = v;
+            }
+        }
+        __syncthreads();
+        for (u32 i = tid; i < 2 * SP_NL * 32; i += 256) acc[i] = 0;
+        q2 = 0;
+        seg_written = true;
+        if (final) {
+            u32 vm = cntM, vu = cntU;
+            for (int off = 32; off > 0; off >>= 1) {
+                vm += __shfl_down(vm, off, 64);
+                vu += __shfl_down(vu, off, 64);
+            }
+            if ((tid & 63) == 0) {
+                cursor[4 + (tid >> 6)] = vm;
+                cursor[8 + (tid >> 6)] = vu;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                seg[2048 + 0] = cursor[4] + cursor[5] + cursor[6] + cursor[7];     // popcount(M) of my tiles
+                seg[2048 + 1] = cursor[8] + cursor[9] + cursor[10] + cursor[11];   // runs starting in my tiles
+            }
+            cntM = 0;
+            cntU = 0;
+            seg_written = false;
+        }
+        __syncthreads();
     };
 
     AcRegs ar;
-    u32 tile = blockIdx.x;
-    if (tile < ntiles) {
-        if (interior(tile))
-            ac_fetch<false>(ar, M, (int64_t)tile * SP_TBW, nbits, tid);
-        else
-            ac_fetch<true>(ar, M, (int64_t)tile * SP_TBW, nbits, tid);
-    }
+    ac_fetch_job(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (u32 g = g0; g < g1; g++) {
         __syncthreads();
-        if (qc >= SP_QSOFT) ac_flush_boundary(cP, cN, qc, lds, l, tid, slab);
+        if (qc >= SP_QSOFT) fold_all();
+        if (q2 >= SP_L2LIMIT) convert(ji, false);
 
         uint4 U, D;
         edge_quad(ar.m, ar.below, U, D);
-        reinterpret_cast<uint4 *>(lds + AC_OFF_U)[tid] = U;
-        reinterpret_cast<uint4 *>(lds + AC_OFF_D)[tid] = D;
+        reinterpret_cast<uint4 *>(lds + L::U)[tid] = U;
+        reinterpret_cast<uint4 *>(lds + L::D)[tid] = D;
         const uint4 E = make_uint4(U.x | D.x, U.y | D.y, U.z | D.z, U.w | D.w);
         cntM += __popc(ar.m.x) + __popc(ar.m.y) + __popc(ar.m.z) + __popc(ar.m.w);
         cntU += __popc(U.x) + __popc(U.y) + __popc(U.z) + __popc(U.w);
         if (tid < 9) {
             uint4 Uh, Dh;
             edge_quad(ar.h, ar.hbelow, Uh, Dh);
-            reinterpret_cast<uint4 *>(lds + AC_OFF_U + SP_TBW)[tid] = Uh;
-            reinterpret_cast<uint4 *>(lds + AC_OFF_D + SP_TBW)[tid] = Dh;
+            reinterpret_cast<uint4 *>(lds + L::U + SP_TBW)[tid] = Uh;
+            reinterpret_cast<uint4 *>(lds + L::D + SP_TBW)[tid] = Dh;
         }
         if (tid == 0) cursor[0] = 0;
         __syncthreads();
 
-        {
-            const u32 nt = tile + gridDim.x;
-            if (nt < ntiles) {
-                if (interior(nt))
-                    ac_fetch<false>(ar, M, (int64_t)nt * SP_TBW, nbits, tid);
-                else
-                    ac_fetch<true>(ar, M, (int64_t)nt * SP_TBW, nbits, tid);
-            }
+        u32 jn = ji;
+        if (g + 1 < g1) {
+            if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
+            ac_fetch_job(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
         }
 
-        const EmitState es = emit_reserve(E, &cursor[0]);
-        emit_write<true>(es, 0, list, sD, 0, tid);   // flag = falling edge
+        const u32 i0 = emit_reserve(E, &cursor[0]);
+        emit_edges(E, D, i0, 0, lds, tid);
         __syncthreads();
         const u32 n = cursor[0];
         for (u32 round_lo = 0; round_lo < n; round_lo += SP_CAP) {
             if (round_lo) {
                 __syncthreads();
-                emit_write<true>(es, round_lo, list, sD, 0, tid);
+                emit_edges(E, D, i0, round_lo, lds, tid);
             }
             const u32 nr = n - round_lo < SP_CAP ? n - round_lo : SP_CAP;
-            emit_pad(list, nr, sg.quad_span, tid);
-            __syncthreads();
             const u32 nq = (nr + sg.quad_span - 1) / sg.quad_span;
-            if (qc + nq > SP_QLIMIT) {
-                planes_flush_slab(cP, qc, slab, l);
-                planes_flush_slab(cN, qc, slab + 1024, l);
-                qc = 0;
-            }
+            emit_pad(reinterpret_cast<uint4 *>(lds + L::LST), nr, nq * sg.quad_span, zero_up, zero_up, tid);
+            __syncthreads();
+            if (qc + nq > SP_QLIMIT) fold_all();
+            const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LST) + sg.slot * 4 * nq;
             for (u32 q = 0; q < nq; q++) {
                 u32 wp[4], wn[4];
 #pragma unroll
                 for (u32 k = 0; k < 4; k++) {
-                    const u32 e = list[(q * 4 + k) * sg.total_slots + sg.slot];
-                    const u32 vmask = (u32)__builtin_amdgcn_sbfe(e, 17, 1);
-                    const u32 fall = (u32)__builtin_amdgcn_sbfe(e, 16, 1);
-                    const u32 wi = ((e >> 5) & 1023u) + l;
-                    const u32 wu = __builtin_amdgcn_alignbit(sU[wi + 1], sU[wi], e) & vmask;
-                    const u32 wd = __builtin_amdgcn_alignbit(sD[wi + 1], sD[wi], e) & vmask;
-                    wp[k] = (fall & wd) | (~fall & wu);   // same-sign pairs: U*U, D*D
-                    wn[k] = (fall & wu) | (~fall & wd);   // opposite-sign pairs: U*D, D*U
+                    const uint4 rec = recs[q * 4 + k];
+                    wp[k] = lds_window(lds, rec.y + sg.l4, rec.x);   // same-sign pairs: U*U, D*D
+                    wn[k] = lds_window(lds, rec.z + sg.l4, rec.x);   // opposite-sign pairs: U*D, D*U
                 }
                 const u32 qq = __builtin_amdgcn_readfirstlane(qc + q);
                 add_quad(cP, wp[0], wp[1], wp[2], wp[3], qq);
@@ -767,32 +908,25 @@ k_autocorr_edges(const u32 *__restrict__ M, uint64_t nbits, u32 lgG, u32 ntiles,
             }
             qc += nq;
         }
-    }
 
-    // retire: counters -> slab rows, popcount(M) and #runs -> scalar row
-    __syncthreads();
-    ac_flush_boundary(cP, cN, qc, lds, l, tid, slab);
-    for (int off = 32; off > 0; off >>= 1) {
-        cntM += __shfl_down(cntM, off, 64);
-        cntU += __shfl_down(cntU, off, 64);
-    }
-    if ((tid & 63) == 0) {
-        cursor[4 + (tid >> 6)] = cntM;
-        cursor[8 + (tid >> 6)] = cntU;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        slab[2048 + 0] = cursor[4] + cursor[5] + cursor[6] + cursor[7];
-        slab[2048 + 1] = cursor[8] + cursor[9] + cursor[10] + cursor[11];
+        if (jn != ji || g + 1 == g1) {
+            __syncthreads();
+            fold_all();
+            convert(ji, true);
+            ji = jn;
+        }
     }
 }
 
-// A(k) recurrence + output.  mode 0: out[k] = A(k), k = 0..max_lag.  mode 1: out[d] = A(|c - d|), d = 0..max_shift.
+// A(k) recurrence + output, one block per job.  Per-job scratch out2: P[1024], N[1024], scalars.
+// mode 0: out[k] = A(k), k = 0..max_lag.  mode 1: out is a result block: row MLEN[d] = A(|c - d|), d = 0..max_shift,
+// and scalar [2] = popcount(M).
 __global__ void __launch_bounds__(256)
-k_autocorr_finish(const u64 *__restrict__ P, const u64 *__restrict__ N, const u64 *__restrict__ scal, u32 max_lag,
-                  u32 mode, int32_t c, u32 max_shift, u64 *__restrict__ out, u64 *__restrict__ popcount_out)
+k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 mode, int32_t c, u32 max_shift, u32 out_stride)
 {
     __shared__ long long A[1025];
+    const SpJobDev &jb = jobs.j[blockIdx.x];
+    const u64 *P = jb.out2, *N = jb.out2 + 1024, *scal = jb.out2 + 2048;
     if (threadIdx.x == 0) {
         long long a_prev = (long long)scal[0];            // A(0) = popcount(M)
         A[0] = a_prev;
@@ -807,15 +941,16 @@ k_autocorr_finish(const u64 *__restrict__ P, const u64 *__restrict__ N, const u6
                 A[k + 1] = a;
             }
         }
-        if (popcount_out) *popcount_out = scal[0];
+        if (mode == 1) jb.out[(size_t)PMX_ROW_SCALARS * out_stride + 2] = scal[0];
     }
     __syncthreads();
     if (mode == 0) {
-        for (u32 k = threadIdx.x; k <= max_lag; k += 256) out[k] = (u64)A[k];
+        for (u32 k = threadIdx.x; k <= max_lag; k += 256) jb.out[k] = (u64)A[k];
     } else {
+        u64 *dst = jb.out + (size_t)PMX_ROW_MLEN * out_stride;
         for (u32 d = threadIdx.x; d <= max_shift; d += 256) {
             const int32_t k = c - (int32_t)d;
-            out[d] = (u64)A[k < 0 ? -k : k];
+            dst[d] = (u64)A[k < 0 ? -k : k];
         }
     }
 }
@@ -825,82 +960,86 @@ k_autocorr_finish(const u64 *__restrict__ P, const u64 *__restrict__ N, const u6
 static uint32_t lg_slot_lanes(uint32_t max_shift)
 {
     const u32 need = (max_shift + 1 + 31) / 32;
-    u32 lg = 2;   // G >= 4 keeps the list padding granule (16 * 64 / G entries) within one workgroup pass
+    u32 lg = 2;   // G >= 4 keeps the record padding granule (16 * 64 / G records) within one workgroup pass
     while ((1u << lg) < need) lg++;
     return lg;
 }
 
-static uint32_t sparse_grid(pmx_ctx *ctx, uint64_t ntiles, uint32_t wg_per_cu)
-{
-    uint64_t gx = (uint64_t)ctx->num_cus * wg_per_cu;
-    if (gx > ntiles) gx = ntiles;
-    if (gx < 1) gx = 1;
-    return (uint32_t)gx;
-}
-
 static inline bool is_aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
-
-// d_tmp: 2 * 1024 + 16 u64 of scratch (P, N, scalars).
-int pmx_launch_autocorr_edges(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_tmp,
-                              uint32_t mode, uint32_t read_len, uint32_t max_shift, u64 *d_out, u64 *d_popcount_out)
-{
-    const uint64_t ntiles = (nbits + 1 + SP_TB - 1) / SP_TB;     // E lives on [0, nbits]
-    const uint32_t gx = sparse_grid(ctx, ntiles, 3);
-    int rc = pmx_ensure_slab(ctx, (size_t)gx * 3 * 1024);
-    if (rc) return rc;
-    u64 *P = d_tmp, *N = d_tmp + 1024, *scal = d_tmp + 2048;
-    PMX_HIP(hipMemsetAsync(ctx->d_slab, 0, (size_t)gx * 3 * 1024 * sizeof(u32), ctx->stream));
-    pmx_timed_launch tl;
-    rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_autocorr_edges, dim3(gx), dim3(256), 0, ctx->stream, (const u32 *)d_M, nbits,
-                       lg_slot_lanes(max_lag), (u32)ntiles, (u32)is_aligned16(d_M), ctx->d_slab);
-    PMX_CHECK_LAUNCH("k_autocorr_edges");
-    rc = pmx_prof_end(ctx, &tl);
-    if (rc) return rc;
-    ReduceRows rr = {};
-    rr.dst[0] = P; rr.src_row[0] = 0; rr.n[0] = max_lag + 1;
-    rr.dst[1] = N; rr.src_row[1] = 1; rr.n[1] = max_lag + 1;
-    rr.dst[2] = scal; rr.src_row[2] = 2; rr.n[2] = 2;
-    hipLaunchKernelGGL(k_reduce_slab, dim3((max_lag + 32) / 32, 3), dim3(256), 0, ctx->stream,
-                       (const u32 *)ctx->d_slab, gx, 3u, rr);
-    PMX_CHECK_LAUNCH("k_reduce_slab");
-    hipLaunchKernelGGL(k_autocorr_finish, dim3(1), dim3(256), 0, ctx->stream, (const u64 *)P, (const u64 *)N,
-                       (const u64 *)scal, max_lag, mode, (int32_t)read_len - 1, max_shift, d_out, d_popcount_out);
-    PMX_CHECK_LAUNCH("k_autocorr_finish");
-    return PMX_OK;
-}
 
 int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len)
 {
     return max_shift >= 3 && max_shift <= 1023 && read_len >= 1 && read_len <= 1024;
 }
 
-int pmx_launch_cc_sparse(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
-                         uint64_t nbits, uint32_t max_shift, uint32_t read_len, bool do_ncc, u64 *d_out,
-                         uint32_t out_stride)
+uint32_t pmx_sparse_max_jobs(void) { return SP_MAXJOBS; }
+
+// Cuts the global tile sequence of a batch into per-workgroup ranges and fills the device job table.
+static void plan_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, bool autocorr, uint32_t wg_per_cu,
+                       SpJobTable *tab, uint32_t *total_tiles, uint32_t *tiles_per_wg, uint32_t *nwg)
 {
-    if (!d_M && !do_ncc) return PMX_OK;
-    uint64_t ntiles = (nbits + SP_TB - 1) / SP_TB;
-    if (ntiles < 1) ntiles = 1;
-    const int32_t c = (int32_t)read_len - 1;
-    const uint32_t gx = sparse_grid(ctx, ntiles, d_M ? 2 : 4);
-    int rc = pmx_ensure_slab(ctx, (size_t)gx * SP_SLAB_ROWS * 1024);
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < njobs; i++) {
+        SpJobDev &d = tab->j[i];
+        const uint64_t bits = jobs[i].nbits + (autocorr ? 1 : 0);   // edges live on [0, nbits]
+        uint64_t nt = (bits + SP_TB - 1) / SP_TB;
+        if (nt < 1) nt = 1;
+        d.F = (const u32 *)jobs[i].d_F;
+        d.R = (const u32 *)jobs[i].d_R;
+        d.M = (const u32 *)jobs[i].d_M;
+        d.nbits = jobs[i].nbits;
+        d.tile0 = t;
+        d.ntiles = (u32)nt;
+        d.aligned16 = autocorr ? is_aligned16(jobs[i].d_M)
+                               : (is_aligned16(jobs[i].d_F) && is_aligned16(jobs[i].d_R) &&
+                                  (!jobs[i].d_M || is_aligned16(jobs[i].d_M)));
+        d.out = (u64 *)jobs[i].d_out;
+        d.out2 = (u64 *)jobs[i].d_out2;
+        d.pad = 0;
+        t += (u32)nt;
+    }
+    uint64_t want = (uint64_t)ctx->num_cus * wg_per_cu;
+    if (want > t) want = t;
+    if (want < 1) want = 1;
+    const uint32_t tpw = (uint32_t)((t + want - 1) / want);
+    const uint32_t n = (t + tpw - 1) / tpw;
+    for (uint32_t i = 0; i < njobs; i++) {
+        SpJobDev &d = tab->j[i];
+        d.wg_first = d.tile0 / tpw;
+        d.wg_last = (d.tile0 + d.ntiles - 1) / tpw;
+    }
+    *total_tiles = t;
+    *tiles_per_wg = tpw;
+    *nwg = n;
+}
+
+int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
+                               uint32_t read_len, bool do_ncc, uint32_t out_stride)
+{
+    if (njobs == 0) return PMX_OK;
+    if (njobs > SP_MAXJOBS) {
+        pmx_set_error("pmx_launch_cc_sparse_batch: at most %u jobs per launch", SP_MAXJOBS);
+        return PMX_ERR_INVALID;
+    }
+    const bool has_m = jobs[0].d_M != nullptr;
+    if (!has_m && !do_ncc) return PMX_OK;
+    SpJobTable tab;
+    memset(&tab, 0, sizeof tab);
+    uint32_t total, tpw, nwg;
+    plan_batch(ctx, jobs, njobs, false, has_m ? 2 : 4, &tab, &total, &tpw, &nwg);
+    int rc = pmx_ensure_slab(ctx, (size_t)(nwg + njobs) * SP_SEG_ROWS * 1024);
     if (rc) return rc;
-    const dim3 grid(gx), block(256);
-    const u32 *F = (const u32 *)d_F, *R = (const u32 *)d_R, *M = (const u32 *)d_M;
-    const u32 al = is_aligned16(d_F) && is_aligned16(d_R) && (!d_M || is_aligned16(d_M));
+    const int32_t c = (int32_t)read_len - 1;
     const u32 lgG = lg_slot_lanes(max_shift);
-    PMX_HIP(hipMemsetAsync(ctx->d_slab, 0, (size_t)gx * SP_SLAB_ROWS * 1024 * sizeof(u32), ctx->stream));
     pmx_timed_launch tl;
     rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl);
     if (rc) return rc;
-#define SP_LAUNCH(HM, NC)                                                                                          \
-    hipLaunchKernelGGL((k_cc_sparse<HM, NC>), grid, block, 0, ctx->stream, F, R, M, nbits, c, lgG, (u32)ntiles, al, \
+#define SP_LAUNCH(HM, NC)                                                                                       \
+    hipLaunchKernelGGL((k_cc_sparse<HM, NC>), dim3(nwg), dim3(256), 0, ctx->stream, tab, njobs, total, tpw, c, lgG, \
                        ctx->d_slab)
-    if (d_M && do_ncc)
+    if (has_m && do_ncc)
         SP_LAUNCH(true, true);
-    else if (d_M)
+    else if (has_m)
         SP_LAUNCH(true, false);
     else
         SP_LAUNCH(false, true);
@@ -908,20 +1047,73 @@ int pmx_launch_cc_sparse(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R,
     PMX_CHECK_LAUNCH("k_cc_sparse");
     rc = pmx_prof_end(ctx, &tl);
     if (rc) return rc;
-    // sum the per-workgroup slabs into the result block
-    u64 *scal = d_out + (size_t)PMX_ROW_SCALARS * out_stride;
-    ReduceRows rr = {};
+    // sum the per-workgroup slab segments into the result blocks
+    ReduceSpec rs;
+    memset(&rs, 0, sizeof rs);
     u32 nr = 0;
-    if (do_ncc) { rr.dst[nr] = d_out + (size_t)PMX_ROW_NCC_CCBINS * out_stride; rr.src_row[nr] = 0; rr.n[nr] = max_shift + 1; nr++; }
-    if (d_M) {
-        rr.dst[nr] = d_out + (size_t)PMX_ROW_MSCC_FSUM * out_stride; rr.src_row[nr] = 1; rr.n[nr] = max_shift + 1; nr++;
-        rr.dst[nr] = d_out + (size_t)PMX_ROW_MSCC_CCBINS * out_stride; rr.src_row[nr] = 2; rr.n[nr] = max_shift + 1; nr++;
-        rr.dst[nr] = d_out + (size_t)PMX_ROW_MSCC_RSUM * out_stride; rr.src_row[nr] = 3; rr.n[nr] = max_shift + 1; nr++;
+    u32 nz = 0;
+    const u32 S1 = max_shift + 1;
+    if (do_ncc) { rs.src_row[nr] = 0; rs.dst_row[nr] = PMX_ROW_NCC_CCBINS; rs.n[nr] = S1; rs.nfill[nr] = S1; nr++; }
+    else rs.zero_row[nz++] = PMX_ROW_NCC_CCBINS;
+    if (has_m) {
+        rs.src_row[nr] = 1; rs.dst_row[nr] = PMX_ROW_MSCC_FSUM; rs.n[nr] = S1; rs.nfill[nr] = S1; nr++;
+        rs.src_row[nr] = 2; rs.dst_row[nr] = PMX_ROW_MSCC_CCBINS; rs.n[nr] = S1; rs.nfill[nr] = S1; nr++;
+        rs.src_row[nr] = 3; rs.dst_row[nr] = PMX_ROW_MSCC_RSUM; rs.n[nr] = S1; rs.nfill[nr] = S1; nr++;
+    } else {
+        rs.zero_row[nz++] = PMX_ROW_MSCC_FSUM;
+        rs.zero_row[nz++] = PMX_ROW_MSCC_CCBINS;
+        rs.zero_row[nz++] = PMX_ROW_MSCC_RSUM;
+        rs.zero_row[nz++] = PMX_ROW_MLEN;
     }
-    rr.dst[nr] = scal; rr.src_row[nr] = 4; rr.n[nr] = 2; nr++;
-    hipLaunchKernelGGL(k_reduce_slab, dim3((max_shift + 32) / 32, nr), dim3(256), 0, ctx->stream,
-                       (const u32 *)ctx->d_slab, gx, (u32)SP_SLAB_ROWS, rr);
-    PMX_CHECK_LAUNCH("k_reduce_slab");
-    PMX_HIP(hipMemsetD32Async((hipDeviceptr_t)(scal + 3), PMX_PATH_SPARSE, 1, ctx->stream));
+    rs.src_row[nr] = 4; rs.dst_row[nr] = PMX_ROW_SCALARS; rs.n[nr] = 2; rs.nfill[nr] = S1; nr++;
+    rs.nrows = nr;
+    rs.nzero = nz;
+    rs.out_stride = out_stride;
+    rs.use_out2 = 0;
+    hipLaunchKernelGGL(k_reduce_segments, dim3((max_shift + 32) / 32, nr + nz, njobs), dim3(256), 0, ctx->stream,
+                       (const u32 *)ctx->d_slab, tab, (u32)SP_SEG_ROWS, rs);
+    PMX_CHECK_LAUNCH("k_reduce_segments");
+    return PMX_OK;
+}
+
+// jobs[i].d_M / nbits: the vector; jobs[i].d_out2: >= 2064 u64 of scratch per job (P, N, scalars);
+// mode 0: jobs[i].d_out[k] = A(k), k <= max_lag.  mode 1: jobs[i].d_out is a result block: row MLEN[d] = A(|L-1-d|),
+// scalar [2] = popcount(M).
+int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag, uint32_t mode,
+                                    uint32_t read_len, uint32_t max_shift, uint32_t out_stride)
+{
+    if (njobs == 0) return PMX_OK;
+    if (njobs > SP_MAXJOBS) {
+        pmx_set_error("pmx_launch_autocorr_edges_batch: at most %u jobs per launch", SP_MAXJOBS);
+        return PMX_ERR_INVALID;
+    }
+    SpJobTable tab;
+    memset(&tab, 0, sizeof tab);
+    uint32_t total, tpw, nwg;
+    plan_batch(ctx, jobs, njobs, true, 3, &tab, &total, &tpw, &nwg);
+    int rc = pmx_ensure_slab(ctx, (size_t)(nwg + njobs) * AC_SEG_ROWS * 1024);
+    if (rc) return rc;
+    pmx_timed_launch tl;
+    rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_autocorr_edges, dim3(nwg), dim3(256), 0, ctx->stream, tab, njobs, total, tpw,
+                       lg_slot_lanes(max_lag), ctx->d_slab);
+    PMX_CHECK_LAUNCH("k_autocorr_edges");
+    rc = pmx_prof_end(ctx, &tl);
+    if (rc) return rc;
+    ReduceSpec rs;
+    memset(&rs, 0, sizeof rs);
+    rs.nrows = 3;
+    rs.src_row[0] = 0; rs.dst_row[0] = 0; rs.n[0] = max_lag + 1; rs.nfill[0] = max_lag + 1;
+    rs.src_row[1] = 1; rs.dst_row[1] = 1; rs.n[1] = max_lag + 1; rs.nfill[1] = max_lag + 1;
+    rs.src_row[2] = 2; rs.dst_row[2] = 2; rs.n[2] = 2; rs.nfill[2] = 2;
+    rs.use_out2 = 1;
+    rs.out_stride = out_stride;
+    hipLaunchKernelGGL(k_reduce_segments, dim3((max_lag + 32) / 32, 3, njobs), dim3(256), 0, ctx->stream,
+                       (const u32 *)ctx->d_slab, tab, (u32)AC_SEG_ROWS, rs);
+    PMX_CHECK_LAUNCH("k_reduce_segments");
+    hipLaunchKernelGGL(k_autocorr_finish, dim3(njobs), dim3(256), 0, ctx->stream, tab, max_lag, mode,
+                       (int32_t)read_len - 1, max_shift, out_stride);
+    PMX_CHECK_LAUNCH("k_autocorr_finish");
     return PMX_OK;
 }

@@ -426,74 +426,117 @@ int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint
     if (rc) return rc;
     REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
             "pmx_mappable_len_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
-    if (!(flags & PMX_FLAG_FORCE_DENSE) && pmx_sparse_supported(max_shift, 1)) {
+    if (!(flags & PMX_FLAG_FORCE_DENSE) && pmx_sparse_supported(max_shift > 3 ? max_shift : 3, 1)) {
         rc = pmx_ensure_scratch(ctx, 4096);
         if (rc) return rc;
-        return pmx_launch_autocorr_edges(ctx, d_M, nbits, max_shift, ctx->d_scratch, 0, 1, max_shift, (u64 *)d_out,
-                                         nullptr);
+        pmx_job job = {nullptr, nullptr, d_M, nbits, d_out, (uint64_t *)ctx->d_scratch};
+        return pmx_launch_autocorr_edges_batch(ctx, &job, 1, max_shift, 0, 1, max_shift, max_shift + 1);
     }
     PMX_HIP(hipMemsetAsync(d_out, 0, ((size_t)max_shift + 1) * sizeof(u64), ctx->stream));
     return pmx_launch_autocorr_dense(ctx, d_M, nbits, max_shift, (u64 *)d_out);
+}
+
+// one chromosome through the dense kernels (atomics into a zeroed block)
+static int cc_dense_one(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M, uint64_t nbits,
+                        uint32_t max_shift, uint32_t read_len, bool do_ncc, uint64_t *d_out)
+{
+    const uint32_t stride = max_shift + 1;
+    u64 *out = (u64 *)d_out;
+    PMX_HIP(hipMemsetAsync(out, 0, (size_t)PMX_NROWS * stride * sizeof(u64), ctx->stream));
+    u64 *scal = out + (size_t)PMX_ROW_SCALARS * stride;
+    int rc = pmx_launch_count(ctx, d_F, nbits, scal + 0);
+    if (rc) return rc;
+    rc = pmx_launch_count(ctx, d_R, nbits, scal + 1);
+    if (rc) return rc;
+    rc = pmx_launch_cc_dense(ctx, d_F, d_R, d_M, nbits, max_shift, read_len, do_ncc, out, stride, scal, 2);
+    if (rc) return rc;
+    if (d_M) {
+        const uint32_t c = read_len - 1;
+        const uint32_t far = max_shift > c ? max_shift - c : 0;   // lags |c - d| over d in [0, max_shift]
+        const uint32_t max_lag = c > far ? c : far;
+        rc = pmx_launch_count(ctx, d_M, nbits, scal + 2);
+        if (rc) return rc;
+        rc = pmx_ensure_scratch(ctx, (size_t)max_lag + 1 + 16);
+        if (rc) return rc;
+        PMX_HIP(hipMemsetAsync(ctx->d_scratch, 0, ((size_t)max_lag + 1) * sizeof(u64), ctx->stream));
+        rc = pmx_launch_autocorr_dense(ctx, d_M, nbits, max_lag, ctx->d_scratch);
+        if (rc) return rc;
+        rc = pmx_launch_mlen_map(ctx, ctx->d_scratch, max_shift, read_len, out + (size_t)PMX_ROW_MLEN * stride);
+        if (rc) return rc;
+    }
+    return PMX_OK;
+}
+
+int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, const uint64_t *const *d_R,
+                     const uint64_t *const *d_M, const uint64_t *nbits, uint32_t max_shift, uint32_t read_len,
+                     uint32_t flags, uint64_t *const *d_out)
+{
+    REQUIRE(ctx && d_F && d_R && nbits && d_out, "pmx_cc_batch_dev: NULL argument");
+    REQUIRE(read_len >= 1 && read_len <= 65535, "pmx_cc_batch_dev: read_len must be in [1, 65535]");
+    REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
+            "pmx_cc_batch_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
+    REQUIRE(max_shift >= 3, "pmx_cc_batch_dev: max_shift must be >= 3");
+    if (njobs == 0) return PMX_OK;
+    const bool has_m = d_M != nullptr && d_M[0] != nullptr;
+    for (uint32_t i = 0; i < njobs; i++) {
+        REQUIRE(d_F[i] && d_R[i] && d_out[i], "pmx_cc_batch_dev: NULL vector or output in the batch");
+        REQUIRE((d_M != nullptr && d_M[i] != nullptr) == has_m,
+                "pmx_cc_batch_dev: mappability must be given for all jobs of a batch or for none");
+        int rc = check_shift_args(nbits[i], max_shift, "pmx_cc_batch_dev");
+        if (rc) return rc;
+    }
+    const bool do_ncc = !(flags & PMX_FLAG_SKIP_NCC);
+    const uint32_t stride = max_shift + 1;
+    const uint32_t c = read_len - 1;
+    const uint32_t far = max_shift > c ? max_shift - c : 0;   // lags |c - d| over d in [0, max_shift]
+    const uint32_t max_lag = c > far ? c : far;
+
+    // The set-bit kernels are correct for any input and faster than the dense ones unless the occupancy
+    // vectors are pathologically dense, so they are the default wherever the geometry is supported.
+    const bool sparse_ok = pmx_sparse_supported(max_shift, read_len) != 0 && max_lag <= 1023;
+    if ((flags & PMX_FLAG_FORCE_SPARSE) && !sparse_ok) {
+        pmx_set_error("pmx_cc_batch_dev: PMX_FLAG_FORCE_SPARSE needs 3 <= max_shift <= 1023 and read_len <= 1024");
+        return PMX_ERR_INVALID;
+    }
+    if (!sparse_ok || (flags & PMX_FLAG_FORCE_DENSE)) {
+        for (uint32_t i = 0; i < njobs; i++) {
+            int rc = cc_dense_one(ctx, d_F[i], d_R[i], has_m ? d_M[i] : nullptr, nbits[i], max_shift, read_len, do_ncc,
+                                  d_out[i]);
+            if (rc) return rc;
+        }
+        return PMX_OK;
+    }
+    const uint32_t chunk = pmx_sparse_max_jobs();
+    pmx_job jobs[64];
+    for (uint32_t lo = 0; lo < njobs; lo += chunk) {
+        const uint32_t n = njobs - lo < chunk ? njobs - lo : chunk;
+        if (has_m) {
+            int rc = pmx_ensure_scratch(ctx, (size_t)n * 2064);
+            if (rc) return rc;
+        }
+        for (uint32_t i = 0; i < n; i++) {
+            jobs[i].d_F = d_F[lo + i];
+            jobs[i].d_R = d_R[lo + i];
+            jobs[i].d_M = has_m ? d_M[lo + i] : nullptr;
+            jobs[i].nbits = nbits[lo + i];
+            jobs[i].d_out = d_out[lo + i];
+            jobs[i].d_out2 = has_m ? (uint64_t *)(ctx->d_scratch + (size_t)i * 2064) : nullptr;
+        }
+        int rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride);
+        if (rc) return rc;
+        if (has_m) {
+            rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
+            if (rc) return rc;
+        }
+    }
+    return PMX_OK;
 }
 
 int pmx_cc_dev(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M, uint64_t nbits,
                uint32_t max_shift, uint32_t read_len, uint32_t flags, uint64_t *d_out)
 {
     REQUIRE(ctx && d_F && d_R && d_out, "pmx_cc_dev: NULL argument");
-    int rc = check_shift_args(nbits, max_shift, "pmx_cc_dev");
-    if (rc) return rc;
-    REQUIRE(read_len >= 1 && read_len <= 65535, "pmx_cc_dev: read_len must be in [1, 65535]");
-    REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
-            "pmx_cc_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
-    REQUIRE(max_shift >= 3, "pmx_cc_dev: max_shift must be >= 3");
-    const bool do_ncc = !(flags & PMX_FLAG_SKIP_NCC);
-    const uint32_t stride = max_shift + 1;
-    u64 *out = (u64 *)d_out;
-    PMX_HIP(hipMemsetAsync(out, 0, (size_t)PMX_NROWS * stride * sizeof(u64), ctx->stream));
-    u64 *scal = out + (size_t)PMX_ROW_SCALARS * stride;
-
-    // The set-bit kernels are correct for any input and faster than the dense ones unless the occupancy
-    // vectors are pathologically dense, so they are the default wherever the geometry is supported.
-    const uint32_t c = read_len - 1;
-    const uint32_t far = max_shift > c ? max_shift - c : 0;   // lags |c - d| over d in [0, max_shift]
-    const uint32_t max_lag = c > far ? c : far;
-    const bool sparse_ok = pmx_sparse_supported(max_shift, read_len) != 0;
-    const bool use_sparse = sparse_ok && !(flags & PMX_FLAG_FORCE_DENSE);
-    if ((flags & PMX_FLAG_FORCE_SPARSE) && !sparse_ok) {
-        pmx_set_error("pmx_cc_dev: PMX_FLAG_FORCE_SPARSE needs 3 <= max_shift <= 1023 and read_len <= 4096");
-        return PMX_ERR_INVALID;
-    }
-    if (use_sparse) {
-        rc = pmx_launch_cc_sparse(ctx, d_F, d_R, d_M, nbits, max_shift, read_len, do_ncc, out, stride);
-        if (rc) return rc;
-    } else {
-        rc = pmx_launch_count(ctx, d_F, nbits, scal + 0);
-        if (rc) return rc;
-        rc = pmx_launch_count(ctx, d_R, nbits, scal + 1);
-        if (rc) return rc;
-        rc = pmx_launch_cc_dense(ctx, d_F, d_R, d_M, nbits, max_shift, read_len, do_ncc, out, stride, scal, 2);
-        if (rc) return rc;
-    }
-    if (d_M) {
-        if (use_sparse && max_lag <= 1023) {
-            rc = pmx_ensure_scratch(ctx, 4096);
-            if (rc) return rc;
-            rc = pmx_launch_autocorr_edges(ctx, d_M, nbits, max_lag, ctx->d_scratch, 1, read_len, max_shift,
-                                           out + (size_t)PMX_ROW_MLEN * stride, scal + 2);
-            if (rc) return rc;
-        } else {
-            rc = pmx_launch_count(ctx, d_M, nbits, scal + 2);
-            if (rc) return rc;
-            rc = pmx_ensure_scratch(ctx, (size_t)max_lag + 1 + 16);
-            if (rc) return rc;
-            PMX_HIP(hipMemsetAsync(ctx->d_scratch, 0, ((size_t)max_lag + 1) * sizeof(u64), ctx->stream));
-            rc = pmx_launch_autocorr_dense(ctx, d_M, nbits, max_lag, ctx->d_scratch);
-            if (rc) return rc;
-            rc = pmx_launch_mlen_map(ctx, ctx->d_scratch, max_shift, read_len, out + (size_t)PMX_ROW_MLEN * stride);
-            if (rc) return rc;
-        }
-    }
-    return PMX_OK;
+    return pmx_cc_batch_dev(ctx, 1, &d_F, &d_R, d_M ? &d_M : nullptr, &nbits, max_shift, read_len, flags, &d_out);
 }
 
 int pmx_calc_correlation(pmx_ctx *ctx, const uint64_t *h_F, const uint64_t *h_R, const uint64_t *h_M,

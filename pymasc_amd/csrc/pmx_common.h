@@ -77,18 +77,24 @@ int pmx_launch_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, u64 
 int pmx_launch_cc_dense(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
                         uint64_t nbits, uint32_t max_shift, uint32_t read_len, bool do_ncc,
                         u64 *d_out, uint32_t out_stride, const u64 *d_select, uint32_t select_mode);
-// set-bit driven cross-correlation (kernels_sparse.hip); same contract as pmx_launch_cc_dense.
-// select_mode: 0 = always run, 1 = run only if popcount(F)+popcount(R) (d_select[0..1]) is sparse
-// (the dense launcher takes the complementary case), so auto-selection needs no host round trip.
+// ---- set-bit driven kernels (kernels_sparse.hip): one launch covers a batch of chromosomes ------------------
+struct pmx_job {
+    const uint64_t *d_F, *d_R, *d_M;   // device bit-vectors (d_M null: no mappability; all jobs of a batch alike)
+    uint64_t nbits;
+    uint64_t *d_out;                   // result block [PMX_NROWS][out_stride] (or the lag row, autocorr mode 0)
+    uint64_t *d_out2;                  // autocorrelation only: >= 2064 u64 of per-job scratch
+};
 int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len);
-int pmx_launch_cc_sparse(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
-                         uint64_t nbits, uint32_t max_shift, uint32_t read_len, bool do_ncc, u64 *d_out,
-                         uint32_t out_stride);
+uint32_t pmx_sparse_max_jobs(void);
+// Writes rows NCC_CCBINS / MSCC_FSUM / MSCC_CCBINS / MSCC_RSUM and the scalar row of every job's result block
+// (rows the batch does not produce are written as zeros, MLEN included when there is no mappability).
+int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
+                               uint32_t read_len, bool do_ncc, uint32_t out_stride);
+// Run-edge autocorrelation of every job's d_M.  mode 0: d_out[k] = A(k), k <= max_lag.
+// mode 1: d_out is a result block: row MLEN[d] = A(|read_len - 1 - d|), d <= max_shift; scalar [2] = popcount(M).
+int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag,
+                                    uint32_t mode, uint32_t read_len, uint32_t max_shift, uint32_t out_stride);
 int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words);
-// run-edge autocorrelation (kernels_sparse.hip). d_tmp: >= 2064 u64 of scratch. mode 0: d_out[k] = A(k), k <= max_lag;
-// mode 1: d_out[d] = A(|read_len - 1 - d|), d <= max_shift. d_popcount_out (nullable) receives popcount(M).
-int pmx_launch_autocorr_edges(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_tmp,
-                              uint32_t mode, uint32_t read_len, uint32_t max_shift, u64 *d_out, u64 *d_popcount_out);
 // out[k] += sum_j M[j] & M[j+k], k = 0..max_lag
 int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_out);
 // mlen_by_shift[d] = autocorr[|read_len - 1 - d|], d = 0..max_shift

@@ -41,7 +41,7 @@ EXPORTS = [
     "pmx_bits_alloc", "pmx_bits_free", "pmx_bits_clear", "pmx_bits_upload", "pmx_bits_download",
     "pmx_bits_set_positions", "pmx_bits_set_positions_dev", "pmx_bits_set_regions", "pmx_bits_set_regions_dev",
     "pmx_bits_count",
-    "pmx_cc_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
+    "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
     "pmx_ctx_set_profiling", "pmx_ctx_reset_kernel_times", "pmx_ctx_kernel_time", "pmx_kernel_name",
 ]
 
@@ -83,6 +83,7 @@ def load_library(path: Optional[str] = None):
     L.pmx_bits_set_regions_dev.argtypes = [vp, vp, u64, vp, vp, u64]
     L.pmx_bits_count.argtypes = [vp, vp, u64, ctypes.POINTER(u64)]
     L.pmx_cc_dev.argtypes = [vp, vp, vp, vp, u64, u32, u32, u32, vp]
+    L.pmx_cc_batch_dev.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, vp]
     L.pmx_calc_correlation.argtypes = [vp, vp, vp, vp, u64, u32, u32, u32, vp]
     L.pmx_mappable_len_dev.argtypes = [vp, vp, u64, u32, u32, vp]
     L.pmx_mappable_len.argtypes = [vp, vp, u64, u32, u32, vp]
@@ -202,6 +203,16 @@ class Context:
         _check(self._L, self._L.pmx_cc_dev(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R),
                                            ctypes.c_void_p(d_M) if d_M else None, int(nbits), int(max_shift),
                                            int(read_len), int(flags), ctypes.c_void_p(d_out)))
+
+    def cc_batch_dev(self, d_F, d_R, d_M, nbits, max_shift: int, read_len: int, flags: int, d_out):
+        """One pass over a batch of chromosomes: sequences of device pointers / sizes (d_M None or full)."""
+        n = len(d_F)
+        assert len(d_R) == n and len(nbits) == n and len(d_out) == n and (d_M is None or len(d_M) == n)
+        arr = lambda xs: (ctypes.c_uint64 * n)(*[int(x) for x in xs])
+        aF, aR, aN, aO = arr(d_F), arr(d_R), arr(nbits), arr(d_out)
+        aM = arr(d_M) if d_M is not None else None
+        _check(self._L, self._L.pmx_cc_batch_dev(self._h, n, aF, aR, aM, aN, int(max_shift), int(read_len),
+                                                 int(flags), aO))
 
     def calc_correlation(self, F: np.ndarray, R: np.ndarray, M: Optional[np.ndarray], nbits: int, max_shift: int,
                          read_len: int, flags: int = 0) -> np.ndarray:
