@@ -41,7 +41,9 @@
 #define SP_NP 10                     // register counter: planes P[0..9], parked carries Q[2..10]
 #define SP_NQ 11
 #define SP_QLIMIT 511u               // quads a register counter may absorb between flushes (count < 2048)
+#ifndef SP_QSOFT
 #define SP_QSOFT 256u                // flush at a tile boundary once this many quads are pending
+#endif
 #define SP_NS 16                     // planes of a slot-combined number handed to the LDS accumulator
 #define SP_NL 24                     // planes of the workgroup accumulator in LDS
 #define SP_L2LIMIT (1u << 21)        // counts folded into the LDS accumulator before it is converted (< 2^24)
@@ -74,7 +76,7 @@ struct SpLds {
     static constexpr u32 ACC = LR + (HAS_M ? 4 * SP_CAP : 0);       // [counter][plane][32]
     static constexpr u32 NCOUNTERS = HAS_M ? 4 : 1;
     static constexpr u32 STAGE = ACC + NCOUNTERS * SP_NL * 32;      // [wave][plane][32]
-    static constexpr u32 MISC = STAGE + 4 * SP_NS * 32;
+    static constexpr u32 MISC = STAGE + 256 * SP_NQ;
     static constexpr u32 TOTAL = MISC + 16;
 };
 
@@ -160,78 +162,85 @@ __device__ __forceinline__ void fa(u32 a, u32 b, u32 cin, u32 &s, u32 &cout)
 }
 
 // Register counter -> workgroup accumulator in LDS (all 256 threads call this together):
-//   1. fold the parked carries into the planes (bit-sliced add inside the lane)          -> 11 planes
-//   2. add the slots of a wave together with cross-lane bit-sliced adds (xor shuffles)    -> <= 15 planes
-//   3. stage the per-wave numbers in LDS, barrier
-//   4. lanes 0..G-1 of wave 0 add the 4 staged numbers into acc[plane][l] (24 planes), barrier
-// The counter is cleared.  Costs a few hundred instructions; runs once per ~40 tiles at typical densities.
-__device__ __forceinline__ void counter_to_lds(Planes &c, u32 quadcnt, u32 lgG, u32 tid, u32 *stage, u32 *acc)
+//   1. every lane folds its parked carries into its planes (bit-sliced add) and writes the 11 planes of its
+//      slot to stage[slot][plane][l]
+//   2. barrier; lanes 0..G-1 of wave 0 add the staged numbers of all slots into acc[plane][l] (24 planes,
+//      read-modify-write in LDS so that this cold code needs almost no registers); barrier
+// Runs once per ~40 tiles at typical densities, so it is deliberately NOT inlined and register-lean: the
+// kernel's register allocation (hence its occupancy) is set by the hot loop, not by this.  The caller passes a
+// copy of its planes (the copy lives in scratch, the hot-loop planes stay in registers).
+__device__ __attribute__((noinline)) void counter_to_lds(const Planes *cp, u32 quadcnt, u32 lgG, u32 tid, u32 *stage,
+                                                         u32 *acc)
 {
 #ifdef SP_ABL_NOFLUSH
-    planes_zero(c);
     return;
 #endif
-    u32 n[SP_NS];
-    // 1. fold
-    {
-        n[0] = c.P[0];
-        n[1] = c.P[1];
-        u32 carry = 0;
-#pragma unroll
-        for (int k = 2; k < SP_NP; k++) {
-            const u32 qv = ((quadcnt >> (k - 2)) & 1u) ? c.Q[k] : 0u;
-            u32 s, co;
-            fa(c.P[k], qv, carry, s, co);
-            n[k] = s;
-            carry = co;
-        }
-        const u32 q10 = ((quadcnt >> 8) & 1u) ? c.Q[10] : 0u;
-        n[10] = q10 ^ carry;   // count < 2048: no carry out of plane 10
-#pragma unroll
-        for (int k = 11; k < SP_NS; k++) n[k] = 0;
-    }
-    planes_zero(c);
-    // 2. combine the slots of this wave: lanes ^ G, ^ 2G, ... hold the same shifts of other slots
-    for (u32 step = 1u << lgG; step < 64; step <<= 1) {
-        u32 carry = 0;
-#pragma unroll
-        for (int k = 0; k < SP_NS; k++) {
-            const u32 o = __shfl_xor(n[k], step, 64);
-            u32 s, co;
-            fa(n[k], o, carry, s, co);
-            n[k] = s;
-            carry = co;
-        }
-    }
-    // 3. stage (first slot of each wave)
-    const u32 lane = tid & 63, wave = tid >> 6;
     const u32 G = 1u << lgG;
-    if (lane < G) {
-#pragma unroll
-        for (int k = 0; k < SP_NS; k++) stage[(wave * SP_NS + k) * 32 + lane] = n[k];
+    const u32 slot = tid >> lgG, l = tid & (G - 1);
+    const u32 nslots = 256u >> lgG;
+    u32 *mine = stage + (slot * SP_NQ) * G + l;   // stage[slot][k][l], k < 11
+    {
+        mine[0] = cp->P[0];
+        mine[G] = cp->P[1];
+        u32 carry = 0;
+#pragma unroll 1
+        for (u32 k = 2; k < SP_NP; k++) {
+            const u32 qv = ((quadcnt >> (k - 2)) & 1u) ? cp->Q[k] : 0u;
+            u32 s, co;
+            fa(cp->P[k], qv, carry, s, co);
+            mine[k * G] = s;
+            carry = co;
+        }
+        const u32 q10 = ((quadcnt >> 8) & 1u) ? cp->Q[10] : 0u;
+        mine[10 * G] = q10 ^ carry;   // count < 2048: no carry out of plane 10
     }
     __syncthreads();
-    // 4. accumulate
     if (tid < G) {
-        u32 a[SP_NL];
-#pragma unroll
-        for (int k = 0; k < SP_NL; k++) a[k] = acc[k * 32 + tid];
-#pragma unroll
-        for (u32 w = 0; w < 4; w++) {
+#pragma unroll 1
+        for (u32 sl = 0; sl < nslots; sl++) {
+            const u32 *src = stage + (sl * SP_NQ) * G + tid;
             u32 carry = 0;
-#pragma unroll
-            for (int k = 0; k < SP_NL; k++) {
-                const u32 o = k < SP_NS ? stage[(w * SP_NS + k) * 32 + tid] : 0u;
+#pragma unroll 1
+            for (u32 k = 0; k < SP_NL; k++) {
+                const u32 o = k < SP_NQ ? src[k * G] : 0u;
+                if (k >= SP_NQ && carry == 0) break;   // nothing left to propagate (lane-local early out)
+                const u32 a = acc[k * 32 + tid];
                 u32 s, co;
-                fa(a[k], o, carry, s, co);
-                a[k] = s;
+                fa(a, o, carry, s, co);
+                acc[k * 32 + tid] = s;
                 carry = co;
             }
         }
-#pragma unroll
-        for (int k = 0; k < SP_NL; k++) acc[k * 32 + tid] = a[k];
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ void flush_counter(Planes &c, u32 quadcnt, u32 lgG, u32 tid, u32 *stage, u32 *acc)
+{
+    const Planes copy = c;
+    counter_to_lds(&copy, quadcnt, lgG, tid, stage, acc);
+    planes_zero(c);
+}
+
+// LDS accumulators (ncounters x 24 planes x 32 words) -> integers added into rows of a slab segment; cleared.
+// `seg_written`: the segment already holds an earlier partial conversion of this job (same thread owns d).
+__device__ __attribute__((noinline)) void acc_to_segment(u32 *acc, u32 ncounters, u32 *__restrict__ seg, bool seg_written,
+                                                         u32 tid)
+{
+    __syncthreads();
+    for (u32 q = 0; q < ncounters; q++) {
+        const u32 *a = acc + q * SP_NL * 32;
+        u32 *row = seg + q * 1024;
+        for (u32 d = tid; d < 1024; d += 256) {
+            const u32 l = d >> 5, i = d & 31;
+            u32 v = seg_written ? row[d] : 0u;
+#pragma unroll
+            for (int k = 0; k < SP_NL; k++) v += ((a[k * 32 + l] >> i) & 1u) << k;
+            row[d] = v;
+        }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < ncounters * SP_NL * 32; i += 256) acc[i] = 0;
 }
 
 // ---- tile staging --------------------------------------------------------------------------------------
@@ -443,8 +452,11 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 
 // ---- the cross-correlation kernel ---------------------------------------------------------------------------
 
+#ifndef SP_WAVES
+#define SP_WAVES 2
+#endif
 template <bool HAS_M, bool DO_NCC>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, SP_WAVES)
 k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
             u32 *__restrict__ slab)
 {
@@ -482,11 +494,11 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 
     // registers -> LDS accumulators (uniform call)
     auto fold_all = [&]() {
-        if (DO_NCC) counter_to_lds(cN, qF, lgG, tid, stage, acc);
+        if (DO_NCC) flush_counter(cN, qF, lgG, tid, stage, acc);
         if (HAS_M) {
-            counter_to_lds(cF, qF, lgG, tid, stage, acc + 1 * SP_NL * 32);
-            counter_to_lds(cC, qF, lgG, tid, stage, acc + 2 * SP_NL * 32);
-            counter_to_lds(cR, qR, lgG, tid, stage, acc + 3 * SP_NL * 32);
+            flush_counter(cF, qF, lgG, tid, stage, acc + 1 * SP_NL * 32);
+            flush_counter(cC, qF, lgG, tid, stage, acc + 2 * SP_NL * 32);
+            flush_counter(cR, qR, lgG, tid, stage, acc + 3 * SP_NL * 32);
         }
         q2 += (qF > qR ? qF : qR) * 4u * sg.total_slots;
         qF = 0;
@@ -495,20 +507,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     // LDS accumulators -> integers in this workgroup's slab segment for job `j` (uniform call)
     auto convert = [&](u32 j, bool final) {
         u32 *seg = slab + (size_t)(blockIdx.x + j) * SP_SEG_ROWS * 1024;
-        __syncthreads();
-        for (u32 q = 0; q < L::NCOUNTERS; q++) {
-            const u32 *a = acc + q * SP_NL * 32;
-            u32 *row = seg + q * 1024;
-            for (u32 d = tid; d < 1024; d += 256) {
-                const u32 l = d >> 5, i = d & 31;
-                u32 v = seg_written ? row[d] : 0u;   // an earlier partial conversion of this job (same thread)
-#pragma unroll
-                for (int k = 0; k < SP_NL; k++) v += ((a[k * 32 + l] >> i) & 1u) << k;
-                row[d] = v;
-            }
-        }
-        __syncthreads();
-        for (u32 i = tid; i < L::NCOUNTERS * SP_NL * 32; i += 256) acc[i] = 0;
+        acc_to_segment(acc, L::NCOUNTERS, seg, seg_written, tid);
         q2 = 0;
         seg_written = true;
         if (final) {
@@ -703,7 +702,7 @@ struct AcLds {
     static constexpr u32 LST = D + AC_W;                 // records (4 dwords each)
     static constexpr u32 ACC = LST + 4 * SP_CAP;         // [2][plane][32]
     static constexpr u32 STAGE = ACC + 2 * SP_NL * 32;
-    static constexpr u32 MISC = STAGE + 4 * SP_NS * 32;
+    static constexpr u32 MISC = STAGE + 256 * SP_NQ;
     static constexpr u32 TOTAL = MISC + 16;
 };
 #define AC_SEG_ROWS 3u               // P, N, scalars
@@ -804,27 +803,14 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
 
     auto fold_all = [&]() {
-        counter_to_lds(cP, qc, lgG, tid, stage, acc);
-        counter_to_lds(cN, qc, lgG, tid, stage, acc + SP_NL * 32);
+        flush_counter(cP, qc, lgG, tid, stage, acc);
+        flush_counter(cN, qc, lgG, tid, stage, acc + SP_NL * 32);
         q2 += qc * 4u * sg.total_slots;
         qc = 0;
     };
     auto convert = [&](u32 j, bool final) {
         u32 *seg = slab + (size_t)(blockIdx.x + j) * AC_SEG_ROWS * 1024;
-        __syncthreads();
-        for (u32 q = 0; q < 2; q++) {
-            const u32 *a = acc + q * SP_NL * 32;
-            u32 *row = seg + q * 1024;
-            for (u32 d = tid; d < 1024; d += 256) {
-                const u32 l = d >> 5, i = d & 31;
-                u32 v = seg_written ? row[d] : 0u;
-#pragma unroll
-                for (int k = 0; k < SP_NL; k++) v += ((a[k * 32 + l] >> i) & 1u) << k;
-                row[d] = v;
-            }
-        }
-        __syncthreads();
-        for (u32 i = tid; i < 2 * SP_NL * 32; i += 256) acc[i] = 0;
+        acc_to_segment(acc, 2, seg, seg_written, tid);
         q2 = 0;
         seg_written = true;
         if (final) {
@@ -1026,7 +1012,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     SpJobTable tab;
     memset(&tab, 0, sizeof tab);
     uint32_t total, tpw, nwg;
-    plan_batch(ctx, jobs, njobs, false, has_m ? 2 : 4, &tab, &total, &tpw, &nwg);
+    plan_batch(ctx, jobs, njobs, false, has_m ? SP_WAVES : 4, &tab, &total, &tpw, &nwg);
     int rc = pmx_ensure_slab(ctx, (size_t)(nwg + njobs) * SP_SEG_ROWS * 1024);
     if (rc) return rc;
     const int32_t c = (int32_t)read_len - 1;
