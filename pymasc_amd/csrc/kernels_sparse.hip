@@ -38,8 +38,8 @@
 #define SP_MW (SP_MLO + SP_TBW + SP_MHI)   // 1128 dwords of M per tile
 #define SP_HALO_M (SP_MLO * 32u)     // 2176 bits
 #define SP_CAP 512u                  // records per list round
-#define SP_NP 10                     // register counter: planes P[0..9], parked carries Q[2..10]
-#define SP_NQ 11
+#define SP_NP 11                     // register counter: planes P[0..10] + two parked carries (Q2, Q3)
+#define SP_NQ 11                     // planes of a folded per-slot number
 #define SP_QLIMIT 511u               // quads a register counter may absorb between flushes (count < 2048)
 #ifndef SP_QSOFT
 #define SP_QSOFT 256u                // flush at a tile boundary once this many quads are pending
@@ -82,15 +82,15 @@ struct SpLds {
 
 struct Planes {
     u32 P[SP_NP];
-    u32 Q[SP_NQ];   // Q[l], l >= 2: carry of weight 2^l parked at level l, valid iff bit (l-2) of the quad count
+    u32 Q2, Q3;   // parked carries of weight 4 / 8: valid iff bit 0 / bit 1 of the quad count
 };
 
 __device__ __forceinline__ void planes_zero(Planes &c)
 {
 #pragma unroll
     for (int l = 0; l < SP_NP; l++) c.P[l] = 0;
-#pragma unroll
-    for (int l = 0; l < SP_NQ; l++) c.Q[l] = 0;
+    c.Q2 = 0;
+    c.Q3 = 0;
 }
 
 // carry-save adder on gfx950's 3-input boolean op: acc = a ^ b ^ acc, carry = maj(a, b, acc)
@@ -102,56 +102,35 @@ __device__ __forceinline__ void csa(u32 &acc, u32 a, u32 b, u32 &carry)
     acc = s;
 }
 
-// add four 32-shift window words; quadcnt = quads this counter absorbed since its last flush (wave-uniform).
-// The weight-4 carry is inserted like an increment of a binary counter: levels whose quadcnt bit is set hold a
-// parked carry -> CSA and pass the carry up; the first level with a clear bit parks it.  Nested wave-uniform
-// branches on the number of trailing one bits; plane indices must stay compile-time constants or the planes
-// leave the register file (the asm markers keep the per-level stores from being merged into one indexed store).
+// Add four 32-shift window words; quadcnt = quads this counter absorbed since its last flush (wave-uniform).
+// A radix-16 Harley-Seal counter made resumable: every quad costs 3 carry-save adders and produces one carry of
+// weight 4; carries of weight 4 and 8 are parked (Q2, Q3) until their partner arrives, i.e. quad 4k+1 pairs the
+// weight-4 carries, quad 4k+3 pairs both levels and ripples the weight-16 carry through the upper planes with
+// half adders.  One wave-uniform branch on (quadcnt & 3); ~11 VALU ops per quad on average, 13 registers.
 __device__ __forceinline__ void add_quad(Planes &c, u32 w0, u32 w1, u32 w2, u32 w3, u32 quadcnt)
 {
     u32 c1a, c1b, c2;
     csa(c.P[0], w0, w1, c1a);
     csa(c.P[0], w2, w3, c1b);
     csa(c.P[1], c1a, c1b, c2);
-#define SP_CSA(L)                     \
-    {                                 \
-        u32 nx_;                      \
-        csa(c.P[L], c.Q[L], c2, nx_); \
-        c2 = nx_;                     \
+    if ((quadcnt & 1u) == 0u) {
+        c.Q2 = c2;
+    } else {
+        u32 c3;
+        csa(c.P[2], c.Q2, c2, c3);
+        if ((quadcnt & 2u) == 0u) {
+            c.Q3 = c3;
+        } else {
+            u32 cy;
+            csa(c.P[3], c.Q3, c3, cy);
+#pragma unroll
+            for (int l = 4; l < SP_NP; l++) {   // half adders
+                const u32 t = c.P[l] & cy;
+                c.P[l] ^= cy;
+                cy = t;
+            }
+        }
     }
-#define SP_PARK(L)                    \
-    {                                 \
-        c.Q[L] = c2;                  \
-        asm volatile("; park " #L);   \
-    }
-    const u32 tz = __builtin_ctz(~quadcnt);
-    if (tz > 0u) {
-        SP_CSA(2);
-        if (tz > 1u) {
-            SP_CSA(3);
-            if (tz > 2u) {
-                SP_CSA(4);
-                if (tz > 3u) {
-                    SP_CSA(5);
-                    if (tz > 4u) {
-                        SP_CSA(6);
-                        if (tz > 5u) {
-                            SP_CSA(7);
-                            if (tz > 6u) {
-                                SP_CSA(8);
-                                if (tz > 7u) {
-                                    SP_CSA(9);
-                                    c.Q[10] = c2;
-                                } else SP_PARK(9)
-                            } else SP_PARK(8)
-                        } else SP_PARK(7)
-                    } else SP_PARK(6)
-                } else SP_PARK(5)
-            } else SP_PARK(4)
-        } else SP_PARK(3)
-    } else SP_PARK(2)
-#undef SP_CSA
-#undef SP_PARK
 }
 
 // full adder on bit planes
@@ -162,7 +141,7 @@ __device__ __forceinline__ void fa(u32 a, u32 b, u32 cin, u32 &s, u32 &cout)
 }
 
 // Register counter -> workgroup accumulator in LDS (all 256 threads call this together):
-//   1. every lane folds its parked carries into its planes (bit-sliced add) and writes the 11 planes of its
+//   1. every lane folds its two parked carries into its planes (bit-sliced add) and writes the 11 planes of its
 //      slot to stage[slot][plane][l]
 //   2. barrier; lanes 0..G-1 of wave 0 add the staged numbers of all slots into acc[plane][l] (24 planes,
 //      read-modify-write in LDS so that this cold code needs almost no registers); barrier
@@ -182,17 +161,19 @@ __device__ __attribute__((noinline)) void counter_to_lds(const Planes *cp, u32 q
     {
         mine[0] = cp->P[0];
         mine[G] = cp->P[1];
-        u32 carry = 0;
+        const u32 q2v = (quadcnt & 1u) ? cp->Q2 : 0u;
+        const u32 q3v = (quadcnt & 2u) ? cp->Q3 : 0u;
+        u32 s2, s3, cy;
+        fa(cp->P[2], q2v, 0u, s2, cy);
+        mine[2 * G] = s2;
+        fa(cp->P[3], q3v, cy, s3, cy);
+        mine[3 * G] = s3;
 #pragma unroll 1
-        for (u32 k = 2; k < SP_NP; k++) {
-            const u32 qv = ((quadcnt >> (k - 2)) & 1u) ? cp->Q[k] : 0u;
-            u32 s, co;
-            fa(cp->P[k], qv, carry, s, co);
-            mine[k * G] = s;
-            carry = co;
+        for (u32 k = 4; k < SP_NP; k++) {
+            const u32 p = cp->P[k];
+            mine[k * G] = p ^ cy;   // count < 2048: no carry out of plane 10
+            cy &= p;
         }
-        const u32 q10 = ((quadcnt >> 8) & 1u) ? cp->Q[10] : 0u;
-        mine[10 * G] = q10 ^ carry;   // count < 2048: no carry out of plane 10
     }
     __syncthreads();
     if (tid < G) {
@@ -373,13 +354,14 @@ __device__ __forceinline__ u32 emit_reserve(const uint4 w, u32 *cursor)
 // Forward-read records: {shift word for the R window, R window byte address (lane adds 4l),
 //                        M window byte address (lane subtracts 4l; the zero region if M[x] = 0), shift word for M}
 template <bool HAS_M>
-__device__ __forceinline__ void emit_forward(const uint4 w, u32 idx0, u32 round_lo, u32 *lds, int32_t c, u32 tid)
+__device__ __forceinline__ void emit_forward(const uint4 w, const uint4 mapped_bits, u32 idx0, u32 round_lo, u32 *lds,
+                                             int32_t c, u32 tid)
 {
     typedef SpLds<HAS_M> L;
     uint4 *list = reinterpret_cast<uint4 *>(lds + L::LF);
-    const u32 *sM = lds + L::M;
     u32 id = idx0 - round_lo;   // unsigned: entries before the round wrap to huge values
     const u32 ws[4] = {w.x, w.y, w.z, w.w};
+    const u32 ms[4] = {mapped_bits.x, mapped_bits.y, mapped_bits.z, mapped_bits.w};   // M at the same positions
 #pragma unroll
     for (u32 k = 0; k < 4; k++) {
         u32 ww = ws[k];
@@ -394,8 +376,7 @@ __device__ __forceinline__ void emit_forward(const uint4 w, u32 idx0, u32 round_
                 rec.z = (L::ZERO + 32u) * 4u;
                 rec.w = 0;
                 if (HAS_M) {
-                    const u32 fa_ = SP_HALO_M + pos;
-                    const u32 mapped = (sM[fa_ >> 5] >> (fa_ & 31)) & 1u;
+                    const u32 mapped = (ms[k] >> b) & 1u;
                     const u32 a0 = pos + (u32)c + SP_HALO_M - 31u;
                     rec.w = a0;
                     if (mapped) rec.z = (L::M + (a0 >> 5)) * 4u;
@@ -438,10 +419,15 @@ __device__ __forceinline__ void emit_reverse(const uint4 w, u32 idx0, u32 round_
     }
 }
 
-// pads a record list up to `npad` (< nround + 256) with records whose windows read the zero region
-__device__ __forceinline__ void emit_pad(uint4 *list, u32 nround, u32 npad, u32 addr_y, u32 addr_z, u32 tid)
+// Each slot owns records [slot * 4 nq, (slot + 1) * 4 nq); the ones at index >= n do not exist: the slot's own
+// lanes overwrite them with records whose windows read the zero region (same wave writes then reads: LDS keeps
+// a wave's accesses in order, so no barrier is needed).
+__device__ __forceinline__ void pad_own_records(uint4 *list, u32 slot, u32 lane_in_slot, u32 G, u32 nq, u32 n, u32 addr_y,
+                                                u32 addr_z)
 {
-    if (nround + tid < npad) list[nround + tid] = make_uint4(0u, addr_y, addr_z, 0u);
+    const u32 base = slot * 4 * nq;
+    for (u32 j = lane_in_slot; j < 4 * nq; j += G)
+        if (base + j >= n) list[base + j] = make_uint4(0u, addr_y, addr_z, 0u);
 }
 
 __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shift_word)
@@ -453,7 +439,7 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 // ---- the cross-correlation kernel ---------------------------------------------------------------------------
 
 #ifndef SP_WAVES
-#define SP_WAVES 2
+#define SP_WAVES 3
 #endif
 template <bool HAS_M, bool DO_NCC>
 __global__ void __launch_bounds__(256, SP_WAVES)
@@ -532,56 +518,65 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 
     TileRegs tr;
     tile_fetch_job<HAS_M>(tr, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
+    if (tid < 4) cursor[tid] = 0;   // [2 par + 0] = F records, [2 par + 1] = R records; parity alternates per tile
+    u32 par = 0;
+    const u32 G = 1u << lgG;
+    const u32 lane_in_slot = sg.l4 >> 2;
 
     for (u32 g = g0; g < g1; g++) {
-        __syncthreads();   // everyone is done with the previous tile's LDS
+        // Two barriers per tile.  B0: everyone is done with the previous tile's LDS.
+        __syncthreads();
         if (qF >= SP_QSOFT || qR >= SP_QSOFT) fold_all();
         if (q2 >= SP_L2LIMIT) convert(ji, false);
 
+        // phase A: consume the prefetched registers -- tile to LDS, set bits to records (needs no LDS input:
+        // the mappability flag of a forward read is a bit of this thread's own M quad)
         tile_store<HAS_M>(tr, lds, tid);
-        if (tid < 2) cursor[tid] = 0;
         if (!HAS_M) cntR_thread += __popc(tr.r.x) + __popc(tr.r.y) + __popc(tr.r.z) + __popc(tr.r.w);
-        const uint4 wf = tr.f, wr = tr.r;
-        __syncthreads();   // tile visible
+        const u32 iF = emit_reserve(tr.f, &cursor[2 * par]);
+        u32 iR = 0;
+        if (HAS_M) iR = emit_reserve(tr.r, &cursor[2 * par + 1]);
+#ifndef SP_ABL_NOEMIT
+        emit_forward<HAS_M>(tr.f, HAS_M ? tr.m : tr.f, iF, 0, lds, c, tid);
+        if (HAS_M) emit_reverse(tr.r, iR, 0, lds, c, tid);
+#endif
+        if (tid < 2) cursor[2 * (par ^ 1) + tid] = 0;   // next tile's cursors (last read before B0)
 
-        // fetch the next tile into registers now; it is consumed after the next loop-top barrier
+        // fetch the next tile into the (now free) registers; consumed after the next B0
         u32 jn = ji;
         if (g + 1 < g1) {
             if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
             tile_fetch_job<HAS_M>(tr, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
         }
-
-        // compact both driver vectors into records
-        const u32 iF = emit_reserve(wf, &cursor[0]);
-        u32 iR = 0;
-        if (HAS_M) iR = emit_reserve(wr, &cursor[1]);
-#ifndef SP_ABL_NOEMIT
-        emit_forward<HAS_M>(wf, iF, 0, lds, c, tid);
-        if (HAS_M) emit_reverse(wr, iR, 0, lds, c, tid);
-#endif
-        __syncthreads();   // cursors final, first round written
+        __syncthreads();   // B1: tile and records visible
 #ifdef SP_ABL_NOPROC
         const u32 nF = 0, nR = 0;
 #else
-        const u32 nF = cursor[0], nR = HAS_M ? cursor[1] : 0u;
+        const u32 nF = cursor[2 * par], nR = HAS_M ? cursor[2 * par + 1] : 0u;
 #endif
+        par ^= 1;
         totF += nF;
         totR += nR;
         const u32 nmax = nF > nR ? nF : nR;
 
         for (u32 round_lo = 0; round_lo < nmax; round_lo += SP_CAP) {
-            if (round_lo) {   // rare: a tile with more than SP_CAP set bits in one vector
+            if (round_lo) {   // rare: a tile with more than SP_CAP set bits in one vector -> re-read its words
                 __syncthreads();
-                emit_forward<HAS_M>(wf, iF, round_lo, lds, c, tid);
-                if (HAS_M) emit_reverse(wr, iR, round_lo, lds, c, tid);
+                TileRegs cur;
+                tile_fetch<HAS_M, true>(cur, jobs.j[ji].F, jobs.j[ji].R, jobs.j[ji].M,
+                                        (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
+                emit_forward<HAS_M>(cur.f, HAS_M ? cur.m : cur.f, iF, round_lo, lds, c, tid);
+                if (HAS_M) emit_reverse(cur.r, iR, round_lo, lds, c, tid);
+                __syncthreads();
             }
             const u32 nFr = nF > round_lo ? (nF - round_lo < SP_CAP ? nF - round_lo : SP_CAP) : 0u;
             const u32 nRr = nR > round_lo ? (nR - round_lo < SP_CAP ? nR - round_lo : SP_CAP) : 0u;
             const u32 nqF = (nFr + sg.quad_span - 1) / sg.quad_span;   // quads per slot
             const u32 nqR = (nRr + sg.quad_span - 1) / sg.quad_span;
-            emit_pad(reinterpret_cast<uint4 *>(lds + L::LF), nFr, nqF * sg.quad_span, zero_up, zero_down, tid);
-            if (HAS_M) emit_pad(reinterpret_cast<uint4 *>(lds + L::LR), nRr, nqR * sg.quad_span, zero_down, zero_down, tid);
-            __syncthreads();
+            pad_own_records(reinterpret_cast<uint4 *>(lds + L::LF), sg.slot, lane_in_slot, G, nqF, nFr, zero_up, zero_down);
+            if (HAS_M)
+                pad_own_records(reinterpret_cast<uint4 *>(lds + L::LR), sg.slot, lane_in_slot, G, nqR, nRr, zero_down,
+                                zero_down);
 
             // a register counter must never absorb more than SP_QLIMIT quads (only very dense tiles get here)
             if (qF + nqF > SP_QLIMIT || qR + nqR > SP_QLIMIT) fold_all();
@@ -837,12 +832,17 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
 
     AcRegs ar;
     ac_fetch_job(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
+    if (tid < 2) cursor[tid] = 0;   // record cursors, parity alternates per tile
+    u32 par = 0;
+    const u32 G = 1u << lgG;
+    const u32 lane_in_slot = sg.l4 >> 2;
 
     for (u32 g = g0; g < g1; g++) {
-        __syncthreads();
+        __syncthreads();   // B0: everyone is done with the previous tile's LDS
         if (qc >= SP_QSOFT) fold_all();
         if (q2 >= SP_L2LIMIT) convert(ji, false);
 
+        // phase A: edges from the prefetched registers -> LDS tiles and records
         uint4 U, D;
         edge_quad(ar.m, ar.below, U, D);
         reinterpret_cast<uint4 *>(lds + L::U)[tid] = U;
@@ -856,28 +856,31 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
             reinterpret_cast<uint4 *>(lds + L::U + SP_TBW)[tid] = Uh;
             reinterpret_cast<uint4 *>(lds + L::D + SP_TBW)[tid] = Dh;
         }
-        if (tid == 0) cursor[0] = 0;
-        __syncthreads();
+        const u32 i0 = emit_reserve(E, &cursor[par]);
+        emit_edges(E, D, i0, 0, lds, tid);
+        if (tid == 0) cursor[par ^ 1] = 0;
 
         u32 jn = ji;
         if (g + 1 < g1) {
             if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
             ac_fetch_job(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
         }
-
-        const u32 i0 = emit_reserve(E, &cursor[0]);
-        emit_edges(E, D, i0, 0, lds, tid);
-        __syncthreads();
-        const u32 n = cursor[0];
+        __syncthreads();   // B1: tiles and records visible
+        const u32 n = cursor[par];
+        par ^= 1;
         for (u32 round_lo = 0; round_lo < n; round_lo += SP_CAP) {
-            if (round_lo) {
+            if (round_lo) {   // rare: more than SP_CAP edges in one tile -> recompute its edge words
                 __syncthreads();
-                emit_edges(E, D, i0, round_lo, lds, tid);
+                AcRegs cur;
+                ac_fetch<true>(cur, jobs.j[ji].M, (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
+                uint4 U2, D2;
+                edge_quad(cur.m, cur.below, U2, D2);
+                emit_edges(make_uint4(U2.x | D2.x, U2.y | D2.y, U2.z | D2.z, U2.w | D2.w), D2, i0, round_lo, lds, tid);
+                __syncthreads();
             }
             const u32 nr = n - round_lo < SP_CAP ? n - round_lo : SP_CAP;
             const u32 nq = (nr + sg.quad_span - 1) / sg.quad_span;
-            emit_pad(reinterpret_cast<uint4 *>(lds + L::LST), nr, nq * sg.quad_span, zero_up, zero_up, tid);
-            __syncthreads();
+            pad_own_records(reinterpret_cast<uint4 *>(lds + L::LST), sg.slot, lane_in_slot, G, nq, nr, zero_up, zero_up);
             if (qc + nq > SP_QLIMIT) fold_all();
             const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LST) + sg.slot * 4 * nq;
             for (u32 q = 0; q < nq; q++) {
