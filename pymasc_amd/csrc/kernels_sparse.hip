@@ -767,7 +767,7 @@ __device__ __forceinline__ void emit_edges(const uint4 w, const uint4 fall, u32 
     }
 }
 
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, 4)
 k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab)
 {
     typedef AcLds L;
@@ -1079,7 +1079,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
     SpJobTable tab;
     memset(&tab, 0, sizeof tab);
     uint32_t total, tpw, nwg;
-    plan_batch(ctx, jobs, njobs, true, 3, &tab, &total, &tpw, &nwg);
+    plan_batch(ctx, jobs, njobs, true, 4, &tab, &total, &tpw, &nwg);
     int rc = pmx_ensure_slab(ctx, (size_t)(nwg + njobs) * AC_SEG_ROWS * 1024);
     if (rc) return rc;
     pmx_timed_launch tl;

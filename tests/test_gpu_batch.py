@@ -1,0 +1,97 @@
+"""GPU parity of the batched entry point (pmx_cc_batch_dev): several chromosomes in one pass of the kernels,
+job boundaries falling inside a workgroup's tile range, more jobs than one launch's job table holds."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as oracle
+from pymasc_amd import ffi
+from . import synth
+from .test_gpu_parity import check_block
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ffi.Context(0)
+    yield c
+    c.close()
+
+
+def run_batch(ctx, cases, S, L, with_m, flags=0):
+    dev = torch.device("cuda", 0)
+    tens, pF, pR, pM, pN, pO, outs = [], [], [], [], [], [], []
+    for nbits, F, R, M in cases:
+        tF = torch.from_numpy(F.view(np.int64)).to(dev)
+        tR = torch.from_numpy(R.view(np.int64)).to(dev)
+        tM = torch.from_numpy(M.view(np.int64)).to(dev) if with_m else None
+        tO = torch.full((ffi.PMX_NROWS, S + 1), -1, dtype=torch.int64, device=dev)   # garbage: must be overwritten
+        tens += [tF, tR, tM, tO]
+        pF.append(tF.data_ptr())
+        pR.append(tR.data_ptr())
+        if with_m:
+            pM.append(tM.data_ptr())
+        pN.append(nbits)
+        pO.append(tO.data_ptr())
+        outs.append(tO)
+    torch.cuda.synchronize()
+    ctx.cc_batch_dev(pF, pR, pM if with_m else None, pN, S, L, flags, pO)
+    ctx.sync()
+    return [o.cpu().numpy().view(np.uint64) for o in outs]
+
+
+@pytest.mark.parametrize("with_m", [True, False])
+def test_small_jobs_of_mixed_sizes(ctx, with_m):
+    S, L = 300, 36
+    lens = [700, 40000, 32768 * 3 + 5, 70000, 1500, 32768 - S - L - 100, 200000]
+    cases = [synth.make_case(100 + i, n, S, L, 0.01, 0.012, with_m) for i, n in enumerate(lens)]
+    outs = run_batch(ctx, cases, S, L, with_m)
+    for (nbits, F, R, M), out in zip(cases, outs):
+        check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, with_m)
+        assert int(out[ffi.PMX_ROW_SCALARS, 3]) == ffi.PMX_PATH_SPARSE
+        if not with_m:
+            assert not out[ffi.PMX_ROW_MSCC_FSUM:ffi.PMX_ROW_MLEN + 1].any()
+
+
+def test_job_boundaries_inside_workgroup_ranges(ctx):
+    # ~1500 tiles > resident workgroups, so every workgroup walks several tiles and some ranges span two jobs
+    S, L = 100, 36
+    lens = [20_000_000, 9_000_001, 20_500_000]
+    cases = [synth.make_case(200 + i, n, S, L, 0.004, 0.004, True, mean_on=2000, mean_off=500) for i, n in enumerate(lens)]
+    outs = run_batch(ctx, cases, S, L, True)
+    for (nbits, F, R, M), out in zip(cases, outs):
+        check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
+
+
+def test_more_jobs_than_one_job_table(ctx):
+    S, L = 64, 20
+    cases = [synth.make_case(300 + i, 3000 + 517 * i, S, L, 0.02, 0.02, True) for i in range(45)]
+    outs = run_batch(ctx, cases, S, L, True)
+    for (nbits, F, R, M), out in zip(cases, outs):
+        check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
+
+
+def test_dense_tiles_force_counter_spills(ctx):
+    # every bit set: thousands of records per tile -> multi-round lists and mid-tile counter folds
+    S, L = 200, 36
+    G = 150000
+    nbits = G + L + S + 100
+    nw = synth.nwords(nbits)
+    rng = np.random.default_rng(9)
+    F = synth.random_bits(rng, nbits, 0.9, 1, G + 1)
+    R = synth.random_bits(rng, nbits, 0.9, 1, G + L)
+    M = synth.random_bits(rng, nbits, 0.7, 1, G + 1)
+    out = run_batch(ctx, [(nbits, F, R, M)], S, L, True, ffi.PMX_FLAG_FORCE_SPARSE)[0]
+    check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
+
+
+def test_mixed_mappability_is_rejected(ctx):
+    S, L = 64, 20
+    a = synth.make_case(1, 5000, S, L)
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(x.view(np.int64)).to(dev) for x in (a[1], a[2], a[3])]
+    o = torch.zeros((ffi.PMX_NROWS, S + 1), dtype=torch.int64, device=dev)
+    with pytest.raises(ffi.PmxError):
+        ctx.cc_batch_dev([t[0].data_ptr()] * 2, [t[1].data_ptr()] * 2, [t[2].data_ptr(), 0], [a[0]] * 2, S, L, 0,
+                         [o.data_ptr()] * 2)
