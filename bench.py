@@ -176,6 +176,20 @@ def main():
     achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     kernel_ms_per_step = {ctx.kernel_name(k): round(ktimes[k][0] / args.steps, 4) for k in ktimes if ktimes[k][1]}
 
+    # HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
+    # rocprofv3 passes of this same command: tools_profile.sh -> profiles/r1_traffic.json); only valid for the
+    # default single-GPU workload it was collected on
+    traffic, traffic_src = None, None
+    try:
+        if world == 1 and args.chroms == 24 and args.density == 0.005 and S == 1000 and with_m:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            key = {ffi.PMX_KERNEL_CC_SPARSE: "k_cc_sparse", ffi.PMX_KERNEL_AUTOCORR: "k_autocorr_edges"}.get(dom)
+            if key:
+                traffic = prof["mode_both"][key]["hbm_bytes"]
+                traffic_src = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    except Exception:
+        traffic, traffic_src = None, None
+
     work_per_step = (S + 1) * total_bp
     value = work_per_step * args.steps / elapsed
 
@@ -211,7 +225,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "avg_launch_ms": avg_ms,
             "launches": dom_n,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,

@@ -270,7 +270,7 @@ const char *pmx_kernel_name(int kernel_id)
     switch (kernel_id) {
     case PMX_KERNEL_CC_DENSE: return "k_cc_dense";
     case PMX_KERNEL_CC_SPARSE: return "k_cc_sparse";
-    case PMX_KERNEL_AUTOCORR: return "k_cc_dense(autocorr)";
+    case PMX_KERNEL_AUTOCORR: return "k_autocorr_edges";
     default: return "?";
     }
 }

@@ -51,8 +51,10 @@ def exchange_results(local_rows: torch.Tensor, assignment: List[List[int]], njob
     if world == 1:
         gathered = local_rows.unsqueeze(0)
     else:
-        gathered = torch.empty((world,) + tuple(local_rows.shape), dtype=local_rows.dtype, device=local_rows.device)
-        dist.all_gather_into_tensor(gathered, local_rows.contiguous(), group=group)
+        flat = torch.empty((world * max_slots,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype,
+                           device=local_rows.device)
+        dist.all_gather_into_tensor(flat, local_rows.contiguous(), group=group)   # rank-major concatenation
+        gathered = flat.view((world,) + tuple(local_rows.shape))
         dist.all_reduce(totals, op=dist.ReduceOp.SUM, group=group)
     table = owner_table(assignment, njobs)
     idx_r = torch.tensor([t[0] for t in table], device=local_rows.device)
