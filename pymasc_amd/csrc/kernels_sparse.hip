@@ -437,6 +437,20 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 }
 
 // ---- the cross-correlation kernel ---------------------------------------------------------------------------
+#ifdef SP_STAMPS   // diagnostic build: where does a tile's time go (never defined in the shipped library)
+#define SP_NSTAMP 8
+#define SP_STAMP(i)                                                                                    \
+    {                                                                                                  \
+        unsigned long long t_;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        stamp_acc[i] += t_ - stamp_last;                                                               \
+        stamp_last = t_;                                                                               \
+    }
+#else
+#define SP_STAMP(i)
+#endif
 
 #ifndef SP_WAVES
 #define SP_WAVES 3
@@ -516,6 +530,11 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         __syncthreads();
     };
 
+#ifdef SP_STAMPS
+    unsigned long long stamp_acc[SP_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     TileRegs tr;
     tile_fetch_job<HAS_M>(tr, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
     if (tid < 4) cursor[tid] = 0;   // [2 par + 0] = F records, [2 par + 1] = R records; parity alternates per tile
@@ -525,13 +544,17 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 
     for (u32 g = g0; g < g1; g++) {
         // Two barriers per tile.  B0: everyone is done with the previous tile's LDS.
+        SP_STAMP(7)
         __syncthreads();
+        SP_STAMP(0)
         if (qF >= SP_QSOFT || qR >= SP_QSOFT) fold_all();
         if (q2 >= SP_L2LIMIT) convert(ji, false);
 
         // phase A: consume the prefetched registers -- tile to LDS, set bits to records (needs no LDS input:
         // the mappability flag of a forward read is a bit of this thread's own M quad)
+        SP_STAMP(1)
         tile_store<HAS_M>(tr, lds, tid);
+        SP_STAMP(2)
         if (!HAS_M) cntR_thread += __popc(tr.r.x) + __popc(tr.r.y) + __popc(tr.r.z) + __popc(tr.r.w);
         const u32 iF = emit_reserve(tr.f, &cursor[2 * par]);
         u32 iR = 0;
@@ -541,6 +564,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         if (HAS_M) emit_reverse(tr.r, iR, 0, lds, c, tid);
 #endif
         if (tid < 2) cursor[2 * (par ^ 1) + tid] = 0;   // next tile's cursors (last read before B0)
+        SP_STAMP(3)
 
         // fetch the next tile into the (now free) registers; consumed after the next B0
         u32 jn = ji;
@@ -548,7 +572,9 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
             tile_fetch_job<HAS_M>(tr, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
         }
+        SP_STAMP(4)
         __syncthreads();   // B1: tile and records visible
+        SP_STAMP(5)
 #ifdef SP_ABL_NOPROC
         const u32 nF = 0, nR = 0;
 #else
@@ -625,6 +651,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             }
         }
 
+        SP_STAMP(6)
         // leaving a job: registers -> LDS accumulators -> this workgroup's segment of that job
         if (jn != ji || g + 1 == g1) {
             __syncthreads();
@@ -633,6 +660,12 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             ji = jn;
         }
     }
+#ifdef SP_STAMPS
+    if ((tid & 63) == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(slab + (size_t)(gridDim.x + njobs) * SP_SEG_ROWS * 1024);
+        for (int i = 0; i < SP_NSTAMP; i++) dbg[((size_t)blockIdx.x * 4 + (tid >> 6)) * SP_NSTAMP + i] = stamp_acc[i];
+    }
+#endif
 }
 
 // out[job][row][i] = sum over the workgroups that touched the job of slab[(wg + job)][src_row][i]
@@ -1016,7 +1049,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     memset(&tab, 0, sizeof tab);
     uint32_t total, tpw, nwg;
     plan_batch(ctx, jobs, njobs, false, has_m ? SP_WAVES : 4, &tab, &total, &tpw, &nwg);
-    int rc = pmx_ensure_slab(ctx, (size_t)(nwg + njobs) * SP_SEG_ROWS * 1024);
+    int rc = pmx_ensure_slab(ctx, (size_t)(nwg + njobs) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 8 * 2 + 64);
     if (rc) return rc;
     const int32_t c = (int32_t)read_len - 1;
     const u32 lgG = lg_slot_lanes(max_shift);

@@ -277,6 +277,15 @@ const char *pmx_kernel_name(int kernel_id)
 
 // ---- device bit-vectors ---------------------------------------------------------------------------
 
+// diagnostics only (not in the public header): copies `bytes` of the slab starting at byte offset `off`
+int pmx_debug_read_slab(pmx_ctx *ctx, uint64_t off, void *dst, uint64_t bytes)
+{
+    REQUIRE(ctx && dst && ctx->d_slab, "pmx_debug_read_slab: bad argument");
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    PMX_HIP(hipMemcpy(dst, (const char *)ctx->d_slab + off, bytes, hipMemcpyDeviceToHost));
+    return PMX_OK;
+}
+
 int pmx_bits_alloc(pmx_ctx *ctx, uint64_t nbits, uint64_t **d_words)
 {
     REQUIRE(ctx && d_words, "pmx_bits_alloc: NULL argument");

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd $R
 for v in BASE SP_ABL_NOPROC SP_ABL_NOEMIT "SP_ABL_NOPROC -DSP_ABL_NOEMIT"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -D$v -o /tmp/libabl.so pymasc_amd/csrc/*.hip 2>/dev/null
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-atomic-optimizer-strategy=DPP -fPIC -shared -D$v -o /tmp/libabl.so pymasc_amd/csrc/*.hip 2>/dev/null
   tag=$(echo "$v" | tr -c 'A-Za-z0-9_' '_')
   (cd /tmp && PYMASC_AMD_LIB=/tmp/libabl.so rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/ic_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > /dev/null 2> $R/gpurun_out/ic_$tag.err)
   python3 - "$R/gpurun_out/ic_$tag" "$v" <<'PY'
