@@ -141,77 +141,83 @@ __device__ __forceinline__ void fa(u32 a, u32 b, u32 cin, u32 &s, u32 &cout)
 }
 
 // Register counter -> workgroup accumulator in LDS (all 256 threads call this together):
-//   1. every lane folds its two parked carries into its planes (bit-sliced add) and writes the 11 planes of its
-//      slot to stage[slot][plane][l]
-//   2. barrier; lanes 0..G-1 of wave 0 add the staged numbers of all slots into acc[plane][l] (24 planes,
-//      read-modify-write in LDS so that this cold code needs almost no registers); barrier
-// Runs once per ~40 tiles at typical densities, so it is deliberately NOT inlined and register-lean: the
-// kernel's register allocation (hence its occupancy) is set by the hot loop, not by this.  The caller passes a
-// copy of its planes (the copy lives in scratch, the hot-loop planes stay in registers).
-__device__ __attribute__((noinline)) void counter_to_lds(const Planes *cp, u32 quadcnt, u32 lgG, u32 tid, u32 *stage,
-                                                         u32 *acc)
+//   1. fold the two parked carries into the planes (bit-sliced add inside the lane)              -> 11 planes
+//   2. add the slots of a wave together with cross-lane bit-sliced adds (xor shuffles)            -> <= 15 planes
+//   3. lanes 0..G-1 of every wave stage their number in LDS, barrier
+//   4. lanes 0..G-1 of wave 0 add the 4 staged numbers into acc[plane][l] (24 planes held in registers), barrier
+// The counter is cleared.  Inlined at exactly ONE place per kernel (the loops below are built around that): its
+// temporaries (n[16], a[24]) are live where few other registers are, so it does not raise the kernel's allocation,
+// whereas a non-inlined callee's registers ADD to the caller's on this target.
+__device__ __forceinline__ void counter_to_lds(Planes &c, u32 quadcnt, u32 lgG, u32 tid, u32 *stage, u32 *acc)
 {
-#ifdef SP_ABL_NOFLUSH
-    return;
-#endif
-    const u32 G = 1u << lgG;
-    const u32 slot = tid >> lgG, l = tid & (G - 1);
-    const u32 nslots = 256u >> lgG;
-    u32 *mine = stage + (slot * SP_NQ) * G + l;   // stage[slot][k][l], k < 11
+    u32 n[SP_NS];
     {
-        mine[0] = cp->P[0];
-        mine[G] = cp->P[1];
-        const u32 q2v = (quadcnt & 1u) ? cp->Q2 : 0u;
-        const u32 q3v = (quadcnt & 2u) ? cp->Q3 : 0u;
-        u32 s2, s3, cy;
-        fa(cp->P[2], q2v, 0u, s2, cy);
-        mine[2 * G] = s2;
-        fa(cp->P[3], q3v, cy, s3, cy);
-        mine[3 * G] = s3;
-#pragma unroll 1
-        for (u32 k = 4; k < SP_NP; k++) {
-            const u32 p = cp->P[k];
-            mine[k * G] = p ^ cy;   // count < 2048: no carry out of plane 10
-            cy &= p;
+        n[0] = c.P[0];
+        n[1] = c.P[1];
+        const u32 q2v = (quadcnt & 1u) ? c.Q2 : 0u;
+        const u32 q3v = (quadcnt & 2u) ? c.Q3 : 0u;
+        u32 cy;
+        fa(c.P[2], q2v, 0u, n[2], cy);
+        fa(c.P[3], q3v, cy, n[3], cy);
+#pragma unroll
+        for (int k = 4; k < SP_NP; k++) {
+            n[k] = c.P[k] ^ cy;   // count < 2048: no carry out of plane 10
+            cy &= c.P[k];
         }
+#pragma unroll
+        for (int k = SP_NP; k < SP_NS; k++) n[k] = 0;
+    }
+    planes_zero(c);
+    for (u32 step = 1u << lgG; step < 64; step <<= 1) {   // lanes ^ G, ^ 2G, ...: the same shifts of other slots
+        u32 carry = 0;
+#pragma unroll
+        for (int k = 0; k < SP_NS; k++) {
+            const u32 o = __shfl_xor(n[k], step, 64);
+            u32 s_, co;
+            fa(n[k], o, carry, s_, co);
+            n[k] = s_;
+            carry = co;
+        }
+    }
+    const u32 lane = tid & 63, wave = tid >> 6;
+    const u32 G = 1u << lgG;
+    if (lane < G) {
+#pragma unroll
+        for (int k = 0; k < SP_NS; k++) stage[(wave * SP_NS + k) * 32 + lane] = n[k];
     }
     __syncthreads();
     if (tid < G) {
+        u32 a[SP_NL];
+#pragma unroll
+        for (int k = 0; k < SP_NL; k++) a[k] = acc[k * 32 + tid];
 #pragma unroll 1
-        for (u32 sl = 0; sl < nslots; sl++) {
-            const u32 *src = stage + (sl * SP_NQ) * G + tid;
+        for (u32 w = 0; w < 4; w++) {
             u32 carry = 0;
-#pragma unroll 1
-            for (u32 k = 0; k < SP_NL; k++) {
-                const u32 o = k < SP_NQ ? src[k * G] : 0u;
-                if (k >= SP_NQ && carry == 0) break;   // nothing left to propagate (lane-local early out)
-                const u32 a = acc[k * 32 + tid];
-                u32 s, co;
-                fa(a, o, carry, s, co);
-                acc[k * 32 + tid] = s;
+#pragma unroll
+            for (int k = 0; k < SP_NL; k++) {
+                const u32 o = k < SP_NS ? stage[(w * SP_NS + k) * 32 + tid] : 0u;
+                u32 s_, co;
+                fa(a[k], o, carry, s_, co);
+                a[k] = s_;
                 carry = co;
             }
         }
+#pragma unroll
+        for (int k = 0; k < SP_NL; k++) acc[k * 32 + tid] = a[k];
     }
     __syncthreads();
-}
-
-__device__ __forceinline__ void flush_counter(Planes &c, u32 quadcnt, u32 lgG, u32 tid, u32 *stage, u32 *acc)
-{
-    const Planes copy = c;
-    counter_to_lds(&copy, quadcnt, lgG, tid, stage, acc);
-    planes_zero(c);
 }
 
 // LDS accumulators (ncounters x 24 planes x 32 words) -> integers added into rows of a slab segment; cleared.
 // `seg_written`: the segment already holds an earlier partial conversion of this job (same thread owns d).
-__device__ __attribute__((noinline)) void acc_to_segment(u32 *acc, u32 ncounters, u32 *__restrict__ seg, bool seg_written,
-                                                         u32 tid)
+__device__ __forceinline__ void acc_to_segment(u32 *acc, u32 ncounters, u32 *__restrict__ seg, bool seg_written, u32 tid)
 {
     __syncthreads();
+#pragma unroll 1
     for (u32 q = 0; q < ncounters; q++) {
         const u32 *a = acc + q * SP_NL * 32;
         u32 *row = seg + q * 1024;
+#pragma unroll 1
         for (u32 d = tid; d < 1024; d += 256) {
             const u32 l = d >> 5, i = d & 31;
             u32 v = seg_written ? row[d] : 0u;
@@ -492,44 +498,6 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     u32 ji = 0;
     while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
 
-    // registers -> LDS accumulators (uniform call)
-    auto fold_all = [&]() {
-        if (DO_NCC) flush_counter(cN, qF, lgG, tid, stage, acc);
-        if (HAS_M) {
-            flush_counter(cF, qF, lgG, tid, stage, acc + 1 * SP_NL * 32);
-            flush_counter(cC, qF, lgG, tid, stage, acc + 2 * SP_NL * 32);
-            flush_counter(cR, qR, lgG, tid, stage, acc + 3 * SP_NL * 32);
-        }
-        q2 += (qF > qR ? qF : qR) * 4u * sg.total_slots;
-        qF = 0;
-        qR = 0;
-    };
-    // LDS accumulators -> integers in this workgroup's slab segment for job `j` (uniform call)
-    auto convert = [&](u32 j, bool final) {
-        u32 *seg = slab + (size_t)(blockIdx.x + j) * SP_SEG_ROWS * 1024;
-        acc_to_segment(acc, L::NCOUNTERS, seg, seg_written, tid);
-        q2 = 0;
-        seg_written = true;
-        if (final) {
-            if (!HAS_M) {   // popcount(R) was counted per thread
-                u32 v = cntR_thread;
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if ((tid & 63) == 0) cursor[4 + (tid >> 6)] = v;
-                __syncthreads();
-                totR = cursor[4] + cursor[5] + cursor[6] + cursor[7];
-                cntR_thread = 0;
-            }
-            if (tid == 0) {   // popcount(F), popcount(R): bit_array_num_bits_set of mscc.pyx:236-237
-                seg[4 * 1024 + 0] = totF;
-                seg[4 * 1024 + 1] = totR;
-            }
-            totF = 0;
-            totR = 0;
-            seg_written = false;
-        }
-        __syncthreads();
-    };
-
 #ifdef SP_STAMPS
     unsigned long long stamp_acc[SP_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last;
@@ -542,122 +510,175 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     const u32 G = 1u << lgG;
     const u32 lane_in_slot = sg.l4 >> 2;
 
-    for (u32 g = g0; g < g1; g++) {
-        // Two barriers per tile.  B0: everyone is done with the previous tile's LDS.
+    // The loop runs over (tile, round) pairs plus one final drain pass, so that the fold / convert code below is
+    // inlined exactly once (one round per tile unless a vector has more than SP_CAP set bits in the tile).
+    u32 g = g0, round_lo = 0, jn = ji;
+    u32 nF = 0, nR = 0, iF = 0, iR = 0, nmax = 0, pendR = 0;
+    bool leaving = false;   // the previous tile was the last of its job (for this workgroup): convert before going on
+    u32 leave_job = 0;
+    for (;;) {
+        const bool have_tile = g < g1;
         SP_STAMP(7)
-        __syncthreads();
+        __syncthreads();   // B0: everyone is done with the previous tile's (round's) LDS
         SP_STAMP(0)
-        if (qF >= SP_QSOFT || qR >= SP_QSOFT) fold_all();
-        if (q2 >= SP_L2LIMIT) convert(ji, false);
-
-        // phase A: consume the prefetched registers -- tile to LDS, set bits to records (needs no LDS input:
-        // the mappability flag of a forward read is a bit of this thread's own M quad)
-        SP_STAMP(1)
-        tile_store<HAS_M>(tr, lds, tid);
-        SP_STAMP(2)
-        if (!HAS_M) cntR_thread += __popc(tr.r.x) + __popc(tr.r.y) + __popc(tr.r.z) + __popc(tr.r.w);
-        const u32 iF = emit_reserve(tr.f, &cursor[2 * par]);
-        u32 iR = 0;
-        if (HAS_M) iR = emit_reserve(tr.r, &cursor[2 * par + 1]);
+        if (have_tile && round_lo == 0) {
+            // phase A: consume the prefetched registers -- tile to LDS, set bits to records (needs no LDS input:
+            // the mappability flag of a forward read is a bit of this thread's own M quad)
+            tile_store<HAS_M>(tr, lds, tid);
+            SP_STAMP(2)
+            if (!HAS_M) pendR = __popc(tr.r.x) + __popc(tr.r.y) + __popc(tr.r.z) + __popc(tr.r.w);
+            iF = emit_reserve(tr.f, &cursor[2 * par]);
+            if (HAS_M) iR = emit_reserve(tr.r, &cursor[2 * par + 1]);
 #ifndef SP_ABL_NOEMIT
-        emit_forward<HAS_M>(tr.f, HAS_M ? tr.m : tr.f, iF, 0, lds, c, tid);
-        if (HAS_M) emit_reverse(tr.r, iR, 0, lds, c, tid);
+            emit_forward<HAS_M>(tr.f, HAS_M ? tr.m : tr.f, iF, 0, lds, c, tid);
+            if (HAS_M) emit_reverse(tr.r, iR, 0, lds, c, tid);
 #endif
-        if (tid < 2) cursor[2 * (par ^ 1) + tid] = 0;   // next tile's cursors (last read before B0)
-        SP_STAMP(3)
-
-        // fetch the next tile into the (now free) registers; consumed after the next B0
-        u32 jn = ji;
-        if (g + 1 < g1) {
-            if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
-            tile_fetch_job<HAS_M>(tr, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
-        }
-        SP_STAMP(4)
-        __syncthreads();   // B1: tile and records visible
-        SP_STAMP(5)
+            if (tid < 2) cursor[2 * (par ^ 1) + tid] = 0;   // next tile's cursors (last read before B0)
+            SP_STAMP(3)
+            // fetch the next tile into the (now free) registers; consumed after the next tile's B0
+            jn = ji;
+            if (g + 1 < g1) {
+                if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
+                tile_fetch_job<HAS_M>(tr, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
+            }
+            SP_STAMP(4)
+            __syncthreads();   // B1: tile and records visible
+            SP_STAMP(5)
 #ifdef SP_ABL_NOPROC
-        const u32 nF = 0, nR = 0;
+            nF = 0;
+            nR = 0;
 #else
-        const u32 nF = cursor[2 * par], nR = HAS_M ? cursor[2 * par + 1] : 0u;
+            nF = cursor[2 * par];
+            nR = HAS_M ? cursor[2 * par + 1] : 0u;
 #endif
-        par ^= 1;
-        totF += nF;
-        totR += nR;
-        const u32 nmax = nF > nR ? nF : nR;
-
-        for (u32 round_lo = 0; round_lo < nmax; round_lo += SP_CAP) {
-            if (round_lo) {   // rare: a tile with more than SP_CAP set bits in one vector -> re-read its words
-                __syncthreads();
-                TileRegs cur;
-                tile_fetch<HAS_M, true>(cur, jobs.j[ji].F, jobs.j[ji].R, jobs.j[ji].M,
-                                        (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
-                emit_forward<HAS_M>(cur.f, HAS_M ? cur.m : cur.f, iF, round_lo, lds, c, tid);
-                if (HAS_M) emit_reverse(cur.r, iR, round_lo, lds, c, tid);
-                __syncthreads();
-            }
-            const u32 nFr = nF > round_lo ? (nF - round_lo < SP_CAP ? nF - round_lo : SP_CAP) : 0u;
-            const u32 nRr = nR > round_lo ? (nR - round_lo < SP_CAP ? nR - round_lo : SP_CAP) : 0u;
-            const u32 nqF = (nFr + sg.quad_span - 1) / sg.quad_span;   // quads per slot
-            const u32 nqR = (nRr + sg.quad_span - 1) / sg.quad_span;
-            pad_own_records(reinterpret_cast<uint4 *>(lds + L::LF), sg.slot, lane_in_slot, G, nqF, nFr, zero_up, zero_down);
-            if (HAS_M)
-                pad_own_records(reinterpret_cast<uint4 *>(lds + L::LR), sg.slot, lane_in_slot, G, nqR, nRr, zero_down,
-                                zero_down);
-
-            // a register counter must never absorb more than SP_QLIMIT quads (only very dense tiles get here)
-            if (qF + nqF > SP_QLIMIT || qR + nqR > SP_QLIMIT) fold_all();
-
-            // ---- forward reads drive: ncc, mscc.fsum, mscc.ccbins ----
-            {
-                const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LF) + sg.slot * 4 * nqF;
-                for (u32 q = 0; q < nqF; q++) {
-                    u32 wN[4], wF[4], wC[4];
-#pragma unroll
-                    for (u32 k = 0; k < 4; k++) {
-                        const uint4 rec = recs[q * 4 + k];
-                        const u32 rw = lds_window(lds, rec.y + sg.l4, rec.x);
-                        wN[k] = rw;
-                        if (HAS_M) {
-                            const u32 mw = __builtin_bitreverse32(lds_window(lds, rec.z - sg.l4, rec.w));
-                            wF[k] = mw;
-                            wC[k] = mw & rw;
-                        }
-                    }
-                    const u32 qc = __builtin_amdgcn_readfirstlane(qF + q);
-                    if (DO_NCC) add_quad(cN, wN[0], wN[1], wN[2], wN[3], qc);
-                    if (HAS_M) {
-                        add_quad(cF, wF[0], wF[1], wF[2], wF[3], qc);
-                        add_quad(cC, wC[0], wC[1], wC[2], wC[3], qc);
-                    }
-                }
-                qF += nqF;
-            }
-            // ---- reverse reads drive: mscc.rsum ----
-            if (HAS_M) {
-                const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LR) + sg.slot * 4 * nqR;
-                for (u32 q = 0; q < nqR; q++) {
-                    u32 wR[4];
-#pragma unroll
-                    for (u32 k = 0; k < 4; k++) {
-                        const uint4 rec = recs[q * 4 + k];
-                        const u32 w1 = lds_window(lds, rec.y - sg.l4, rec.x);
-                        const u32 w2 = lds_window(lds, rec.z - sg.l4, rec.w);
-                        wR[k] = __builtin_bitreverse32(w1 & w2);
-                    }
-                    const u32 qc = __builtin_amdgcn_readfirstlane(qR + q);
-                    add_quad(cR, wR[0], wR[1], wR[2], wR[3], qc);
-                }
-                qR += nqR;
-            }
-        }
-
-        SP_STAMP(6)
-        // leaving a job: registers -> LDS accumulators -> this workgroup's segment of that job
-        if (jn != ji || g + 1 == g1) {
+            par ^= 1;
+            nmax = nF > nR ? nF : nR;
+        } else if (have_tile) {
+            // rare: a tile with more than SP_CAP set bits in one vector -> re-read its words, emit the next round
+            TileRegs cur;
+            tile_fetch<HAS_M, true>(cur, jobs.j[ji].F, jobs.j[ji].R, jobs.j[ji].M,
+                                    (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
+            emit_forward<HAS_M>(cur.f, HAS_M ? cur.m : cur.f, iF, round_lo, lds, c, tid);
+            if (HAS_M) emit_reverse(cur.r, iR, round_lo, lds, c, tid);
             __syncthreads();
-            fold_all();
-            convert(ji, true);
+        }
+        u32 nFr = 0, nRr = 0;
+        if (have_tile) {
+            nFr = nF > round_lo ? (nF - round_lo < SP_CAP ? nF - round_lo : SP_CAP) : 0u;
+            nRr = nR > round_lo ? (nR - round_lo < SP_CAP ? nR - round_lo : SP_CAP) : 0u;
+        }
+        const u32 nqF = (nFr + sg.quad_span - 1) / sg.quad_span;   // quads per slot
+        const u32 nqR = (nRr + sg.quad_span - 1) / sg.quad_span;
+
+        // ---- the one fold / convert site ----
+        // registers -> LDS accumulators: when leaving a job, at a tile boundary once enough quads are pending,
+        // or (dense tiles only) before a round that would overflow a register counter
+        if (leaving || (round_lo == 0 && (qF >= SP_QSOFT || qR >= SP_QSOFT)) || qF + nqF > SP_QLIMIT ||
+            qR + nqR > SP_QLIMIT) {
+            if (DO_NCC) counter_to_lds(cN, qF, lgG, tid, stage, acc);
+            if (HAS_M) {
+                counter_to_lds(cF, qF, lgG, tid, stage, acc + 1 * SP_NL * 32);
+                counter_to_lds(cC, qF, lgG, tid, stage, acc + 2 * SP_NL * 32);
+                counter_to_lds(cR, qR, lgG, tid, stage, acc + 3 * SP_NL * 32);
+            }
+            q2 += (qF > qR ? qF : qR) * 4u * sg.total_slots;
+            qF = 0;
+            qR = 0;
+        }
+        // LDS accumulators -> integers in this workgroup's slab segment of the job (when leaving it, or before the
+        // 24-plane accumulators could overflow)
+        if (leaving || q2 >= SP_L2LIMIT) {
+            const u32 j = leaving ? leave_job : ji;
+            u32 *seg = slab + (size_t)(blockIdx.x + j) * SP_SEG_ROWS * 1024;
+            acc_to_segment(acc, L::NCOUNTERS, seg, seg_written, tid);
+            q2 = 0;
+            seg_written = true;
+            if (leaving) {
+                if (!HAS_M) {   // popcount(R) was counted per thread
+                    u32 v = cntR_thread;
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                    if ((tid & 63) == 0) cursor[4 + (tid >> 6)] = v;
+                    __syncthreads();
+                    totR = cursor[4] + cursor[5] + cursor[6] + cursor[7];
+                    cntR_thread = 0;
+                }
+                if (tid == 0) {   // popcount(F), popcount(R): bit_array_num_bits_set of mscc.pyx:236-237
+                    seg[4 * 1024 + 0] = totF;
+                    seg[4 * 1024 + 1] = totR;
+                }
+                totF = 0;
+                totR = 0;
+                seg_written = false;
+                leaving = false;
+            }
+            __syncthreads();
+        }
+        SP_STAMP(1)
+        if (!have_tile) break;
+
+        if (round_lo == 0) {
+            totF += nF;
+            totR += nR;
+            cntR_thread += pendR;
+        }
+        pad_own_records(reinterpret_cast<uint4 *>(lds + L::LF), sg.slot, lane_in_slot, G, nqF, nFr, zero_up, zero_down);
+        if (HAS_M)
+            pad_own_records(reinterpret_cast<uint4 *>(lds + L::LR), sg.slot, lane_in_slot, G, nqR, nRr, zero_down, zero_down);
+
+        // ---- forward reads drive: ncc, mscc.fsum, mscc.ccbins ----
+        {
+            const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LF) + sg.slot * 4 * nqF;
+            for (u32 q = 0; q < nqF; q++) {
+                u32 wN[4], wF[4], wC[4];
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    const uint4 rec = recs[q * 4 + k];
+                    const u32 rw = lds_window(lds, rec.y + sg.l4, rec.x);
+                    wN[k] = rw;
+                    if (HAS_M) {
+                        const u32 mw = __builtin_bitreverse32(lds_window(lds, rec.z - sg.l4, rec.w));
+                        wF[k] = mw;
+                        wC[k] = mw & rw;
+                    }
+                }
+                const u32 qc = __builtin_amdgcn_readfirstlane(qF + q);
+                if (DO_NCC) add_quad(cN, wN[0], wN[1], wN[2], wN[3], qc);
+                if (HAS_M) {
+                    add_quad(cF, wF[0], wF[1], wF[2], wF[3], qc);
+                    add_quad(cC, wC[0], wC[1], wC[2], wC[3], qc);
+                }
+            }
+            qF += nqF;
+        }
+        // ---- reverse reads drive: mscc.rsum ----
+        if (HAS_M) {
+            const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LR) + sg.slot * 4 * nqR;
+            for (u32 q = 0; q < nqR; q++) {
+                u32 wR[4];
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    const uint4 rec = recs[q * 4 + k];
+                    const u32 w1 = lds_window(lds, rec.y - sg.l4, rec.x);
+                    const u32 w2 = lds_window(lds, rec.z - sg.l4, rec.w);
+                    wR[k] = __builtin_bitreverse32(w1 & w2);
+                }
+                const u32 qc = __builtin_amdgcn_readfirstlane(qR + q);
+                add_quad(cR, wR[0], wR[1], wR[2], wR[3], qc);
+            }
+            qR += nqR;
+        }
+        SP_STAMP(6)
+
+        // next round of this tile, or next tile (and remember to convert when the job ends here)
+        round_lo += SP_CAP;
+        if (round_lo >= nmax) {
+            round_lo = 0;
+            if (jn != ji || g + 1 == g1) {
+                leaving = true;
+                leave_job = ji;
+            }
             ji = jn;
+            g++;
         }
     }
 #ifdef SP_STAMPS
@@ -830,39 +851,6 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     u32 ji = 0;
     while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
 
-    auto fold_all = [&]() {
-        flush_counter(cP, qc, lgG, tid, stage, acc);
-        flush_counter(cN, qc, lgG, tid, stage, acc + SP_NL * 32);
-        q2 += qc * 4u * sg.total_slots;
-        qc = 0;
-    };
-    auto convert = [&](u32 j, bool final) {
-        u32 *seg = slab + (size_t)(blockIdx.x + j) * AC_SEG_ROWS * 1024;
-        acc_to_segment(acc, 2, seg, seg_written, tid);
-        q2 = 0;
-        seg_written = true;
-        if (final) {
-            u32 vm = cntM, vu = cntU;
-            for (int off = 32; off > 0; off >>= 1) {
-                vm += __shfl_down(vm, off, 64);
-                vu += __shfl_down(vu, off, 64);
-            }
-            if ((tid & 63) == 0) {
-                cursor[4 + (tid >> 6)] = vm;
-                cursor[8 + (tid >> 6)] = vu;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                seg[2048 + 0] = cursor[4] + cursor[5] + cursor[6] + cursor[7];     // popcount(M) of my tiles
-                seg[2048 + 1] = cursor[8] + cursor[9] + cursor[10] + cursor[11];   // runs starting in my tiles
-            }
-            cntM = 0;
-            cntU = 0;
-            seg_written = false;
-        }
-        __syncthreads();
-    };
-
     AcRegs ar;
     ac_fetch_job(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
     if (tid < 2) cursor[tid] = 0;   // record cursors, parity alternates per tile
@@ -870,51 +858,95 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     const u32 G = 1u << lgG;
     const u32 lane_in_slot = sg.l4 >> 2;
 
-    for (u32 g = g0; g < g1; g++) {
-        __syncthreads();   // B0: everyone is done with the previous tile's LDS
-        if (qc >= SP_QSOFT) fold_all();
-        if (q2 >= SP_L2LIMIT) convert(ji, false);
-
-        // phase A: edges from the prefetched registers -> LDS tiles and records
-        uint4 U, D;
-        edge_quad(ar.m, ar.below, U, D);
-        reinterpret_cast<uint4 *>(lds + L::U)[tid] = U;
-        reinterpret_cast<uint4 *>(lds + L::D)[tid] = D;
-        const uint4 E = make_uint4(U.x | D.x, U.y | D.y, U.z | D.z, U.w | D.w);
-        cntM += __popc(ar.m.x) + __popc(ar.m.y) + __popc(ar.m.z) + __popc(ar.m.w);
-        cntU += __popc(U.x) + __popc(U.y) + __popc(U.z) + __popc(U.w);
-        if (tid < 9) {
-            uint4 Uh, Dh;
-            edge_quad(ar.h, ar.hbelow, Uh, Dh);
-            reinterpret_cast<uint4 *>(lds + L::U + SP_TBW)[tid] = Uh;
-            reinterpret_cast<uint4 *>(lds + L::D + SP_TBW)[tid] = Dh;
-        }
-        const u32 i0 = emit_reserve(E, &cursor[par]);
-        emit_edges(E, D, i0, 0, lds, tid);
-        if (tid == 0) cursor[par ^ 1] = 0;
-
-        u32 jn = ji;
-        if (g + 1 < g1) {
-            if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
-            ac_fetch_job(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
-        }
-        __syncthreads();   // B1: tiles and records visible
-        const u32 n = cursor[par];
-        par ^= 1;
-        for (u32 round_lo = 0; round_lo < n; round_lo += SP_CAP) {
-            if (round_lo) {   // rare: more than SP_CAP edges in one tile -> recompute its edge words
-                __syncthreads();
-                AcRegs cur;
-                ac_fetch<true>(cur, jobs.j[ji].M, (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
-                uint4 U2, D2;
-                edge_quad(cur.m, cur.below, U2, D2);
-                emit_edges(make_uint4(U2.x | D2.x, U2.y | D2.y, U2.z | D2.z, U2.w | D2.w), D2, i0, round_lo, lds, tid);
-                __syncthreads();
+    // (tile, round) pairs + one drain pass; the fold / convert code is inlined once (see k_cc_sparse)
+    u32 g = g0, round_lo = 0, jn = ji, n = 0, i0 = 0, pendM = 0, pendU = 0;
+    bool leaving = false;
+    u32 leave_job = 0;
+    for (;;) {
+        const bool have_tile = g < g1;
+        __syncthreads();   // B0: everyone is done with the previous tile's (round's) LDS
+        if (have_tile && round_lo == 0) {
+            // phase A: edges from the prefetched registers -> LDS tiles and records
+            uint4 U, D;
+            edge_quad(ar.m, ar.below, U, D);
+            reinterpret_cast<uint4 *>(lds + L::U)[tid] = U;
+            reinterpret_cast<uint4 *>(lds + L::D)[tid] = D;
+            const uint4 E = make_uint4(U.x | D.x, U.y | D.y, U.z | D.z, U.w | D.w);
+            pendM = __popc(ar.m.x) + __popc(ar.m.y) + __popc(ar.m.z) + __popc(ar.m.w);
+            pendU = __popc(U.x) + __popc(U.y) + __popc(U.z) + __popc(U.w);
+            if (tid < 9) {
+                uint4 Uh, Dh;
+                edge_quad(ar.h, ar.hbelow, Uh, Dh);
+                reinterpret_cast<uint4 *>(lds + L::U + SP_TBW)[tid] = Uh;
+                reinterpret_cast<uint4 *>(lds + L::D + SP_TBW)[tid] = Dh;
             }
-            const u32 nr = n - round_lo < SP_CAP ? n - round_lo : SP_CAP;
-            const u32 nq = (nr + sg.quad_span - 1) / sg.quad_span;
-            pad_own_records(reinterpret_cast<uint4 *>(lds + L::LST), sg.slot, lane_in_slot, G, nq, nr, zero_up, zero_up);
-            if (qc + nq > SP_QLIMIT) fold_all();
+            i0 = emit_reserve(E, &cursor[par]);
+            emit_edges(E, D, i0, 0, lds, tid);
+            if (tid == 0) cursor[par ^ 1] = 0;
+            jn = ji;
+            if (g + 1 < g1) {
+                if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
+                ac_fetch_job(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
+            }
+            __syncthreads();   // B1: tiles and records visible
+            n = cursor[par];
+            par ^= 1;
+        } else if (have_tile) {
+            // rare: more than SP_CAP edges in one tile -> recompute its edge words, emit the next round
+            AcRegs cur;
+            ac_fetch<true>(cur, jobs.j[ji].M, (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
+            uint4 U2, D2;
+            edge_quad(cur.m, cur.below, U2, D2);
+            emit_edges(make_uint4(U2.x | D2.x, U2.y | D2.y, U2.z | D2.z, U2.w | D2.w), D2, i0, round_lo, lds, tid);
+            __syncthreads();
+        }
+        u32 nr = 0;
+        if (have_tile) nr = n > round_lo ? (n - round_lo < SP_CAP ? n - round_lo : SP_CAP) : 0u;
+        const u32 nq = (nr + sg.quad_span - 1) / sg.quad_span;
+
+        // ---- the one fold / convert site ----
+        if (leaving || (round_lo == 0 && qc >= SP_QSOFT) || qc + nq > SP_QLIMIT) {
+            counter_to_lds(cP, qc, lgG, tid, stage, acc);
+            counter_to_lds(cN, qc, lgG, tid, stage, acc + SP_NL * 32);
+            q2 += qc * 4u * sg.total_slots;
+            qc = 0;
+        }
+        if (leaving || q2 >= SP_L2LIMIT) {
+            const u32 j = leaving ? leave_job : ji;
+            u32 *seg = slab + (size_t)(blockIdx.x + j) * AC_SEG_ROWS * 1024;
+            acc_to_segment(acc, 2, seg, seg_written, tid);
+            q2 = 0;
+            seg_written = true;
+            if (leaving) {
+                u32 vm = cntM, vu = cntU;
+                for (int off = 32; off > 0; off >>= 1) {
+                    vm += __shfl_down(vm, off, 64);
+                    vu += __shfl_down(vu, off, 64);
+                }
+                if ((tid & 63) == 0) {
+                    cursor[4 + (tid >> 6)] = vm;
+                    cursor[8 + (tid >> 6)] = vu;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    seg[2048 + 0] = cursor[4] + cursor[5] + cursor[6] + cursor[7];     // popcount(M) of my tiles
+                    seg[2048 + 1] = cursor[8] + cursor[9] + cursor[10] + cursor[11];   // runs starting in my tiles
+                }
+                cntM = 0;
+                cntU = 0;
+                seg_written = false;
+                leaving = false;
+            }
+            __syncthreads();
+        }
+        if (!have_tile) break;
+
+        if (round_lo == 0) {
+            cntM += pendM;
+            cntU += pendU;
+        }
+        pad_own_records(reinterpret_cast<uint4 *>(lds + L::LST), sg.slot, lane_in_slot, G, nq, nr, zero_up, zero_up);
+        {
             const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LST) + sg.slot * 4 * nq;
             for (u32 q = 0; q < nq; q++) {
                 u32 wp[4], wn[4];
@@ -931,11 +963,15 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
             qc += nq;
         }
 
-        if (jn != ji || g + 1 == g1) {
-            __syncthreads();
-            fold_all();
-            convert(ji, true);
+        round_lo += SP_CAP;
+        if (round_lo >= n) {
+            round_lo = 0;
+            if (jn != ji || g + 1 == g1) {
+                leaving = true;
+                leave_job = ji;
+            }
             ji = jn;
+            g++;
         }
     }
 }
