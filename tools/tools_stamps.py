@@ -2,7 +2,7 @@
 """GPU box diagnostic: builds the library with -DSP_STAMPS and prints where a tile's cycles go in k_cc_sparse."""
 import ctypes, os, subprocess, sys, glob
 import numpy as np
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = "/tmp/libstamps.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP", "-fPIC", "-shared", "-DSP_STAMPS",
