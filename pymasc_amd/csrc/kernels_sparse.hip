@@ -71,9 +71,10 @@ struct SpLds {
     static constexpr u32 M = R + SP_TBW + SP_RHI;
     static constexpr u32 E = M + (HAS_M ? SP_MW : 0);
     static constexpr u32 O = E + (HAS_M ? SP_MW / 2 : 0);
-    static constexpr u32 LF = O + (HAS_M ? SP_MW / 2 : 0);          // F records (4 dwords each)
-    static constexpr u32 LR = LF + 4 * SP_CAP;
-    static constexpr u32 ACC = LR + (HAS_M ? 4 * SP_CAP : 0);       // [counter][plane][32]
+    static constexpr u32 PLF = O + (HAS_M ? SP_MW / 2 : 0);         // positions of the set bits of F (+ flag)
+    static constexpr u32 PLR = PLF + SP_CAP;                        // positions of the set bits of R
+    static constexpr u32 REC = PLR + (HAS_M ? SP_CAP : 0);          // per-slot record staging (4 dwords each)
+    static constexpr u32 ACC = REC + 4 * SP_CAP;                    // [counter][plane][32]
     static constexpr u32 NCOUNTERS = HAS_M ? 4 : 1;
     static constexpr u32 STAGE = ACC + NCOUNTERS * SP_NL * 32;      // [wave][plane][32]
     static constexpr u32 MISC = STAGE + 256 * SP_NQ;
@@ -210,16 +211,19 @@ __device__ __forceinline__ void counter_to_lds(Planes &c, u32 quadcnt, u32 lgG, 
 
 // LDS accumulators (ncounters x 24 planes x 32 words) -> integers added into rows of a slab segment; cleared.
 // `seg_written`: the segment already holds an earlier partial conversion of this job (same thread owns d).
-__device__ __forceinline__ void acc_to_segment(u32 *acc, u32 ncounters, u32 *__restrict__ seg, bool seg_written, u32 tid)
+// `rev_mask`: counters kept in bit-reversed order inside each 32-shift word (bit i <-> shift 32 l + 31 - i).
+__device__ __forceinline__ void acc_to_segment(u32 *acc, u32 ncounters, u32 rev_mask, u32 *__restrict__ seg, bool seg_written,
+                                               u32 tid)
 {
     __syncthreads();
 #pragma unroll 1
     for (u32 q = 0; q < ncounters; q++) {
         const u32 *a = acc + q * SP_NL * 32;
         u32 *row = seg + q * 1024;
+        const u32 flip = ((rev_mask >> q) & 1u) ? 31u : 0u;
 #pragma unroll 1
         for (u32 d = tid; d < 1024; d += 256) {
-            const u32 l = d >> 5, i = d & 31;
+            const u32 l = d >> 5, i = (d & 31) ^ flip;
             u32 v = seg_written ? row[d] : 0u;
 #pragma unroll
             for (int k = 0; k < SP_NL; k++) v += ((a[k * 32 + l] >> i) & 1u) << k;
@@ -290,23 +294,23 @@ __device__ __forceinline__ void tile_fetch_job(TileRegs &tr, const SpJobDev &jb,
         tile_fetch<HAS_M, true>(tr, jb.F, jb.R, jb.M, (int64_t)local_tile * SP_TBW, jb.nbits, tid);
 }
 
-// 16 even bits of each of two dwords -> one dword (lo's bits in the low half)
-__device__ __forceinline__ u32 even16x2(u32 lo, u32 hi)
+// bit unshuffle: even bits of x to the low half, odd bits to the high half (4 swap steps, 2 bitop3 each)
+__device__ __forceinline__ u32 unshuffle32(u32 x)
 {
-    u32 a = lo & 0x55555555u, b = hi & 0x55555555u;
-    a = (a | (a >> 1)) & 0x33333333u;
-    b = (b | (b >> 1)) & 0x33333333u;
-    a = (a | (a >> 2)) & 0x0f0f0f0fu;
-    b = (b | (b >> 2)) & 0x0f0f0f0fu;
-    a = a | (a >> 4);   // bytes 0 and 2 now hold 8 packed bits each
-    b = b | (b >> 4);
-    return (a & 0xffu) | ((a >> 8) & 0xff00u) | ((b & 0xffu) << 16) | ((b << 8) & 0xff000000u);
+    u32 t;
+    t = (x ^ (x >> 1)) & 0x22222222u; x = x ^ t ^ (t << 1);
+    t = (x ^ (x >> 2)) & 0x0c0c0c0cu; x = x ^ t ^ (t << 2);
+    t = (x ^ (x >> 4)) & 0x00f000f0u; x = x ^ t ^ (t << 4);
+    t = (x ^ (x >> 8)) & 0x0000ff00u; x = x ^ t ^ (t << 8);
+    return x;
 }
 
+// even / odd decimated copies of four consecutive M dwords: sE[off/2 .. +1], sO[off/2 .. +1]
 __device__ __forceinline__ void decimate_quad(const uint4 m, u32 *sE, u32 *sO, u32 dword_off)
 {
-    const u32 e0 = even16x2(m.x, m.y), e1 = even16x2(m.z, m.w);
-    const u32 o0 = even16x2(m.x >> 1, m.y >> 1), o1 = even16x2(m.z >> 1, m.w >> 1);
+    const u32 x0 = unshuffle32(m.x), x1 = unshuffle32(m.y), x2 = unshuffle32(m.z), x3 = unshuffle32(m.w);
+    const u32 e0 = (x0 & 0xffffu) | (x1 << 16), e1 = (x2 & 0xffffu) | (x3 << 16);
+    const u32 o0 = (x0 >> 16) | (x1 & 0xffff0000u), o1 = (x2 >> 16) | (x3 & 0xffff0000u);
     *reinterpret_cast<uint2 *>(sE + dword_off / 2) = make_uint2(e0, e1);
     *reinterpret_cast<uint2 *>(sO + dword_off / 2) = make_uint2(o0, o1);
 }
@@ -357,83 +361,74 @@ __device__ __forceinline__ u32 emit_reserve(const uint4 w, u32 *cursor)
     return n ? atomicAdd(cursor, n) : 0u;
 }
 
-// Forward-read records: {shift word for the R window, R window byte address (lane adds 4l),
-//                        M window byte address (lane subtracts 4l; the zero region if M[x] = 0), shift word for M}
-template <bool HAS_M>
-__device__ __forceinline__ void emit_forward(const uint4 w, const uint4 mapped_bits, u32 idx0, u32 round_lo, u32 *lds,
-                                             int32_t c, u32 tid)
+// Stage 1 of the compaction (phase A, divergent loops, so the body is kept minimal): position of every set bit,
+// with one flag bit (forward read mappable / falling edge), into an LDS list.
+__device__ __forceinline__ void emit_positions(const uint4 w, const uint4 flag_bits, u32 idx0, u32 round_lo, u32 *list, u32 tid)
 {
-    typedef SpLds<HAS_M> L;
-    uint4 *list = reinterpret_cast<uint4 *>(lds + L::LF);
     u32 id = idx0 - round_lo;   // unsigned: entries before the round wrap to huge values
     const u32 ws[4] = {w.x, w.y, w.z, w.w};
-    const u32 ms[4] = {mapped_bits.x, mapped_bits.y, mapped_bits.z, mapped_bits.w};   // M at the same positions
+    const u32 fs[4] = {flag_bits.x, flag_bits.y, flag_bits.z, flag_bits.w};
 #pragma unroll
     for (u32 k = 0; k < 4; k++) {
         u32 ww = ws[k];
         while (ww) {
             const u32 b = __builtin_ctz(ww);
             ww &= ww - 1;
-            if (id < SP_CAP) {
-                const u32 pos = 128u * tid + 32u * k + b;
-                uint4 rec;
-                rec.x = pos;
-                rec.y = (L::R + (pos >> 5)) * 4u;
-                rec.z = (L::ZERO + 32u) * 4u;
-                rec.w = 0;
-                if (HAS_M) {
-                    const u32 mapped = (ms[k] >> b) & 1u;
-                    const u32 a0 = pos + (u32)c + SP_HALO_M - 31u;
-                    rec.w = a0;
-                    if (mapped) rec.z = (L::M + (a0 >> 5)) * 4u;
-                }
-                list[id] = rec;
-            }
+            if (id < SP_CAP) list[id] = (128u * tid + 32u * k + b) | (((fs[k] >> b) & 1u) << 16);
             id++;
         }
     }
 }
 
-// Reverse-read records: {shift word for M[p-d], its byte address (lane subtracts 4l),
-//                        byte address of the decimated copy holding M[p+c-2d] (lane subtracts 4l), its shift word}
-__device__ __forceinline__ void emit_reverse(const uint4 w, u32 idx0, u32 round_lo, u32 *lds, int32_t c, u32 tid)
+// Stage 2 (after B1, no divergence): every slot turns ITS share of the positions into 16-byte records in its own
+// staging region (same wave writes then reads: LDS keeps a wave's accesses in order, so no barrier).  A record
+// holds the LDS byte addresses and shift words of the entry's windows; positions beyond the list end, and
+// unmappable forward reads, get the address of the zero region instead of a mask.
+//   forward: {shift word of the R window, R window address (lane adds 4l), M window address (lane subtracts 4l), M shift}
+template <bool HAS_M>
+__device__ __forceinline__ void build_forward_records(u32 *lds, uint4 *recs, u32 first, u32 lane_in_slot, u32 G, u32 nq,
+                                                      u32 n, int32_t c)
+{
+    typedef SpLds<HAS_M> L;
+    const u32 *pl = lds + L::PLF;
+    for (u32 j = lane_in_slot; j < 4 * nq; j += G) {
+        uint4 rec = make_uint4(0u, L::ZERO * 4u, (L::ZERO + 32u) * 4u, 0u);
+        if (first + j < n) {
+            const u32 e = pl[first + j];
+            const u32 pos = e & 0x7fffu;
+            rec.x = pos;
+            rec.y = (L::R + (pos >> 5)) * 4u;
+            if (HAS_M) {
+                const u32 a0 = pos + (u32)c + SP_HALO_M - 31u;
+                rec.w = a0;
+                if (e >> 16) rec.z = (L::M + (a0 >> 5)) * 4u;
+            }
+        }
+        recs[j] = rec;
+    }
+}
+
+//   reverse: {shift word of M[p-d], its address (lane subtracts 4l), address of the decimated copy holding M[p+c-2d]
+//             (lane subtracts 4l), its shift word}
+__device__ __forceinline__ void build_reverse_records(u32 *lds, uint4 *recs, u32 first, u32 lane_in_slot, u32 G, u32 nq, u32 n,
+                                                      int32_t c)
 {
     typedef SpLds<true> L;
-    uint4 *list = reinterpret_cast<uint4 *>(lds + L::LR);
-    u32 id = idx0 - round_lo;
-    const u32 ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (u32 k = 0; k < 4; k++) {
-        u32 ww = ws[k];
-        while (ww) {
-            const u32 b = __builtin_ctz(ww);
-            ww &= ww - 1;
-            if (id < SP_CAP) {
-                const u32 p = 128u * tid + 32u * k + b;
-                const u32 a1 = p + SP_HALO_M - 31u;
-                const u32 bb = p + SP_HALO_M + (u32)c;
-                const u32 a2 = (bb >> 1) - 31u;
-                uint4 rec;
-                rec.x = a1;
-                rec.y = (L::M + (a1 >> 5)) * 4u;
-                rec.z = (((bb & 1u) ? L::O : L::E) + (a2 >> 5)) * 4u;
-                rec.w = a2;
-                list[id] = rec;
-            }
-            id++;
+    const u32 *pl = lds + L::PLR;
+    for (u32 j = lane_in_slot; j < 4 * nq; j += G) {
+        uint4 rec = make_uint4(0u, (L::ZERO + 32u) * 4u, (L::ZERO + 32u) * 4u, 0u);
+        if (first + j < n) {
+            const u32 p = pl[first + j] & 0x7fffu;
+            const u32 a1 = p + SP_HALO_M - 31u;
+            const u32 bb = p + SP_HALO_M + (u32)c;
+            const u32 a2 = (bb >> 1) - 31u;
+            rec.x = a1;
+            rec.y = (L::M + (a1 >> 5)) * 4u;
+            rec.z = (((bb & 1u) ? L::O : L::E) + (a2 >> 5)) * 4u;
+            rec.w = a2;
         }
+        recs[j] = rec;
     }
-}
-
-// Each slot owns records [slot * 4 nq, (slot + 1) * 4 nq); the ones at index >= n do not exist: the slot's own
-// lanes overwrite them with records whose windows read the zero region (same wave writes then reads: LDS keeps
-// a wave's accesses in order, so no barrier is needed).
-__device__ __forceinline__ void pad_own_records(uint4 *list, u32 slot, u32 lane_in_slot, u32 G, u32 nq, u32 n, u32 addr_y,
-                                                u32 addr_z)
-{
-    const u32 base = slot * 4 * nq;
-    for (u32 j = lane_in_slot; j < 4 * nq; j += G)
-        if (base + j >= n) list[base + j] = make_uint4(0u, addr_y, addr_z, 0u);
 }
 
 __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shift_word)
@@ -474,7 +469,6 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 
     const u32 tid = threadIdx.x;
     const SlotGeom sg = slot_geom(lgG, tid);
-    const u32 zero_up = (L::ZERO) * 4u, zero_down = (L::ZERO + 32u) * 4u;
 
     const u32 g0 = blockIdx.x * tiles_per_wg;
     const u32 g1 = g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles;
@@ -530,8 +524,8 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             iF = emit_reserve(tr.f, &cursor[2 * par]);
             if (HAS_M) iR = emit_reserve(tr.r, &cursor[2 * par + 1]);
 #ifndef SP_ABL_NOEMIT
-            emit_forward<HAS_M>(tr.f, HAS_M ? tr.m : tr.f, iF, 0, lds, c, tid);
-            if (HAS_M) emit_reverse(tr.r, iR, 0, lds, c, tid);
+            emit_positions(tr.f, HAS_M ? tr.m : tr.f, iF, 0, lds + L::PLF, tid);
+            if (HAS_M) emit_positions(tr.r, tr.r, iR, 0, lds + L::PLR, tid);
 #endif
             if (tid < 2) cursor[2 * (par ^ 1) + tid] = 0;   // next tile's cursors (last read before B0)
             SP_STAMP(3)
@@ -558,8 +552,8 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             TileRegs cur;
             tile_fetch<HAS_M, true>(cur, jobs.j[ji].F, jobs.j[ji].R, jobs.j[ji].M,
                                     (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
-            emit_forward<HAS_M>(cur.f, HAS_M ? cur.m : cur.f, iF, round_lo, lds, c, tid);
-            if (HAS_M) emit_reverse(cur.r, iR, round_lo, lds, c, tid);
+            emit_positions(cur.f, HAS_M ? cur.m : cur.f, iF, round_lo, lds + L::PLF, tid);
+            if (HAS_M) emit_positions(cur.r, cur.r, iR, round_lo, lds + L::PLR, tid);
             __syncthreads();
         }
         u32 nFr = 0, nRr = 0;
@@ -590,7 +584,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         if (leaving || q2 >= SP_L2LIMIT) {
             const u32 j = leaving ? leave_job : ji;
             u32 *seg = slab + (size_t)(blockIdx.x + j) * SP_SEG_ROWS * 1024;
-            acc_to_segment(acc, L::NCOUNTERS, seg, seg_written, tid);
+            acc_to_segment(acc, L::NCOUNTERS, HAS_M ? 8u : 0u, seg, seg_written, tid);   // counter 3 (rsum) is bit-reversed
             q2 = 0;
             seg_written = true;
             if (leaving) {
@@ -621,13 +615,12 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             totR += nR;
             cntR_thread += pendR;
         }
-        pad_own_records(reinterpret_cast<uint4 *>(lds + L::LF), sg.slot, lane_in_slot, G, nqF, nFr, zero_up, zero_down);
-        if (HAS_M)
-            pad_own_records(reinterpret_cast<uint4 *>(lds + L::LR), sg.slot, lane_in_slot, G, nqR, nRr, zero_down, zero_down);
+        // this slot's record staging region (fixed size, shared by the forward and the reverse pass)
+        uint4 *const recs = reinterpret_cast<uint4 *>(lds + L::REC) + sg.slot * (SP_CAP / sg.total_slots);
 
         // ---- forward reads drive: ncc, mscc.fsum, mscc.ccbins ----
         {
-            const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LF) + sg.slot * 4 * nqF;
+            build_forward_records<HAS_M>(lds, recs, sg.slot * 4 * nqF, lane_in_slot, G, nqF, nFr, c);
             for (u32 q = 0; q < nqF; q++) {
                 u32 wN[4], wF[4], wC[4];
 #pragma unroll
@@ -652,7 +645,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         }
         // ---- reverse reads drive: mscc.rsum ----
         if (HAS_M) {
-            const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LR) + sg.slot * 4 * nqR;
+            build_reverse_records(lds, recs, sg.slot * 4 * nqR, lane_in_slot, G, nqR, nRr, c);
             for (u32 q = 0; q < nqR; q++) {
                 u32 wR[4];
 #pragma unroll
@@ -660,7 +653,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     const uint4 rec = recs[q * 4 + k];
                     const u32 w1 = lds_window(lds, rec.y - sg.l4, rec.x);
                     const u32 w2 = lds_window(lds, rec.z - sg.l4, rec.w);
-                    wR[k] = __builtin_bitreverse32(w1 & w2);
+                    wR[k] = w1 & w2;   // bit i <-> shift 32 l + 31 - i: this counter is kept bit-reversed (see convert)
                 }
                 const u32 qc = __builtin_amdgcn_readfirstlane(qR + q);
                 add_quad(cR, wR[0], wR[1], wR[2], wR[3], qc);
@@ -748,8 +741,9 @@ struct AcLds {
     static constexpr u32 ZERO = 0;
     static constexpr u32 U = 40;
     static constexpr u32 D = U + AC_W;
-    static constexpr u32 LST = D + AC_W;                 // records (4 dwords each)
-    static constexpr u32 ACC = LST + 4 * SP_CAP;         // [2][plane][32]
+    static constexpr u32 PL = D + AC_W;                  // positions of the edges (+ falling flag)
+    static constexpr u32 REC = PL + SP_CAP;              // per-slot record staging (4 dwords each)
+    static constexpr u32 ACC = REC + 4 * SP_CAP;         // [2][plane][32]
     static constexpr u32 STAGE = ACC + 2 * SP_NL * 32;
     static constexpr u32 MISC = STAGE + 256 * SP_NQ;
     static constexpr u32 TOTAL = MISC + 16;
@@ -797,27 +791,20 @@ __device__ __forceinline__ void edge_quad(const uint4 m, u32 below, uint4 &U, ui
 }
 
 // Edge records: {shift word, byte address of the SAME-sign edge vector window (lane adds 4l),
-//                byte address of the OPPOSITE-sign edge vector window, 0}
-__device__ __forceinline__ void emit_edges(const uint4 w, const uint4 fall, u32 idx0, u32 round_lo, u32 *lds, u32 tid)
+//                byte address of the OPPOSITE-sign edge vector window, 0}; built per slot from the position list
+__device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 first, u32 lane_in_slot, u32 G, u32 nq, u32 n)
 {
-    uint4 *list = reinterpret_cast<uint4 *>(lds + AcLds::LST);
-    u32 id = idx0 - round_lo;
-    const u32 ws[4] = {w.x, w.y, w.z, w.w};
-    const u32 fs[4] = {fall.x, fall.y, fall.z, fall.w};
-#pragma unroll
-    for (u32 k = 0; k < 4; k++) {
-        u32 ww = ws[k];
-        while (ww) {
-            const u32 b = __builtin_ctz(ww);
-            ww &= ww - 1;
-            if (id < SP_CAP) {
-                const u32 pos = 128u * tid + 32u * k + b;
-                const u32 is_fall = (fs[k] >> b) & 1u;
-                const u32 au = (AcLds::U + (pos >> 5)) * 4u, ad = (AcLds::D + (pos >> 5)) * 4u;
-                list[id] = make_uint4(pos, is_fall ? ad : au, is_fall ? au : ad, 0u);
-            }
-            id++;
+    const u32 *pl = lds + AcLds::PL;
+    for (u32 j = lane_in_slot; j < 4 * nq; j += G) {
+        uint4 rec = make_uint4(0u, AcLds::ZERO * 4u, AcLds::ZERO * 4u, 0u);
+        if (first + j < n) {
+            const u32 e = pl[first + j];
+            const u32 pos = e & 0x7fffu;
+            const u32 au = (AcLds::U + (pos >> 5)) * 4u, ad = (AcLds::D + (pos >> 5)) * 4u;
+            const bool fall = (e >> 16) != 0;
+            rec = make_uint4(pos, fall ? ad : au, fall ? au : ad, 0u);
         }
+        recs[j] = rec;
     }
 }
 
@@ -832,7 +819,6 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
 
     const u32 tid = threadIdx.x;
     const SlotGeom sg = slot_geom(lgG, tid);
-    const u32 zero_up = L::ZERO * 4u;
 
     const u32 g0 = blockIdx.x * tiles_per_wg;
     const u32 g1 = g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles;
@@ -881,7 +867,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
                 reinterpret_cast<uint4 *>(lds + L::D + SP_TBW)[tid] = Dh;
             }
             i0 = emit_reserve(E, &cursor[par]);
-            emit_edges(E, D, i0, 0, lds, tid);
+            emit_positions(E, D, i0, 0, lds + L::PL, tid);   // flag = falling edge
             if (tid == 0) cursor[par ^ 1] = 0;
             jn = ji;
             if (g + 1 < g1) {
@@ -897,7 +883,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
             ac_fetch<true>(cur, jobs.j[ji].M, (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
             uint4 U2, D2;
             edge_quad(cur.m, cur.below, U2, D2);
-            emit_edges(make_uint4(U2.x | D2.x, U2.y | D2.y, U2.z | D2.z, U2.w | D2.w), D2, i0, round_lo, lds, tid);
+            emit_positions(make_uint4(U2.x | D2.x, U2.y | D2.y, U2.z | D2.z, U2.w | D2.w), D2, i0, round_lo, lds + L::PL, tid);
             __syncthreads();
         }
         u32 nr = 0;
@@ -914,7 +900,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
         if (leaving || q2 >= SP_L2LIMIT) {
             const u32 j = leaving ? leave_job : ji;
             u32 *seg = slab + (size_t)(blockIdx.x + j) * AC_SEG_ROWS * 1024;
-            acc_to_segment(acc, 2, seg, seg_written, tid);
+            acc_to_segment(acc, 2, 0u, seg, seg_written, tid);
             q2 = 0;
             seg_written = true;
             if (leaving) {
@@ -945,9 +931,9 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
             cntM += pendM;
             cntU += pendU;
         }
-        pad_own_records(reinterpret_cast<uint4 *>(lds + L::LST), sg.slot, lane_in_slot, G, nq, nr, zero_up, zero_up);
         {
-            const uint4 *recs = reinterpret_cast<const uint4 *>(lds + L::LST) + sg.slot * 4 * nq;
+            uint4 *const recs = reinterpret_cast<uint4 *>(lds + L::REC) + sg.slot * (SP_CAP / sg.total_slots);
+            build_edge_records(lds, recs, sg.slot * 4 * nq, lane_in_slot, G, nq, nr);
             for (u32 q = 0; q < nq; q++) {
                 u32 wp[4], wn[4];
 #pragma unroll
