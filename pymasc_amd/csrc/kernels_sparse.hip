@@ -339,7 +339,7 @@ __device__ __forceinline__ void tile_store(const TileRegs &tr, u32 *lds, u32 tid
 // ---- set-bit records ---------------------------------------------------------------------------------------
 
 struct SlotGeom {
-    u32 total_slots, slot, l4, quad_span;
+    u32 total_slots, slot, l4, quad_span, lg_span, lg_region;   // quad_span = 4 * total_slots = 2^lg_span records
 };
 
 __device__ __forceinline__ SlotGeom slot_geom(u32 lgG, u32 tid)
@@ -351,6 +351,8 @@ __device__ __forceinline__ SlotGeom slot_geom(u32 lgG, u32 tid)
     g.slot = wave * spw + (lane >> lgG);
     g.l4 = 4u * (lane & ((1u << lgG) - 1));
     g.quad_span = g.total_slots * 4;
+    g.lg_span = 10 - lgG;                 // 4 * 4 * (64 >> lgG)
+    g.lg_region = lgG + 1;                // records per slot region: SP_CAP / total_slots = 512 / (256 >> lgG)
     return g;
 }
 
@@ -561,8 +563,8 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             nFr = nF > round_lo ? (nF - round_lo < SP_CAP ? nF - round_lo : SP_CAP) : 0u;
             nRr = nR > round_lo ? (nR - round_lo < SP_CAP ? nR - round_lo : SP_CAP) : 0u;
         }
-        const u32 nqF = (nFr + sg.quad_span - 1) / sg.quad_span;   // quads per slot
-        const u32 nqR = (nRr + sg.quad_span - 1) / sg.quad_span;
+        const u32 nqF = (nFr + sg.quad_span - 1) >> sg.lg_span;   // quads per slot
+        const u32 nqR = (nRr + sg.quad_span - 1) >> sg.lg_span;
 
         // ---- the one fold / convert site ----
         // registers -> LDS accumulators: when leaving a job, at a tile boundary once enough quads are pending,
@@ -616,7 +618,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             cntR_thread += pendR;
         }
         // this slot's record staging region (fixed size, shared by the forward and the reverse pass)
-        uint4 *const recs = reinterpret_cast<uint4 *>(lds + L::REC) + sg.slot * (SP_CAP / sg.total_slots);
+        uint4 *const recs = reinterpret_cast<uint4 *>(lds + L::REC) + (sg.slot << sg.lg_region);
 
         // ---- forward reads drive: ncc, mscc.fsum, mscc.ccbins ----
         {
@@ -888,7 +890,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
         }
         u32 nr = 0;
         if (have_tile) nr = n > round_lo ? (n - round_lo < SP_CAP ? n - round_lo : SP_CAP) : 0u;
-        const u32 nq = (nr + sg.quad_span - 1) / sg.quad_span;
+        const u32 nq = (nr + sg.quad_span - 1) >> sg.lg_span;
 
         // ---- the one fold / convert site ----
         if (leaving || (round_lo == 0 && qc >= SP_QSOFT) || qc + nq > SP_QLIMIT) {
@@ -932,7 +934,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
             cntU += pendU;
         }
         {
-            uint4 *const recs = reinterpret_cast<uint4 *>(lds + L::REC) + sg.slot * (SP_CAP / sg.total_slots);
+            uint4 *const recs = reinterpret_cast<uint4 *>(lds + L::REC) + (sg.slot << sg.lg_region);
             build_edge_records(lds, recs, sg.slot * 4 * nq, lane_in_slot, G, nq, nr);
             for (u32 q = 0; q < nq; q++) {
                 u32 wp[4], wn[4];

@@ -38,6 +38,20 @@ def owner_table(assignment: List[List[int]], njobs: int) -> List[Tuple[int, int]
     return table
 
 
+_INDEX_CACHE: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _owner_index(assignment: List[List[int]], njobs: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rank, slot) index tensors of every job, built once per assignment (no per-step host->device copies)."""
+    key = (tuple(tuple(a) for a in assignment), njobs, str(device))
+    hit = _INDEX_CACHE.get(key)
+    if hit is None:
+        table = owner_table(assignment, njobs)
+        hit = (torch.tensor([t[0] for t in table], device=device), torch.tensor([t[1] for t in table], device=device))
+        _INDEX_CACHE[key] = hit
+    return hit
+
+
 def exchange_results(local_rows: torch.Tensor, assignment: List[List[int]], njobs: int,
                      group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """local_rows: int64 [max_slots, nrows, stride], this rank's jobs in slot order (unused slots zero).
@@ -56,8 +70,6 @@ def exchange_results(local_rows: torch.Tensor, assignment: List[List[int]], njob
         dist.all_gather_into_tensor(flat, local_rows.contiguous(), group=group)   # rank-major concatenation
         gathered = flat.view((world,) + tuple(local_rows.shape))
         dist.all_reduce(totals, op=dist.ReduceOp.SUM, group=group)
-    table = owner_table(assignment, njobs)
-    idx_r = torch.tensor([t[0] for t in table], device=local_rows.device)
-    idx_s = torch.tensor([t[1] for t in table], device=local_rows.device)
+    idx_r, idx_s = _owner_index(assignment, njobs, local_rows.device)
     rows = gathered[idx_r, idx_s]
     return rows, totals
