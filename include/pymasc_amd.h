@@ -50,7 +50,8 @@ extern "C" {
 #define PMX_FLAG_SKIP_NCC     1u  /* skip_ncc=True (mscc.pyx:235,313): row 0 left zero (popcounts still reported) */
 #define PMX_FLAG_FORCE_DENSE  2u  /* use the dense word-parallel kernels (one lane per shift)          */
 #define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven window kernels (error if unsupported) */
-/* default (neither): set-bit kernels when 3 <= max_shift <= 1023, dense kernels otherwise */
+/* default (neither): set-bit kernels (3 <= max_shift <= 65535, read_len <= 1024; shifts beyond 1023 are
+ * processed in chunks of 1024), dense kernels otherwise */
 
 #define PMX_PATH_DENSE  1
 #define PMX_PATH_SPARSE 2

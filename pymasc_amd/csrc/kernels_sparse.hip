@@ -29,6 +29,7 @@
 #include "pmx_common.h"
 
 #include <string.h>
+#include <vector>
 
 #define SP_TB 32768u                 // driver bits per tile
 #define SP_TBW 1024u                 // dwords per tile
@@ -50,13 +51,18 @@
 #define SP_MAXJOBS 32u               // jobs per launch (job table travels in the kernel arguments)
 #define SP_SEG_ROWS 5u               // slab segment rows of 1024 u32: ncc, fsum, ccbins(mscc), rsum, scalars
 
+// A job is one chromosome x one CHUNK of 1024 shifts.  Shifts d = d_off + d' (d' < 1024) are obtained by staging
+// the WINDOW tiles from dword-shifted positions of the same vectors (d_off is a multiple of 1024 bits = 32 dwords):
+// R windows from +off, M windows from -off, the decimated M copies from -2 off; drivers and flags stay unshifted.
 struct SpJobDev {
     const u32 *F, *R, *M;
     u64 nbits;
     u32 tile0, ntiles;     // position in the global tile sequence
-    u32 aligned16, wg_first, wg_last, pad;
+    u32 aligned16, wg_first, wg_last;
+    u32 flags;             // bit 0: this job writes the scalar row / zero rows of its result block (chunk 0)
+    u32 d_off, d_n;        // first shift and number of shifts of this chunk
     u64 *out;              // result block of the job
-    u64 *out2;             // autocorrelation: per-job scratch (P, N, scalars)
+    u64 *out2;             // autocorrelation: per-job scratch (P, N, scalars, A)
 };
 
 struct SpJobTable {
@@ -263,35 +269,60 @@ __device__ __forceinline__ uint4 ld_quad(const u32 *__restrict__ p, int64_t j, u
 struct TileRegs {
     uint4 f, r, m, h;   // main F / R / M quads of this thread + one halo quad (threads 0..34)
 };
+struct TileRegsX {      // shift chunks > 0 only: window tiles come from shifted positions
+    uint4 rw, mw, md;   // main quads of the R window tile, the M window tile, the M tile to decimate
+    uint4 hw, hd;       // halo quads of the window tiles / of the tile to decimate
+};
 
 // thread t: main dwords 4t..4t+3 of each vector; halo quads: t in [0,17) M below, [17,26) M above, [26,35) R above
-template <bool HAS_M, bool GUARD>
-__device__ __forceinline__ void tile_fetch(TileRegs &tr, const u32 *__restrict__ F, const u32 *__restrict__ R,
-                                           const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid)
+template <bool HAS_M, bool CH, bool GUARD>
+__device__ __forceinline__ void tile_fetch(TileRegs &tr, TileRegsX &tx, const u32 *__restrict__ F, const u32 *__restrict__ R,
+                                           const u32 *__restrict__ M, int64_t d0, int64_t off, uint64_t nbits, u32 tid)
 {
     const int64_t j = d0 + 4 * (int64_t)tid;
     tr.f = ld_quad<GUARD>(F, j, nbits);
     tr.r = ld_quad<GUARD>(R, j, nbits);
     if (HAS_M) tr.m = ld_quad<GUARD>(M, j, nbits);
     tr.h = make_uint4(0, 0, 0, 0);
-    if (HAS_M && tid < 17)
-        tr.h = ld_quad<GUARD>(M, d0 - (int64_t)SP_MLO + 4 * (int64_t)tid, nbits);
-    else if (HAS_M && tid < 26)
-        tr.h = ld_quad<GUARD>(M, d0 + SP_TBW + 4 * (int64_t)(tid - 17), nbits);
-    else if (tid >= 26 && tid < 35)
-        tr.h = ld_quad<GUARD>(R, d0 + SP_TBW + 4 * (int64_t)(tid - 26), nbits);
+    if (!CH) {
+        if (HAS_M && tid < 17)
+            tr.h = ld_quad<GUARD>(M, d0 - (int64_t)SP_MLO + 4 * (int64_t)tid, nbits);
+        else if (HAS_M && tid < 26)
+            tr.h = ld_quad<GUARD>(M, d0 + SP_TBW + 4 * (int64_t)(tid - 17), nbits);
+        else if (tid >= 26 && tid < 35)
+            tr.h = ld_quad<GUARD>(R, d0 + SP_TBW + 4 * (int64_t)(tid - 26), nbits);
+    } else {
+        tx.rw = ld_quad<GUARD>(R, j + off, nbits);
+        tx.hw = make_uint4(0, 0, 0, 0);
+        tx.hd = make_uint4(0, 0, 0, 0);
+        if (HAS_M) {
+            tx.mw = ld_quad<GUARD>(M, j - off, nbits);
+            tx.md = ld_quad<GUARD>(M, j - 2 * off, nbits);
+            if (tid < 17) {
+                tx.hw = ld_quad<GUARD>(M, d0 - off - (int64_t)SP_MLO + 4 * (int64_t)tid, nbits);
+                tx.hd = ld_quad<GUARD>(M, d0 - 2 * off - (int64_t)SP_MLO + 4 * (int64_t)tid, nbits);
+            } else if (tid < 26) {
+                tx.hw = ld_quad<GUARD>(M, d0 - off + SP_TBW + 4 * (int64_t)(tid - 17), nbits);
+                tx.hd = ld_quad<GUARD>(M, d0 - 2 * off + SP_TBW + 4 * (int64_t)(tid - 17), nbits);
+            }
+        }
+        if (tid >= 26 && tid < 35) tx.hw = ld_quad<GUARD>(R, d0 + off + SP_TBW + 4 * (int64_t)(tid - 26), nbits);
+    }
 }
 
-template <bool HAS_M>
-__device__ __forceinline__ void tile_fetch_job(TileRegs &tr, const SpJobDev &jb, u32 local_tile, u32 tid)
+template <bool HAS_M, bool CH>
+__device__ __forceinline__ void tile_fetch_job(TileRegs &tr, TileRegsX &tx, const SpJobDev &jb, u32 local_tile, u32 tid)
 {
     // edge tiles (or unaligned vectors) take the guarded loader
-    const uint64_t hi = (uint64_t)local_tile * SP_TBW + SP_TBW + SP_MHI;   // one past the highest dword touched
-    const bool interior = jb.aligned16 && local_tile > 0 && hi + 2 <= jb.nbits / 32;
+    const int64_t d0 = (int64_t)local_tile * SP_TBW;
+    const int64_t off = CH ? (int64_t)(jb.d_off / 32) : 0;
+    const int64_t lo = d0 - 2 * off - (int64_t)SP_MLO;                        // lowest dword touched
+    const uint64_t hi = (uint64_t)(d0 + off) + SP_TBW + SP_MHI;                // one past the highest
+    const bool interior = jb.aligned16 && lo >= 0 && hi + 2 <= jb.nbits / 32;
     if (interior)
-        tile_fetch<HAS_M, false>(tr, jb.F, jb.R, jb.M, (int64_t)local_tile * SP_TBW, jb.nbits, tid);
+        tile_fetch<HAS_M, CH, false>(tr, tx, jb.F, jb.R, jb.M, d0, off, jb.nbits, tid);
     else
-        tile_fetch<HAS_M, true>(tr, jb.F, jb.R, jb.M, (int64_t)local_tile * SP_TBW, jb.nbits, tid);
+        tile_fetch<HAS_M, CH, true>(tr, tx, jb.F, jb.R, jb.M, d0, off, jb.nbits, tid);
 }
 
 // bit unshuffle: even bits of x to the low half, odd bits to the high half (4 swap steps, 2 bitop3 each)
@@ -315,25 +346,30 @@ __device__ __forceinline__ void decimate_quad(const uint4 m, u32 *sE, u32 *sO, u
     *reinterpret_cast<uint2 *>(sO + dword_off / 2) = make_uint2(o0, o1);
 }
 
-template <bool HAS_M>
-__device__ __forceinline__ void tile_store(const TileRegs &tr, u32 *lds, u32 tid)
+template <bool HAS_M, bool CH>
+__device__ __forceinline__ void tile_store(const TileRegs &tr, const TileRegsX &tx, u32 *lds, u32 tid)
 {
     typedef SpLds<HAS_M> L;
-    reinterpret_cast<uint4 *>(lds + L::R)[tid] = tr.r;
+    const uint4 rq = CH ? tx.rw : tr.r;     // R window tile
+    const uint4 mq = CH ? tx.mw : tr.m;     // M window tile
+    const uint4 dq = CH ? tx.md : tr.m;     // M tile that is decimated
+    const uint4 hq = CH ? tx.hw : tr.h;     // halo of the window tiles
+    const uint4 hdq = CH ? tx.hd : tr.h;    // halo of the decimated tile
+    reinterpret_cast<uint4 *>(lds + L::R)[tid] = rq;
     if (HAS_M) {
-        reinterpret_cast<uint4 *>(lds + L::M + SP_MLO)[tid] = tr.m;
+        reinterpret_cast<uint4 *>(lds + L::M + SP_MLO)[tid] = mq;
 #ifndef SP_ABL_NODEC
-        decimate_quad(tr.m, lds + L::E, lds + L::O, SP_MLO + 4 * tid);
+        decimate_quad(dq, lds + L::E, lds + L::O, SP_MLO + 4 * tid);
 #endif
         if (tid < 17) {
-            reinterpret_cast<uint4 *>(lds + L::M)[tid] = tr.h;
-            decimate_quad(tr.h, lds + L::E, lds + L::O, 4 * tid);
+            reinterpret_cast<uint4 *>(lds + L::M)[tid] = hq;
+            decimate_quad(hdq, lds + L::E, lds + L::O, 4 * tid);
         } else if (tid < 26) {
-            reinterpret_cast<uint4 *>(lds + L::M + SP_MLO + SP_TBW)[tid - 17] = tr.h;
-            decimate_quad(tr.h, lds + L::E, lds + L::O, SP_MLO + SP_TBW + 4 * (tid - 17));
+            reinterpret_cast<uint4 *>(lds + L::M + SP_MLO + SP_TBW)[tid - 17] = hq;
+            decimate_quad(hdq, lds + L::E, lds + L::O, SP_MLO + SP_TBW + 4 * (tid - 17));
         }
     }
-    if (tid >= 26 && tid < 35) reinterpret_cast<uint4 *>(lds + L::R + SP_TBW)[tid - 26] = tr.h;
+    if (tid >= 26 && tid < 35) reinterpret_cast<uint4 *>(lds + L::R + SP_TBW)[tid - 26] = hq;
 }
 
 // ---- set-bit records ---------------------------------------------------------------------------------------
@@ -458,8 +494,8 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 #ifndef SP_WAVES
 #define SP_WAVES 3
 #endif
-template <bool HAS_M, bool DO_NCC>
-__global__ void __launch_bounds__(256, SP_WAVES)
+template <bool HAS_M, bool DO_NCC, bool CH>
+__global__ void __launch_bounds__(256, CH ? 2 : SP_WAVES)
 k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
             u32 *__restrict__ slab)
 {
@@ -500,7 +536,8 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
     TileRegs tr;
-    tile_fetch_job<HAS_M>(tr, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
+    TileRegsX tx;
+    tile_fetch_job<HAS_M, CH>(tr, tx, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
     if (tid < 4) cursor[tid] = 0;   // [2 par + 0] = F records, [2 par + 1] = R records; parity alternates per tile
     u32 par = 0;
     const u32 G = 1u << lgG;
@@ -520,7 +557,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         if (have_tile && round_lo == 0) {
             // phase A: consume the prefetched registers -- tile to LDS, set bits to records (needs no LDS input:
             // the mappability flag of a forward read is a bit of this thread's own M quad)
-            tile_store<HAS_M>(tr, lds, tid);
+            tile_store<HAS_M, CH>(tr, tx, lds, tid);
             SP_STAMP(2)
             if (!HAS_M) pendR = __popc(tr.r.x) + __popc(tr.r.y) + __popc(tr.r.z) + __popc(tr.r.w);
             iF = emit_reserve(tr.f, &cursor[2 * par]);
@@ -535,7 +572,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             jn = ji;
             if (g + 1 < g1) {
                 if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
-                tile_fetch_job<HAS_M>(tr, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
+                tile_fetch_job<HAS_M, CH>(tr, tx, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
             }
             SP_STAMP(4)
             __syncthreads();   // B1: tile and records visible
@@ -552,8 +589,9 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         } else if (have_tile) {
             // rare: a tile with more than SP_CAP set bits in one vector -> re-read its words, emit the next round
             TileRegs cur;
-            tile_fetch<HAS_M, true>(cur, jobs.j[ji].F, jobs.j[ji].R, jobs.j[ji].M,
-                                    (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
+            TileRegsX curx;
+            tile_fetch<HAS_M, false, true>(cur, curx, jobs.j[ji].F, jobs.j[ji].R, jobs.j[ji].M,
+                                           (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, 0, jobs.j[ji].nbits, tid);
             emit_positions(cur.f, HAS_M ? cur.m : cur.f, iF, round_lo, lds + L::PLF, tid);
             if (HAS_M) emit_positions(cur.r, cur.r, iR, round_lo, lds + L::PLR, tid);
             __syncthreads();
@@ -684,16 +722,15 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 #endif
 }
 
-// out[job][row][i] = sum over the workgroups that touched the job of slab[(wg + job)][src_row][i]
+// dst[job][row][d_off + i] = sum over the workgroups that touched the job of slab[(wg + job)][src_row][i], i < d_n
 struct ReduceSpec {
     u32 nrows;
     u32 src_row[5];
-    u32 dst_row[5];     // row of the result block (PMX_ROW_*), or 1024-u64 row of out2
-    u32 n[5];           // elements that are sums over slab segments
-    u32 nfill[5];       // elements written in total (>= n): the rest of the row is zero-filled
+    u32 dst_row[5];     // row of the result block (PMX_ROW_*); with use_out2: offset (u64 units) into the job's out2
+    u32 is_scalar[5];   // the scalar row: 2 sums, the rest of the row zero-filled, [3] = path marker; chunk 0 only
     u32 out_stride;
     u32 use_out2;       // autocorrelation: rows go to out2 (per-job scratch) instead of the result block
-    u32 nzero;          // rows of the result block this batch does not produce: written as zeros
+    u32 nzero;          // rows of the result block this batch does not produce: written as zeros (chunk 0 only)
     u32 zero_row[5];
 };
 
@@ -707,10 +744,15 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
     const u32 e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const u32 i = blockIdx.x * 32 + e;
     if (r >= rs.nrows) {   // a row this batch leaves empty
-        if (g == 0 && i < rs.out_stride) jb.out[(size_t)rs.zero_row[r - rs.nrows] * rs.out_stride + i] = 0;
+        if ((jb.flags & 1u) && g == 0) {
+            u64 *dst = jb.out + (size_t)rs.zero_row[r - rs.nrows] * rs.out_stride;
+            for (u32 k = i; k < rs.out_stride; k += gridDim.x * 32) dst[k] = 0;
+        }
         return;
     }
-    const u32 n = rs.n[r];
+    const bool scalar = rs.is_scalar[r] != 0;
+    if (scalar && !(jb.flags & 1u)) return;
+    const u32 n = scalar ? 2u : jb.d_n;
     u64 sum = 0;
     if (i < n) {
         const size_t stride = (size_t)seg_rows * 1024;
@@ -719,13 +761,18 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
     }
     part[g][e] = sum;
     __syncthreads();
-    if (g == 0 && i < rs.nfill[r]) {
-        u64 t = 0;
+    if (g != 0) return;
+    u64 t = 0;
 #pragma unroll
-        for (u32 k = 0; k < 8; k++) t += part[k][e];
-        u64 *dst = rs.use_out2 ? jb.out2 + (size_t)rs.dst_row[r] * 1024 : jb.out + (size_t)rs.dst_row[r] * rs.out_stride;
-        if (!rs.use_out2 && rs.dst_row[r] == PMX_ROW_SCALARS && i == 3) t = PMX_PATH_SPARSE;   // the path that ran
-        dst[i] = t;
+    for (u32 k = 0; k < 8; k++) t += part[k][e];
+    if (rs.use_out2) {
+        if (i < n) jb.out2[(size_t)rs.dst_row[r] + (scalar ? 0u : jb.d_off) + i] = t;
+    } else if (scalar) {
+        u64 *dst = jb.out + (size_t)rs.dst_row[r] * rs.out_stride;
+        for (u32 k = i; k < rs.out_stride; k += gridDim.x * 32)   // [0],[1] sums, [3] path, everything else zero
+            dst[k] = k < 2 ? t : (k == 3 ? (u64)PMX_PATH_SPARSE : 0ull);
+    } else if (i < n) {
+        jb.out[(size_t)rs.dst_row[r] * rs.out_stride + jb.d_off + i] = t;
     }
 }
 
@@ -753,34 +800,43 @@ struct AcLds {
 #define AC_SEG_ROWS 3u               // P, N, scalars
 
 struct AcRegs {
-    uint4 m, h;   // main quad + (threads 0..8) the quad above the tile
-    u32 below;    // dword just below this thread's main quad (for M[j-1])
+    uint4 m, h;    // driver quad (unshifted) + (threads 0..8) the quad above the WINDOW tile
+    u32 below;     // dword just below the driver quad (for M[j-1])
     u32 hbelow;
+    uint4 mw;      // lag chunks > 0 only: main quad of the window tile, staged from +off dwords
+    u32 wbelow;
 };
 
-template <bool GUARD>
-__device__ __forceinline__ void ac_fetch(AcRegs &ar, const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid)
+template <bool GUARD, bool CH>
+__device__ __forceinline__ void ac_fetch(AcRegs &ar, const u32 *__restrict__ M, int64_t d0, int64_t off, uint64_t nbits, u32 tid)
 {
     const int64_t j = d0 + 4 * (int64_t)tid;
     ar.m = ld_quad<GUARD>(M, j, nbits);
     ar.below = GUARD ? ld_dword_guarded(M, j - 1, nbits) : M[j - 1];
+    if (CH) {
+        ar.mw = ld_quad<GUARD>(M, j + off, nbits);
+        ar.wbelow = GUARD ? ld_dword_guarded(M, j + off - 1, nbits) : M[j + off - 1];
+    }
     ar.h = make_uint4(0, 0, 0, 0);
     ar.hbelow = 0;
     if (tid < 9) {
-        const int64_t jh = d0 + SP_TBW + 4 * (int64_t)tid;
+        const int64_t jh = d0 + off + SP_TBW + 4 * (int64_t)tid;
         ar.h = ld_quad<GUARD>(M, jh, nbits);
         ar.hbelow = GUARD ? ld_dword_guarded(M, jh - 1, nbits) : M[jh - 1];
     }
 }
 
+template <bool CH>
 __device__ __forceinline__ void ac_fetch_job(AcRegs &ar, const SpJobDev &jb, u32 local_tile, u32 tid)
 {
-    const uint64_t hi = (uint64_t)local_tile * SP_TBW + SP_TBW + SP_RHI;
+    const int64_t d0 = (int64_t)local_tile * SP_TBW;
+    const int64_t off = CH ? (int64_t)(jb.d_off / 32) : 0;
+    const uint64_t hi = (uint64_t)(d0 + off) + SP_TBW + SP_RHI;
     const bool interior = jb.aligned16 && local_tile > 0 && hi + 2 <= jb.nbits / 32;
     if (interior)
-        ac_fetch<false>(ar, jb.M, (int64_t)local_tile * SP_TBW, jb.nbits, tid);
+        ac_fetch<false, CH>(ar, jb.M, d0, off, jb.nbits, tid);
     else
-        ac_fetch<true>(ar, jb.M, (int64_t)local_tile * SP_TBW, jb.nbits, tid);
+        ac_fetch<true, CH>(ar, jb.M, d0, off, jb.nbits, tid);
 }
 
 // rising (U) and falling (D) edge words of a quad; `below` = the dword preceding m.x
@@ -810,6 +866,7 @@ __device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 fi
     }
 }
 
+template <bool CH>
 __global__ void __launch_bounds__(256, 4)
 k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab)
 {
@@ -840,7 +897,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
 
     AcRegs ar;
-    ac_fetch_job(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
+    ac_fetch_job<CH>(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
     if (tid < 2) cursor[tid] = 0;   // record cursors, parity alternates per tile
     u32 par = 0;
     const u32 G = 1u << lgG;
@@ -856,9 +913,16 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
         if (have_tile && round_lo == 0) {
             // phase A: edges from the prefetched registers -> LDS tiles and records
             uint4 U, D;
-            edge_quad(ar.m, ar.below, U, D);
-            reinterpret_cast<uint4 *>(lds + L::U)[tid] = U;
-            reinterpret_cast<uint4 *>(lds + L::D)[tid] = D;
+            edge_quad(ar.m, ar.below, U, D);   // the drivers: edges inside this tile
+            if (CH) {                          // the windows start d_off bits above
+                uint4 Uw, Dw;
+                edge_quad(ar.mw, ar.wbelow, Uw, Dw);
+                reinterpret_cast<uint4 *>(lds + L::U)[tid] = Uw;
+                reinterpret_cast<uint4 *>(lds + L::D)[tid] = Dw;
+            } else {
+                reinterpret_cast<uint4 *>(lds + L::U)[tid] = U;
+                reinterpret_cast<uint4 *>(lds + L::D)[tid] = D;
+            }
             const uint4 E = make_uint4(U.x | D.x, U.y | D.y, U.z | D.z, U.w | D.w);
             pendM = __popc(ar.m.x) + __popc(ar.m.y) + __popc(ar.m.z) + __popc(ar.m.w);
             pendU = __popc(U.x) + __popc(U.y) + __popc(U.z) + __popc(U.w);
@@ -874,7 +938,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
             jn = ji;
             if (g + 1 < g1) {
                 if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
-                ac_fetch_job(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
+                ac_fetch_job<CH>(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
             }
             __syncthreads();   // B1: tiles and records visible
             n = cursor[par];
@@ -882,7 +946,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
         } else if (have_tile) {
             // rare: more than SP_CAP edges in one tile -> recompute its edge words, emit the next round
             AcRegs cur;
-            ac_fetch<true>(cur, jobs.j[ji].M, (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, jobs.j[ji].nbits, tid);
+            ac_fetch<true, false>(cur, jobs.j[ji].M, (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, 0, jobs.j[ji].nbits, tid);
             uint4 U2, D2;
             edge_quad(cur.m, cur.below, U2, D2);
             emit_positions(make_uint4(U2.x | D2.x, U2.y | D2.y, U2.z | D2.z, U2.w | D2.w), D2, i0, round_lo, lds + L::PL, tid);
@@ -964,37 +1028,66 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     }
 }
 
-// A(k) recurrence + output, one block per job.  Per-job scratch out2: P[1024], N[1024], scalars.
+// A(k) from EE(k) = P(k) - N(k), one block per chromosome.  A(k+1) = 2 A(k) - A(k-1) - EE(k) is a double prefix sum:
+// with Delta(k) = A(k+1) - A(k):  Delta(0) = -#runs, Delta(k) = Delta(k-1) - EE(k);  A(k) = A(0) + sum_{i<k} Delta(i).
+// Per-job scratch out2 (u64): P[lagcap], N[lagcap], scalars[16], A[lagcap].  All arithmetic in signed 64-bit.
 // mode 0: out[k] = A(k), k = 0..max_lag.  mode 1: out is a result block: row MLEN[d] = A(|c - d|), d = 0..max_shift,
 // and scalar [2] = popcount(M).
-__global__ void __launch_bounds__(256)
-k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 mode, int32_t c, u32 max_shift, u32 out_stride)
+__device__ __forceinline__ long long block_exclusive_offset(long long local_sum, long long *part, u32 tid)
 {
-    __shared__ long long A[1025];
-    const SpJobDev &jb = jobs.j[blockIdx.x];
-    const u64 *P = jb.out2, *N = jb.out2 + 1024, *scal = jb.out2 + 2048;
-    if (threadIdx.x == 0) {
-        long long a_prev = (long long)scal[0];            // A(0) = popcount(M)
-        A[0] = a_prev;
-        if (max_lag >= 1) {
-            long long a = a_prev - (long long)scal[1];    // A(1) = A(0) - #runs
-            A[1] = a;
-            for (u32 k = 1; k < max_lag; k++) {
-                const long long ee = (long long)P[k] - (long long)N[k];
-                const long long nxt = 2 * a - a_prev - ee;
-                a_prev = a;
-                a = nxt;
-                A[k + 1] = a;
-            }
+    part[tid] = local_sum;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (u32 i = 0; i < 256; i++) {
+            const long long v = part[i];
+            part[i] = run;
+            run += v;
         }
-        if (mode == 1) jb.out[(size_t)PMX_ROW_SCALARS * out_stride + 2] = scal[0];
+    }
+    __syncthreads();
+    const long long off = part[tid];
+    __syncthreads();
+    return off;
+}
+
+__global__ void __launch_bounds__(256)
+k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 lagcap, u32 mode, int32_t c, u32 max_shift, u32 out_stride)
+{
+    __shared__ long long part[256];
+    const SpJobDev &jb = jobs.j[blockIdx.x];
+    if (!(jb.flags & 1u)) return;   // one finish per chromosome (its chunk-0 job)
+    const u64 *P = jb.out2, *N = jb.out2 + lagcap, *scal = jb.out2 + 2 * (size_t)lagcap;
+    long long *A = reinterpret_cast<long long *>(jb.out2 + 2 * (size_t)lagcap + 16);
+    const u32 tid = threadIdx.x;
+    const long long a0 = (long long)scal[0], runs = (long long)scal[1];
+    const u32 seg = (max_lag + 1 + 255) / 256;
+    const u32 k0 = tid * seg, k1 = (k0 + seg < max_lag + 1) ? k0 + seg : max_lag + 1;
+    // pass 1: Delta(k) = inclusive prefix of x(k), x(0) = -runs, x(k) = -(P[k] - N[k])
+    long long sum = 0;
+    for (u32 k = k0; k < k1; k++) sum += k == 0 ? -runs : (long long)N[k] - (long long)P[k];
+    long long run = block_exclusive_offset(sum, part, tid);
+    for (u32 k = k0; k < k1; k++) {
+        run += k == 0 ? -runs : (long long)N[k] - (long long)P[k];
+        A[k] = run;   // Delta(k)
+    }
+    __syncthreads();
+    // pass 2: A(k) = a0 + exclusive prefix of Delta (in place: each thread owns its segment)
+    sum = 0;
+    for (u32 k = k0; k < k1; k++) sum += A[k];
+    run = a0 + block_exclusive_offset(sum, part, tid);
+    for (u32 k = k0; k < k1; k++) {
+        const long long d = A[k];
+        A[k] = run;
+        run += d;
     }
     __syncthreads();
     if (mode == 0) {
-        for (u32 k = threadIdx.x; k <= max_lag; k += 256) jb.out[k] = (u64)A[k];
+        for (u32 k = tid; k <= max_lag; k += 256) jb.out[k] = (u64)A[k];
     } else {
+        if (tid == 0) jb.out[(size_t)PMX_ROW_SCALARS * out_stride + 2] = (u64)a0;
         u64 *dst = jb.out + (size_t)PMX_ROW_MLEN * out_stride;
-        for (u32 d = threadIdx.x; d <= max_shift; d += 256) {
+        for (u32 d = tid; d <= max_shift; d += 256) {
             const int32_t k = c - (int32_t)d;
             dst[d] = (u64)A[k < 0 ? -k : k];
         }
@@ -1003,9 +1096,9 @@ k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 mode, int32_t c, u32 m
 
 // ---- host side ----------------------------------------------------------------------------------------------
 
-static uint32_t lg_slot_lanes(uint32_t max_shift)
+static uint32_t lg_slot_lanes(uint32_t nshifts)   // nshifts = shifts handled per slot
 {
-    const u32 need = (max_shift + 1 + 31) / 32;
+    const u32 need = (nshifts + 31) / 32;
     u32 lg = 2;   // G >= 4 keeps the record padding granule (16 * 64 / G records) within one workgroup pass
     while ((1u << lg) < need) lg++;
     return lg;
@@ -1015,151 +1108,204 @@ static inline bool is_aligned16(const void *p) { return ((uintptr_t)p & 15u) == 
 
 int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len)
 {
-    return max_shift >= 3 && max_shift <= 1023 && read_len >= 1 && read_len <= 1024;
+    return max_shift >= 3 && max_shift <= 65535 && read_len >= 1 && read_len <= 1024;
 }
 
 uint32_t pmx_sparse_max_jobs(void) { return SP_MAXJOBS; }
 
-// Cuts the global tile sequence of a batch into per-workgroup ranges and fills the device job table.
-static void plan_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, bool autocorr, uint32_t wg_per_cu,
-                       SpJobTable *tab, uint32_t *total_tiles, uint32_t *tiles_per_wg, uint32_t *nwg)
+// one launch's worth of (chromosome, shift chunk) jobs
+struct VJob {
+    const pmx_job *job;
+    u32 d_off, d_n;
+};
+
+// Cuts the global tile sequence of a launch into per-workgroup ranges and fills the device job table.
+static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr, uint32_t wg_per_cu, SpJobTable *tab,
+                        uint32_t *total_tiles, uint32_t *tiles_per_wg, uint32_t *nwg)
 {
     uint32_t t = 0;
-    for (uint32_t i = 0; i < njobs; i++) {
+    for (uint32_t i = 0; i < n; i++) {
         SpJobDev &d = tab->j[i];
-        const uint64_t bits = jobs[i].nbits + (autocorr ? 1 : 0);   // edges live on [0, nbits]
+        const pmx_job &jb = *vj[i].job;
+        const uint64_t bits = jb.nbits + (autocorr ? 1 : 0);   // edges live on [0, nbits]
         uint64_t nt = (bits + SP_TB - 1) / SP_TB;
         if (nt < 1) nt = 1;
-        d.F = (const u32 *)jobs[i].d_F;
-        d.R = (const u32 *)jobs[i].d_R;
-        d.M = (const u32 *)jobs[i].d_M;
-        d.nbits = jobs[i].nbits;
+        d.F = (const u32 *)jb.d_F;
+        d.R = (const u32 *)jb.d_R;
+        d.M = (const u32 *)jb.d_M;
+        d.nbits = jb.nbits;
         d.tile0 = t;
         d.ntiles = (u32)nt;
-        d.aligned16 = autocorr ? is_aligned16(jobs[i].d_M)
-                               : (is_aligned16(jobs[i].d_F) && is_aligned16(jobs[i].d_R) &&
-                                  (!jobs[i].d_M || is_aligned16(jobs[i].d_M)));
-        d.out = (u64 *)jobs[i].d_out;
-        d.out2 = (u64 *)jobs[i].d_out2;
-        d.pad = 0;
+        d.aligned16 = autocorr ? is_aligned16(jb.d_M)
+                               : (is_aligned16(jb.d_F) && is_aligned16(jb.d_R) && (!jb.d_M || is_aligned16(jb.d_M)));
+        d.flags = vj[i].d_off == 0 ? 1u : 0u;
+        d.d_off = vj[i].d_off;
+        d.d_n = vj[i].d_n;
+        d.out = (u64 *)jb.d_out;
+        d.out2 = (u64 *)jb.d_out2;
         t += (u32)nt;
     }
     uint64_t want = (uint64_t)ctx->num_cus * wg_per_cu;
     if (want > t) want = t;
     if (want < 1) want = 1;
     const uint32_t tpw = (uint32_t)((t + want - 1) / want);
-    const uint32_t n = (t + tpw - 1) / tpw;
-    for (uint32_t i = 0; i < njobs; i++) {
+    const uint32_t nw = (t + tpw - 1) / tpw;
+    for (uint32_t i = 0; i < n; i++) {
         SpJobDev &d = tab->j[i];
         d.wg_first = d.tile0 / tpw;
         d.wg_last = (d.tile0 + d.ntiles - 1) / tpw;
     }
     *total_tiles = t;
     *tiles_per_wg = tpw;
-    *nwg = n;
+    *nwg = nw;
+}
+
+// (chromosome x chunk-of-1024-shifts) jobs of a batch, in launches of at most SP_MAXJOBS
+static void expand_chunks(const pmx_job *jobs, uint32_t njobs, uint32_t nshifts, std::vector<VJob> &out)
+{
+    for (uint32_t i = 0; i < njobs; i++)
+        for (uint32_t off = 0; off < nshifts; off += 1024) {
+            VJob v;
+            v.job = &jobs[i];
+            v.d_off = off;
+            v.d_n = nshifts - off < 1024 ? nshifts - off : 1024;
+            out.push_back(v);
+        }
 }
 
 int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
                                uint32_t read_len, bool do_ncc, uint32_t out_stride)
 {
     if (njobs == 0) return PMX_OK;
-    if (njobs > SP_MAXJOBS) {
-        pmx_set_error("pmx_launch_cc_sparse_batch: at most %u jobs per launch", SP_MAXJOBS);
-        return PMX_ERR_INVALID;
-    }
     const bool has_m = jobs[0].d_M != nullptr;
     if (!has_m && !do_ncc) return PMX_OK;
-    SpJobTable tab;
-    memset(&tab, 0, sizeof tab);
-    uint32_t total, tpw, nwg;
-    plan_batch(ctx, jobs, njobs, false, has_m ? SP_WAVES : 4, &tab, &total, &tpw, &nwg);
-    int rc = pmx_ensure_slab(ctx, (size_t)(nwg + njobs) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 8 * 2 + 64);
-    if (rc) return rc;
+    const bool chunked = max_shift > 1023;
+    std::vector<VJob> vjobs;
+    expand_chunks(jobs, njobs, max_shift + 1, vjobs);
     const int32_t c = (int32_t)read_len - 1;
-    const u32 lgG = lg_slot_lanes(max_shift);
-    pmx_timed_launch tl;
-    rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl);
-    if (rc) return rc;
-#define SP_LAUNCH(HM, NC)                                                                                       \
-    hipLaunchKernelGGL((k_cc_sparse<HM, NC>), dim3(nwg), dim3(256), 0, ctx->stream, tab, njobs, total, tpw, c, lgG, \
-                       ctx->d_slab)
-    if (has_m && do_ncc)
-        SP_LAUNCH(true, true);
-    else if (has_m)
-        SP_LAUNCH(true, false);
-    else
-        SP_LAUNCH(false, true);
-#undef SP_LAUNCH
-    PMX_CHECK_LAUNCH("k_cc_sparse");
-    rc = pmx_prof_end(ctx, &tl);
-    if (rc) return rc;
-    // sum the per-workgroup slab segments into the result blocks
+    const u32 lgG = chunked ? 5u : lg_slot_lanes(max_shift + 1);
+
     ReduceSpec rs;
     memset(&rs, 0, sizeof rs);
-    u32 nr = 0;
-    u32 nz = 0;
-    const u32 S1 = max_shift + 1;
-    if (do_ncc) { rs.src_row[nr] = 0; rs.dst_row[nr] = PMX_ROW_NCC_CCBINS; rs.n[nr] = S1; rs.nfill[nr] = S1; nr++; }
+    u32 nr = 0, nz = 0;
+    if (do_ncc) { rs.src_row[nr] = 0; rs.dst_row[nr] = PMX_ROW_NCC_CCBINS; nr++; }
     else rs.zero_row[nz++] = PMX_ROW_NCC_CCBINS;
     if (has_m) {
-        rs.src_row[nr] = 1; rs.dst_row[nr] = PMX_ROW_MSCC_FSUM; rs.n[nr] = S1; rs.nfill[nr] = S1; nr++;
-        rs.src_row[nr] = 2; rs.dst_row[nr] = PMX_ROW_MSCC_CCBINS; rs.n[nr] = S1; rs.nfill[nr] = S1; nr++;
-        rs.src_row[nr] = 3; rs.dst_row[nr] = PMX_ROW_MSCC_RSUM; rs.n[nr] = S1; rs.nfill[nr] = S1; nr++;
+        rs.src_row[nr] = 1; rs.dst_row[nr] = PMX_ROW_MSCC_FSUM; nr++;
+        rs.src_row[nr] = 2; rs.dst_row[nr] = PMX_ROW_MSCC_CCBINS; nr++;
+        rs.src_row[nr] = 3; rs.dst_row[nr] = PMX_ROW_MSCC_RSUM; nr++;
     } else {
         rs.zero_row[nz++] = PMX_ROW_MSCC_FSUM;
         rs.zero_row[nz++] = PMX_ROW_MSCC_CCBINS;
         rs.zero_row[nz++] = PMX_ROW_MSCC_RSUM;
         rs.zero_row[nz++] = PMX_ROW_MLEN;
     }
-    rs.src_row[nr] = 4; rs.dst_row[nr] = PMX_ROW_SCALARS; rs.n[nr] = 2; rs.nfill[nr] = S1; nr++;
+    rs.src_row[nr] = 4; rs.dst_row[nr] = PMX_ROW_SCALARS; rs.is_scalar[nr] = 1; nr++;
     rs.nrows = nr;
     rs.nzero = nz;
     rs.out_stride = out_stride;
     rs.use_out2 = 0;
-    hipLaunchKernelGGL(k_reduce_segments, dim3((max_shift + 32) / 32, nr + nz, njobs), dim3(256), 0, ctx->stream,
-                       (const u32 *)ctx->d_slab, tab, (u32)SP_SEG_ROWS, rs);
-    PMX_CHECK_LAUNCH("k_reduce_segments");
+
+    for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS) {
+        const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS ? vjobs.size() - lo : SP_MAXJOBS);
+        SpJobTable tab;
+        memset(&tab, 0, sizeof tab);
+        uint32_t total, tpw, nwg;
+        plan_launch(ctx, &vjobs[lo], n, false, chunked ? 2 : (has_m ? SP_WAVES : 4), &tab, &total, &tpw, &nwg);
+        int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 8 * 2 + 64);
+        if (rc) return rc;
+        pmx_timed_launch tl;
+        rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl);
+        if (rc) return rc;
+#define SP_LAUNCH(HM, NC, CK)                                                                                      \
+    hipLaunchKernelGGL((k_cc_sparse<HM, NC, CK>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, c, lgG, \
+                       ctx->d_slab)
+        if (chunked) {
+            if (has_m && do_ncc) SP_LAUNCH(true, true, true);
+            else if (has_m) SP_LAUNCH(true, false, true);
+            else SP_LAUNCH(false, true, true);
+        } else {
+            if (has_m && do_ncc) SP_LAUNCH(true, true, false);
+            else if (has_m) SP_LAUNCH(true, false, false);
+            else SP_LAUNCH(false, true, false);
+        }
+#undef SP_LAUNCH
+        PMX_CHECK_LAUNCH("k_cc_sparse");
+        rc = pmx_prof_end(ctx, &tl);
+        if (rc) return rc;
+        // sum the per-workgroup slab segments into the result blocks
+        hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab,
+                           (u32)SP_SEG_ROWS, rs);
+        PMX_CHECK_LAUNCH("k_reduce_segments");
+    }
     return PMX_OK;
 }
 
-// jobs[i].d_M / nbits: the vector; jobs[i].d_out2: >= 2064 u64 of scratch per job (P, N, scalars);
+size_t pmx_autocorr_scratch_words(uint32_t max_lag)
+{
+    const size_t lagcap = ((size_t)max_lag + 1 + 1023) / 1024 * 1024;
+    return 3 * lagcap + 16;
+}
+
+// jobs[i].d_M / nbits: the vector; jobs[i].d_out2: pmx_autocorr_scratch_words(max_lag) u64 of scratch per job;
 // mode 0: jobs[i].d_out[k] = A(k), k <= max_lag.  mode 1: jobs[i].d_out is a result block: row MLEN[d] = A(|L-1-d|),
 // scalar [2] = popcount(M).
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag, uint32_t mode,
                                     uint32_t read_len, uint32_t max_shift, uint32_t out_stride)
 {
     if (njobs == 0) return PMX_OK;
-    if (njobs > SP_MAXJOBS) {
-        pmx_set_error("pmx_launch_autocorr_edges_batch: at most %u jobs per launch", SP_MAXJOBS);
-        return PMX_ERR_INVALID;
-    }
-    SpJobTable tab;
-    memset(&tab, 0, sizeof tab);
-    uint32_t total, tpw, nwg;
-    plan_batch(ctx, jobs, njobs, true, 4, &tab, &total, &tpw, &nwg);
-    int rc = pmx_ensure_slab(ctx, (size_t)(nwg + njobs) * AC_SEG_ROWS * 1024);
-    if (rc) return rc;
-    pmx_timed_launch tl;
-    rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_autocorr_edges, dim3(nwg), dim3(256), 0, ctx->stream, tab, njobs, total, tpw,
-                       lg_slot_lanes(max_lag), ctx->d_slab);
-    PMX_CHECK_LAUNCH("k_autocorr_edges");
-    rc = pmx_prof_end(ctx, &tl);
-    if (rc) return rc;
+    const bool chunked = max_lag > 1023;
+    const u32 lagcap = (u32)(((size_t)max_lag + 1 + 1023) / 1024 * 1024);
+    std::vector<VJob> vjobs;
+    expand_chunks(jobs, njobs, max_lag + 1, vjobs);
+    const u32 lgG = chunked ? 5u : lg_slot_lanes(max_lag + 1);
+
     ReduceSpec rs;
     memset(&rs, 0, sizeof rs);
     rs.nrows = 3;
-    rs.src_row[0] = 0; rs.dst_row[0] = 0; rs.n[0] = max_lag + 1; rs.nfill[0] = max_lag + 1;
-    rs.src_row[1] = 1; rs.dst_row[1] = 1; rs.n[1] = max_lag + 1; rs.nfill[1] = max_lag + 1;
-    rs.src_row[2] = 2; rs.dst_row[2] = 2; rs.n[2] = 2; rs.nfill[2] = 2;
+    rs.src_row[0] = 0; rs.dst_row[0] = 0;            // P
+    rs.src_row[1] = 1; rs.dst_row[1] = lagcap;       // N
+    rs.src_row[2] = 2; rs.dst_row[2] = 2 * lagcap; rs.is_scalar[2] = 1;
     rs.use_out2 = 1;
     rs.out_stride = out_stride;
-    hipLaunchKernelGGL(k_reduce_segments, dim3((max_lag + 32) / 32, 3, njobs), dim3(256), 0, ctx->stream,
-                       (const u32 *)ctx->d_slab, tab, (u32)AC_SEG_ROWS, rs);
-    PMX_CHECK_LAUNCH("k_reduce_segments");
-    hipLaunchKernelGGL(k_autocorr_finish, dim3(njobs), dim3(256), 0, ctx->stream, tab, max_lag, mode,
-                       (int32_t)read_len - 1, max_shift, out_stride);
-    PMX_CHECK_LAUNCH("k_autocorr_finish");
+
+    for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS) {
+        const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS ? vjobs.size() - lo : SP_MAXJOBS);
+        SpJobTable tab;
+        memset(&tab, 0, sizeof tab);
+        uint32_t total, tpw, nwg;
+        plan_launch(ctx, &vjobs[lo], n, true, 4, &tab, &total, &tpw, &nwg);
+        int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
+        if (rc) return rc;
+        pmx_timed_launch tl;
+        rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
+        if (rc) return rc;
+        if (chunked)
+            hipLaunchKernelGGL(k_autocorr_edges<true>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,
+                               ctx->d_slab);
+        else
+            hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,
+                               ctx->d_slab);
+        PMX_CHECK_LAUNCH("k_autocorr_edges");
+        rc = pmx_prof_end(ctx, &tl);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_reduce_segments, dim3(32, 3, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab,
+                           (u32)AC_SEG_ROWS, rs);
+        PMX_CHECK_LAUNCH("k_reduce_segments");
+    }
+    // the recurrence needs every chunk of a chromosome: run it once all launches are queued (same stream)
+    for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS) {
+        const uint32_t n = njobs - lo < SP_MAXJOBS ? njobs - lo : SP_MAXJOBS;
+        SpJobTable tab;
+        memset(&tab, 0, sizeof tab);
+        for (uint32_t i = 0; i < n; i++) {
+            tab.j[i].flags = 1;
+            tab.j[i].out = (u64 *)jobs[lo + i].d_out;
+            tab.j[i].out2 = (u64 *)jobs[lo + i].d_out2;
+        }
+        hipLaunchKernelGGL(k_autocorr_finish, dim3(n), dim3(256), 0, ctx->stream, tab, max_lag, lagcap, mode,
+                           (int32_t)read_len - 1, max_shift, out_stride);
+        PMX_CHECK_LAUNCH("k_autocorr_finish");
+    }
     return PMX_OK;
 }

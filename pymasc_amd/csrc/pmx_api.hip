@@ -436,7 +436,7 @@ int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint
     REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
             "pmx_mappable_len_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
     if (!(flags & PMX_FLAG_FORCE_DENSE) && pmx_sparse_supported(max_shift > 3 ? max_shift : 3, 1)) {
-        rc = pmx_ensure_scratch(ctx, 4096);
+        rc = pmx_ensure_scratch(ctx, pmx_autocorr_scratch_words(max_shift));
         if (rc) return rc;
         pmx_job job = {nullptr, nullptr, d_M, nbits, d_out, (uint64_t *)ctx->d_scratch};
         return pmx_launch_autocorr_edges_batch(ctx, &job, 1, max_shift, 0, 1, max_shift, max_shift + 1);
@@ -502,9 +502,9 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
 
     // The set-bit kernels are correct for any input and faster than the dense ones unless the occupancy
     // vectors are pathologically dense, so they are the default wherever the geometry is supported.
-    const bool sparse_ok = pmx_sparse_supported(max_shift, read_len) != 0 && max_lag <= 1023;
+    const bool sparse_ok = pmx_sparse_supported(max_shift, read_len) != 0;
     if ((flags & PMX_FLAG_FORCE_SPARSE) && !sparse_ok) {
-        pmx_set_error("pmx_cc_batch_dev: PMX_FLAG_FORCE_SPARSE needs 3 <= max_shift <= 1023 and read_len <= 1024");
+        pmx_set_error("pmx_cc_batch_dev: PMX_FLAG_FORCE_SPARSE needs 3 <= max_shift <= 65535 and read_len <= 1024");
         return PMX_ERR_INVALID;
     }
     if (!sparse_ok || (flags & PMX_FLAG_FORCE_DENSE)) {
@@ -516,11 +516,12 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         return PMX_OK;
     }
     const uint32_t chunk = pmx_sparse_max_jobs();
+    const size_t ac_words = pmx_autocorr_scratch_words(max_lag);
     pmx_job jobs[64];
     for (uint32_t lo = 0; lo < njobs; lo += chunk) {
         const uint32_t n = njobs - lo < chunk ? njobs - lo : chunk;
         if (has_m) {
-            int rc = pmx_ensure_scratch(ctx, (size_t)n * 2064);
+            int rc = pmx_ensure_scratch(ctx, (size_t)n * ac_words);
             if (rc) return rc;
         }
         for (uint32_t i = 0; i < n; i++) {
@@ -529,7 +530,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             jobs[i].d_M = has_m ? d_M[lo + i] : nullptr;
             jobs[i].nbits = nbits[lo + i];
             jobs[i].d_out = d_out[lo + i];
-            jobs[i].d_out2 = has_m ? (uint64_t *)(ctx->d_scratch + (size_t)i * 2064) : nullptr;
+            jobs[i].d_out2 = has_m ? (uint64_t *)(ctx->d_scratch + (size_t)i * ac_words) : nullptr;
         }
         int rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride);
         if (rc) return rc;

@@ -82,7 +82,7 @@ struct pmx_job {
     const uint64_t *d_F, *d_R, *d_M;   // device bit-vectors (d_M null: no mappability; all jobs of a batch alike)
     uint64_t nbits;
     uint64_t *d_out;                   // result block [PMX_NROWS][out_stride] (or the lag row, autocorr mode 0)
-    uint64_t *d_out2;                  // autocorrelation only: >= 2064 u64 of per-job scratch
+    uint64_t *d_out2;                  // autocorrelation only: pmx_autocorr_scratch_words(max_lag) u64 of per-job scratch
 };
 int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len);
 uint32_t pmx_sparse_max_jobs(void);
@@ -95,6 +95,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag,
                                     uint32_t mode, uint32_t read_len, uint32_t max_shift, uint32_t out_stride);
 int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words);
+size_t pmx_autocorr_scratch_words(uint32_t max_lag);
 // out[k] += sum_j M[j] & M[j+k], k = 0..max_lag
 int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_out);
 // mlen_by_shift[d] = autocorr[|read_len - 1 - d|], d = 0..max_shift

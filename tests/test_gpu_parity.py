@@ -39,6 +39,10 @@ CASES = [
     (6, 40000, 1023, 20, 0.01, 0.02, False),   # NCC only
     (7, 900, 700, 36, 0.05, 0.05, True),       # shift range ~ chromosome length
     (8, 65536 - 36 - 300 - 100, 300, 36, 0.01, 0.01, True),  # nbits multiple of 64
+    (9, 120000, 2500, 100, 0.01, 0.01, True),   # max_shift > 1023: shift chunks (BASELINE config 5 shape)
+    (10, 90000, 5000, 100, 0.005, 0.02, True),  # -d 5000
+    (11, 70000, 1024, 36, 0.01, 0.01, False),   # first shift of the second chunk, NCC only
+    (12, 40000, 3000, 1024, 0.02, 0.01, True),  # longest supported read length
 ]
 
 
@@ -65,11 +69,12 @@ def test_skip_ncc(ctx):
     assert not out[ffi.PMX_ROW_NCC_CCBINS].any()
 
 
+@pytest.mark.parametrize("max_shift", [300, 1023, 1024, 4000])
 @pytest.mark.parametrize("flags", [ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE, 0])
-def test_mappable_len_readless(ctx, flags):
-    nbits, _, _, M = synth.make_case(12, 50000, 300, 36)
-    ref = oracle.mappable_len_readless(M, nbits, 300)
-    out = ctx.mappable_len(M, nbits, 300, flags)
+def test_mappable_len_readless(ctx, flags, max_shift):
+    nbits, _, _, M = synth.make_case(12, 50000, max_shift, 36)
+    ref = oracle.mappable_len_readless(M, nbits, max_shift)
+    out = ctx.mappable_len(M, nbits, max_shift, flags)
     np.testing.assert_array_equal(out.astype(np.int64), ref)
 
 
