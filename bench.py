@@ -91,15 +91,23 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    device = torch.device("cuda", local_rank)
+    # BENCH_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the
+    # exchange is staged through host memory); the driver's multi-GPU runs use the default: nccl = RCCL over xGMI.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     S, L = args.max_shift, args.read_len
     with_m = args.mode == "both"
     flags = {"auto": 0, "dense": ffi.PMX_FLAG_FORCE_DENSE, "sparse": ffi.PMX_FLAG_FORCE_SPARSE}[args.path]
-    ctx = ffi.Context(local_rank)
+    ctx = ffi.Context(dev_index)
 
     chroms = synth.HG38[:args.chroms]
     # batch = `world` samples x chromosomes; LPT over ranks (identical on every rank)
@@ -133,6 +141,8 @@ def main():
         # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev), then the exchange
         ctx.cc_batch_dev(pF, pR, pM, pN, S, L, flags, pO)
         ctx.sync()
+        if world > 1 and backend != "nccl":
+            return sharding.exchange_results(d_rows.cpu(), assignment, len(jobs))
         return sharding.exchange_results(d_rows, assignment, len(jobs))
 
     def fence():
@@ -153,7 +163,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
