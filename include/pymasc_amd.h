@@ -50,6 +50,9 @@ extern "C" {
 #define PMX_FLAG_SKIP_NCC     1u  /* skip_ncc=True (mscc.pyx:235,313): row 0 left zero (popcounts still reported) */
 #define PMX_FLAG_FORCE_DENSE  2u  /* use the dense word-parallel kernels (one lane per shift)          */
 #define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven window kernels (error if unsupported) */
+#define PMX_FLAG_SKIP_MLEN    8u  /* the caller holds mappable_len already (the *_mappability.json cache,
+                                   * handler/mappability.py:239-259): no autocorrelation pass; row 4 and
+                                   * scalars[2] are written as zeros */
 /* default (neither): set-bit kernels (3 <= max_shift <= 65535, read_len <= 1024; shifts beyond 1023 are
  * processed in chunks of 1024), dense kernels otherwise */
 

@@ -72,7 +72,8 @@ class CCHipCalculator:
 
     def __init__(self, max_shift: int, read_len: int, references: Sequence[str], lengths: Sequence[int],
                  bwfeeder: Any = None, skip_ncc: bool = False, logger_lock: Any = None, progress_bar: Any = None,
-                 device: int = 0, kernel_flags: int = 0, context: Optional[ffi.Context] = None):
+                 device: int = 0, kernel_flags: int = 0, context: Optional[ffi.Context] = None,
+                 chrom2mappable_len: Optional[Dict[str, Sequence[int]]] = None):
         self.max_shift = int(max_shift)
         self.read_len = int(read_len)
         self.references = list(references)
@@ -83,6 +84,9 @@ class CCHipCalculator:
         self._bwfeeder = bwfeeder
         self._progress = progress_bar
         self._kernel_flags = int(kernel_flags)
+        # lag tables known beforehand (the *_mappability.json cache, pymasc_amd/mappability.py): chromosomes
+        # found here skip the autocorrelation pass
+        self._known_mlen: Dict[str, Sequence[int]] = dict(chrom2mappable_len or {})
 
         self.ref2ncc_result: Dict[str, NCCResult] = {}
         self.ref2mscc_result: Dict[str, MSCCResult] = {}
@@ -259,6 +263,12 @@ class CCHipCalculator:
 
         self._logging_info("Calculate cross-correlation for {}...".format(chrom))
         flags = self._kernel_flags | (ffi.PMX_FLAG_SKIP_NCC if self.skip_ncc else 0)
+        c = L - 1
+        known = self._known_mlen.get(chrom) if d_m is not None else None
+        if known is not None and len(known) <= max(c, S - c):      # cache too short for this run: recompute
+            known = None
+        if known is not None:
+            flags |= ffi.PMX_FLAG_SKIP_MLEN
         words = ffi.PMX_NROWS * (S + 1)
         d_out = self._device_out(words)
         self._ctx.cc_dev(d_f, d_r, d_m, nbits, S, L, flags, d_out)
@@ -275,7 +285,7 @@ class CCHipCalculator:
                 ccbins=[int(x) for x in out[ffi.PMX_ROW_NCC_CCBINS]])
             res.calc_cc()
         if d_m is not None:
-            by_shift = out[ffi.PMX_ROW_MLEN]
+            by_shift = out[ffi.PMX_ROW_MLEN] if known is None else [known[abs(c - d)] for d in range(S + 1)]
             # the reference stores mappable_len by LAG: d < L -> index L-1-d, L <= d < 2L-1 skipped
             # (same value by symmetry), d >= 2L-1 appended (mscc.pyx:271,292-298)
             mlen: List[Optional[int]] = [None] * L
@@ -303,6 +313,10 @@ class CCHipCalculator:
             return
         result = self.ref2mscc_result[chrom] = EmptyMSCCResult.create_empty(glen, S, L)
         nbits = glen + self._array_extend_size
+        known = self._known_mlen.get(chrom)
+        if known is not None and len(known) > S:      # cached table long enough: no track load, no kernel
+            result.mappable_len = tuple(int(x) for x in known[:S + 1])
+            return
         try:
             d_m = self._load_mappability(chrom, nbits)
             if d_m is None:

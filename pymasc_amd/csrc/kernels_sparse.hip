@@ -1174,7 +1174,7 @@ static void expand_chunks(const pmx_job *jobs, uint32_t njobs, uint32_t nshifts,
 }
 
 int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
-                               uint32_t read_len, bool do_ncc, uint32_t out_stride)
+                               uint32_t read_len, bool do_ncc, uint32_t out_stride, bool zero_mlen)
 {
     if (njobs == 0) return PMX_OK;
     const bool has_m = jobs[0].d_M != nullptr;
@@ -1194,6 +1194,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         rs.src_row[nr] = 1; rs.dst_row[nr] = PMX_ROW_MSCC_FSUM; nr++;
         rs.src_row[nr] = 2; rs.dst_row[nr] = PMX_ROW_MSCC_CCBINS; nr++;
         rs.src_row[nr] = 3; rs.dst_row[nr] = PMX_ROW_MSCC_RSUM; nr++;
+        if (zero_mlen) rs.zero_row[nz++] = PMX_ROW_MLEN;   // no autocorrelation pass will write it
     } else {
         rs.zero_row[nz++] = PMX_ROW_MSCC_FSUM;
         rs.zero_row[nz++] = PMX_ROW_MSCC_CCBINS;

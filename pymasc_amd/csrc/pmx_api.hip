@@ -447,7 +447,7 @@ int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint
 
 // one chromosome through the dense kernels (atomics into a zeroed block)
 static int cc_dense_one(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M, uint64_t nbits,
-                        uint32_t max_shift, uint32_t read_len, bool do_ncc, uint64_t *d_out)
+                        uint32_t max_shift, uint32_t read_len, bool do_ncc, bool do_mlen, uint64_t *d_out)
 {
     const uint32_t stride = max_shift + 1;
     u64 *out = (u64 *)d_out;
@@ -459,7 +459,7 @@ static int cc_dense_one(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, 
     if (rc) return rc;
     rc = pmx_launch_cc_dense(ctx, d_F, d_R, d_M, nbits, max_shift, read_len, do_ncc, out, stride, scal, 2);
     if (rc) return rc;
-    if (d_M) {
+    if (d_M && do_mlen) {
         const uint32_t c = read_len - 1;
         const uint32_t far = max_shift > c ? max_shift - c : 0;   // lags |c - d| over d in [0, max_shift]
         const uint32_t max_lag = c > far ? c : far;
@@ -495,6 +495,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         if (rc) return rc;
     }
     const bool do_ncc = !(flags & PMX_FLAG_SKIP_NCC);
+    const bool do_mlen = has_m && !(flags & PMX_FLAG_SKIP_MLEN);
     const uint32_t stride = max_shift + 1;
     const uint32_t c = read_len - 1;
     const uint32_t far = max_shift > c ? max_shift - c : 0;   // lags |c - d| over d in [0, max_shift]
@@ -510,7 +511,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
     if (!sparse_ok || (flags & PMX_FLAG_FORCE_DENSE)) {
         for (uint32_t i = 0; i < njobs; i++) {
             int rc = cc_dense_one(ctx, d_F[i], d_R[i], has_m ? d_M[i] : nullptr, nbits[i], max_shift, read_len, do_ncc,
-                                  d_out[i]);
+                                  do_mlen, d_out[i]);
             if (rc) return rc;
         }
         return PMX_OK;
@@ -520,7 +521,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
     pmx_job jobs[64];
     for (uint32_t lo = 0; lo < njobs; lo += chunk) {
         const uint32_t n = njobs - lo < chunk ? njobs - lo : chunk;
-        if (has_m) {
+        if (do_mlen) {
             int rc = pmx_ensure_scratch(ctx, (size_t)n * ac_words);
             if (rc) return rc;
         }
@@ -532,9 +533,9 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             jobs[i].d_out = d_out[lo + i];
             jobs[i].d_out2 = has_m ? (uint64_t *)(ctx->d_scratch + (size_t)i * ac_words) : nullptr;
         }
-        int rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride);
+        int rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, !do_mlen);
         if (rc) return rc;
-        if (has_m) {
+        if (do_mlen) {
             rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
             if (rc) return rc;
         }

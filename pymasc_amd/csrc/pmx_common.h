@@ -89,7 +89,7 @@ uint32_t pmx_sparse_max_jobs(void);
 // Writes rows NCC_CCBINS / MSCC_FSUM / MSCC_CCBINS / MSCC_RSUM and the scalar row of every job's result block
 // (rows the batch does not produce are written as zeros, MLEN included when there is no mappability).
 int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
-                               uint32_t read_len, bool do_ncc, uint32_t out_stride);
+                               uint32_t read_len, bool do_ncc, uint32_t out_stride, bool zero_mlen);
 // Run-edge autocorrelation of every job's d_M.  mode 0: d_out[k] = A(k), k <= max_lag.
 // mode 1: d_out is a result block: row MLEN[d] = A(|read_len - 1 - d|), d <= max_shift; scalar [2] = popcount(M).
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag,

@@ -25,6 +25,7 @@ PMX_NROWS = 6
 PMX_FLAG_SKIP_NCC = 1
 PMX_FLAG_FORCE_DENSE = 2
 PMX_FLAG_FORCE_SPARSE = 4
+PMX_FLAG_SKIP_MLEN = 8
 
 PMX_PATH_DENSE = 1
 PMX_PATH_SPARSE = 2

@@ -15,7 +15,7 @@ Chromosomes without reads (Empty*Result) take no part in the merge nor in the co
 sorted by name (table.py:198-201).
 
 Everything here is host-side float64/text over a few thousand numbers; the integers it consumes come from the
-HIP path (pymasc_amd/calculator.py).  Nothing under oracle/ is used.
+HIP path (pymasc_amd/calculator.py).
 """
 from __future__ import annotations
 

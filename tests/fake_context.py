@@ -69,7 +69,8 @@ class FakeContext:
             out[ffi.PMX_ROW_MSCC_FSUM] = ref["mscc_forward_sum"]
             out[ffi.PMX_ROW_MSCC_RSUM] = ref["mscc_reverse_sum"]
             out[ffi.PMX_ROW_MSCC_CCBINS] = ref["mscc_ccbins"]
-            out[ffi.PMX_ROW_MLEN] = ref["mappable_len_by_shift"]
+            if not flags & ffi.PMX_FLAG_SKIP_MLEN:
+                out[ffi.PMX_ROW_MLEN] = ref["mappable_len_by_shift"]
         self._mem[d_out][:out.size] = out.reshape(-1)
 
     def mappable_len_dev(self, d_M, nbits, max_shift, flags, d_out):
