@@ -1,4 +1,5 @@
-"""Builds libpymasc_hip.so (the C-ABI library of include/pymasc_amd.h) in-tree with hipcc for gfx950.
+"""Builds libpymasc_hip.so (the C-ABI library of include/pymasc_amd.h) in-tree with hipcc for gfx950, and
+libpymasc_io.so (include/pymasc_amd_io.h, host-side readers) with g++.
 
 The .so is git-ignored but travels with the gpurun snapshot; hipcc cross-compiles without a GPU.
 """
@@ -39,5 +40,27 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+IO_LIB = os.path.join(HERE, "libpymasc_io.so")
+
+
+def io_sources():
+    return sorted(glob.glob(os.path.join(CSRC, "io", "*.cpp")))
+
+
+def build_io(force=False, verbose=False):
+    """libpymasc_io.so (include/pymasc_amd_io.h): the host-side BAM / BigWig readers, plain g++ + zlib."""
+    deps = io_sources() + glob.glob(os.path.join(CSRC, "io", "*.h")) + [os.path.join(HERE, "..", "include",
+                                                                                      "pymasc_amd_io.h")]
+    if not force and os.path.exists(IO_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(IO_LIB) for d in deps):
+        return IO_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", IO_LIB,
+           *io_sources(), "-lz", "-pthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return IO_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_io(force="--force" in sys.argv, verbose=True))

@@ -207,13 +207,18 @@ class CCHipCalculator:
         """mscc.pyx:327-349 -> device vector, or None without a feeder; KeyError if the track is missing."""
         if not self._bwfeeder:
             return None
-        feeder = self._bwfeeder.fetch(self.MAPPABILITY_THRESHOLD, chrom)
-        self._logging_info("Loading {} mappability to bit array...".format(chrom))
-        iv = [(b, e) for b, e, _v in feeder]
-        d_m = self._device_vector("M", nbits)
-        if iv:
+        bulk = getattr(self._bwfeeder, "fetch_arrays", None)
+        if bulk is not None:          # pymasc_amd.bigwig.BigWigReader: arrays, no per-interval Python objects
+            begin, end, _v = bulk(self.MAPPABILITY_THRESHOLD, chrom)
+            first, last = begin.astype(np.int64) + 1, end.astype(np.int64)
+        else:
+            iv = [(b, e) for b, e, _v in self._bwfeeder.fetch(self.MAPPABILITY_THRESHOLD, chrom)]
             arr = np.asarray(iv, dtype=np.int64).reshape(-1, 2)
-            self._ctx.bits_set_regions(d_m, nbits, arr[:, 0] + 1, arr[:, 1].copy())   # set(begin + 1, end)
+            first, last = arr[:, 0] + 1, arr[:, 1].copy()
+        self._logging_info("Loading {} mappability to bit array...".format(chrom))
+        d_m = self._device_vector("M", nbits)
+        if first.size:
+            self._ctx.bits_set_regions(d_m, nbits, first, last)   # set(begin + 1, end), mscc.pyx:343-344
         return d_m
 
     def _calc_correlation(self):

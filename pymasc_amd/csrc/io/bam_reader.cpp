@@ -1,0 +1,425 @@
+// BAM -> filtered (ref_id, pos, query length, strand) arrays for the MI355X calculator.
+//
+// Replaces the reference's per-read Python loop (PyMaSC/handler/calc.py:140-153 iterating a pysam.AlignmentFile,
+// handler/read.py:62-155 filtering and extracting) with a windowed, multi-threaded native reader:
+//
+//   file (mmap) --scan BGZF headers--> window of <= WINDOW_BLOCKS blocks --parallel raw-inflate + CRC32-->
+//   contiguous uncompressed bytes (+ the partial record carried from the previous window)
+//   --serial hop over block_size fields--> record offsets --parallel decode + filter--> compact arrays
+//
+// Formats: SAM/BAM spec v1 section 4.1 (BGZF: gzip members with a 'BC' extra subfield holding BSIZE, <= 64 KiB of
+// payload each) and 4.2 (BAM header and alignment records, little endian).  pysam/htslib are absent from this
+// image; what they would have returned for the fields used here is fixed by the spec, and the parity test replays
+// the reference's own BAM <-> SAM twin (tests/data/ENCFF000RMB-test.{bam,sam}).
+#include "../../../include/pymasc_amd_io.h"
+#include "io_common.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t WINDOW_BLOCKS = 4096;       // <= 256 MiB of uncompressed data per window
+constexpr size_t BGZF_HEADER = 18, BGZF_FOOTER = 8;
+
+struct Block {
+    const uint8_t *cdata;   // raw deflate stream
+    uint32_t clen;
+    uint32_t isize;         // uncompressed size (footer)
+    uint32_t crc;
+    size_t out_off;
+};
+
+inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline int32_t le32s(const uint8_t *p) { return (int32_t)le32(p); }
+
+}  // namespace
+
+struct pmx_bam {
+    pmx_io::MappedFile file;
+    size_t next_off = 0;            // file offset of the next BGZF block to scan
+    bool eof = false;
+    int nthreads = 1;
+
+    std::string text;
+    std::vector<std::string> ref_names;
+    std::vector<int64_t> ref_lens;
+
+    std::vector<uint8_t> buf;       // [carry | inflated window]
+    size_t carry = 0;               // bytes of an incomplete record at the front of buf
+    std::vector<Block> blocks;
+    std::vector<size_t> rec_off;
+
+    // decoded, filtered records of the current window
+    std::vector<int32_t> w_ref, w_pos, w_len;
+    std::vector<uint8_t> w_rev;
+    size_t w_cursor = 0;
+
+    bool filter_set = false;
+    uint32_t mapq_min = 0, flag_exclude = 0;
+    uint64_t n_records = 0, n_kept = 0, bytes_out = 0, bytes_in = 0;
+};
+
+namespace {
+
+// Parses the BGZF member at `off`; false at a clean end of file.  Throws on a malformed member.
+bool scan_block(const pmx_bam &b, size_t off, Block &blk, size_t &next)
+{
+    const uint8_t *base = b.file.data;
+    const size_t size = b.file.size;
+    if (off == size) return false;
+    if (off + BGZF_HEADER + BGZF_FOOTER > size) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "truncated BGZF block header");
+    const uint8_t *p = base + off;
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4))
+        throw pmx_io::Error(PMX_IO_ERR_FORMAT, "not a BGZF block (bad gzip magic / no extra field)");
+    const uint32_t xlen = le16(p + 10);
+    if (off + 12 + xlen + BGZF_FOOTER > size) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "truncated BGZF extra field");
+    uint32_t bsize = 0;
+    bool found = false;
+    for (uint32_t x = 0; x + 4 <= xlen;) {
+        const uint8_t *s = p + 12 + x;
+        const uint32_t slen = le16(s + 2);
+        if (s[0] == 'B' && s[1] == 'C' && slen == 2 && x + 6 <= xlen) {
+            bsize = le16(s + 4);
+            found = true;
+            break;
+        }
+        x += 4 + slen;
+    }
+    if (!found) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "gzip member without the BGZF 'BC' subfield");
+    const size_t total = (size_t)bsize + 1;
+    if (total < 12 + xlen + BGZF_FOOTER || off + total > size)
+        throw pmx_io::Error(PMX_IO_ERR_FORMAT, "truncated BGZF block");
+    blk.cdata = p + 12 + xlen;
+    blk.clen = (uint32_t)(total - 12 - xlen - BGZF_FOOTER);
+    blk.crc = le32(p + total - 8);
+    blk.isize = le32(p + total - 4);
+    if (blk.isize > 65536) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BGZF block larger than 64 KiB");
+    next = off + total;
+    return true;
+}
+
+void inflate_block(const Block &blk, uint8_t *dst)
+{
+    if (blk.isize == 0) return;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "zlib: inflateInit2 failed");
+    zs.next_in = const_cast<Bytef *>(blk.cdata);
+    zs.avail_in = blk.clen;
+    zs.next_out = dst;
+    zs.avail_out = blk.isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.avail_out == 0;
+    inflateEnd(&zs);
+    if (!ok) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BGZF block does not inflate to its recorded size");
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, blk.isize) != blk.crc)
+        throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BGZF block CRC32 mismatch");
+}
+
+using pmx_io::parallel_for;
+
+// Appends the next window of inflated bytes behind the carried partial record.  Returns false when no block is left.
+bool load_window(pmx_bam &b, uint32_t max_blocks)
+{
+    b.blocks.clear();
+    size_t out = b.carry;
+    while (b.blocks.size() < max_blocks) {
+        Block blk;
+        size_t next;
+        if (!scan_block(b, b.next_off, blk, next)) {
+            b.eof = true;
+            break;
+        }
+        blk.out_off = out;
+        out += blk.isize;
+        b.bytes_in += next - b.next_off;
+        b.next_off = next;
+        b.blocks.push_back(blk);
+    }
+    if (b.blocks.empty()) return false;
+    b.buf.resize(out);
+    uint8_t *dst = b.buf.data();
+    const std::vector<Block> &blocks = b.blocks;
+    parallel_for(b.nthreads, blocks.size(), 16, [&](size_t lo, size_t hi, size_t) {
+        for (size_t i = lo; i < hi; i++) inflate_block(blocks[i], dst + blocks[i].out_off);
+    });
+    b.bytes_out += out - b.carry;
+    return true;
+}
+
+// Query length as pysam's infer_query_length(): CIGAR operations that consume the query, hard clips excluded.
+inline uint32_t query_length(const uint8_t *cig, uint32_t n)
+{
+    uint32_t q = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t v = le32(cig + 4 * i), op = v & 15u;
+        // M=0 I=1 S=4 '='=7 X=8
+        if ((0x193u >> op) & 1u) q += v >> 4;
+    }
+    return q;
+}
+
+// htslib moves a CIGAR of more than 65535 operations into the CG:B,I tag and leaves the placeholder
+// "<l_seq>S<ref_len>N" (SAM spec 4.2.2); returns the real operations when `rec` is such a record.
+bool long_cigar(const uint8_t *rec, uint32_t rec_len, uint32_t l_name, uint32_t n_cig, uint32_t l_seq,
+                const uint8_t *&cig, uint32_t &n)
+{
+    if (n_cig != 2) return false;
+    const uint8_t *c = rec + 32 + l_name;
+    const uint32_t c0 = le32(c), c1 = le32(c + 4);
+    if ((c0 & 15u) != 4 || (c0 >> 4) != l_seq || (c1 & 15u) != 3) return false;
+    size_t p = 32 + (size_t)l_name + 8 + ((size_t)l_seq + 1) / 2 + l_seq;
+    while (p + 3 <= rec_len) {
+        const uint8_t t0 = rec[p], t1 = rec[p + 1], ty = rec[p + 2];
+        p += 3;
+        size_t sz;
+        switch (ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'Z': case 'H': {
+            const void *z = memchr(rec + p, 0, rec_len - p);
+            if (!z) return false;
+            sz = (const uint8_t *)z - (rec + p) + 1;
+            break;
+        }
+        case 'B': {
+            if (p + 5 > rec_len) return false;
+            const uint8_t sub = rec[p];
+            const uint32_t cnt = le32(rec + p + 1);
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') {
+                if (p + 5 + (size_t)cnt * 4 > rec_len) return false;
+                cig = rec + p + 5;
+                n = cnt;
+                return true;
+            }
+            sz = 5 + (size_t)cnt * es;
+            break;
+        }
+        default: return false;
+        }
+        p += sz;
+    }
+    return false;
+}
+
+struct Decoded {
+    std::vector<int32_t> ref, pos, len;
+    std::vector<uint8_t> rev;
+};
+
+void decode_range(const pmx_bam &b, size_t lo, size_t hi, Decoded &out)
+{
+    const uint8_t *buf = b.buf.data();
+    const int32_t nref = (int32_t)b.ref_names.size();
+    for (size_t i = lo; i < hi; i++) {
+        const uint8_t *rec = buf + b.rec_off[i] + 4;          // past block_size
+        const uint32_t rec_len = le32(rec - 4);
+        const int32_t ref = le32s(rec);
+        const int32_t pos = le32s(rec + 4);
+        const uint32_t l_name = rec[8], mapq = rec[9];
+        const uint32_t n_cig = le16(rec + 12), flag = le16(rec + 14);
+        const uint32_t l_seq = le32(rec + 16);
+        if (32 + (size_t)l_name + 4 * (size_t)n_cig > rec_len)
+            throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BAM record shorter than its name and CIGAR");
+        if (ref >= nref) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BAM record refers to an unknown reference id");
+        if ((flag & b.flag_exclude) || mapq < b.mapq_min || ref < 0) continue;
+        const uint8_t *cig = rec + 32 + l_name;
+        uint32_t n = n_cig;
+        long_cigar(rec, rec_len, l_name, n_cig, l_seq, cig, n);
+        const uint32_t q = query_length(cig, n);
+        if (q == 0) continue;
+        out.ref.push_back(ref);
+        out.pos.push_back(pos + 1);
+        out.len.push_back((int32_t)q);
+        out.rev.push_back((flag & PMX_BAM_FLAG_REVERSE) ? 1 : 0);
+    }
+}
+
+// Decodes every complete record in buf into the window arrays and keeps the tail as carry.
+void decode_window(pmx_bam &b)
+{
+    const uint8_t *buf = b.buf.data();
+    const size_t n = b.buf.size();
+    b.rec_off.clear();
+    size_t p = 0;
+    while (p + 4 <= n) {
+        const uint32_t bs = le32(buf + p);
+        if (bs < 32) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BAM record with block_size < 32");
+        if (p + 4 + (size_t)bs > n) break;
+        b.rec_off.push_back(p);
+        p += 4 + (size_t)bs;
+    }
+    const size_t nrec = b.rec_off.size();
+    const size_t grain = 1 << 16;
+    const size_t chunks = (nrec + grain - 1) / grain;
+    std::vector<Decoded> parts(chunks);
+    parallel_for(b.nthreads, nrec, grain, [&](size_t lo, size_t hi, size_t c) { decode_range(b, lo, hi, parts[c]); });
+    size_t kept = 0;
+    for (auto &d : parts) kept += d.ref.size();
+    b.w_ref.resize(kept);
+    b.w_pos.resize(kept);
+    b.w_len.resize(kept);
+    b.w_rev.resize(kept);
+    size_t o = 0;
+    for (auto &d : parts) {
+        const size_t k = d.ref.size();
+        if (!k) continue;
+        memcpy(b.w_ref.data() + o, d.ref.data(), k * 4);
+        memcpy(b.w_pos.data() + o, d.pos.data(), k * 4);
+        memcpy(b.w_len.data() + o, d.len.data(), k * 4);
+        memcpy(b.w_rev.data() + o, d.rev.data(), k);
+        o += k;
+    }
+    b.w_cursor = 0;
+    b.n_records += nrec;
+    b.n_kept += kept;
+    // carry the incomplete tail to the front
+    b.carry = n - p;
+    if (b.carry) memmove(b.buf.data(), b.buf.data() + p, b.carry);
+    b.buf.resize(b.carry);
+}
+
+void parse_header(pmx_bam &b)
+{
+    // The header may span several BGZF blocks: inflate block by block until it is complete.
+    auto need = [&](size_t upto) {
+        while (b.buf.size() < upto) {
+            b.carry = b.buf.size();
+            if (!load_window(b, 1)) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "file ends inside the BAM header");
+        }
+    };
+    need(12);
+    if (memcmp(b.buf.data(), "BAM\1", 4) != 0) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "not a BAM file (bad magic)");
+    const uint32_t l_text = le32(b.buf.data() + 4);
+    need(12 + (size_t)l_text);
+    b.text.assign((const char *)b.buf.data() + 8, l_text);
+    while (!b.text.empty() && b.text.back() == '\0') b.text.pop_back();
+    size_t p = 8 + (size_t)l_text;
+    const uint32_t n_ref = le32(b.buf.data() + p);
+    p += 4;
+    b.ref_names.reserve(n_ref);
+    b.ref_lens.reserve(n_ref);
+    for (uint32_t i = 0; i < n_ref; i++) {
+        need(p + 4);
+        const uint32_t l_name = le32(b.buf.data() + p);
+        if (l_name == 0 || l_name > (1u << 20)) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "bad reference name length");
+        need(p + 4 + l_name + 4);
+        const char *nm = (const char *)b.buf.data() + p + 4;
+        b.ref_names.emplace_back(nm, strnlen(nm, l_name));
+        b.ref_lens.push_back((int64_t)le32(b.buf.data() + p + 4 + l_name));
+        p += 4 + (size_t)l_name + 4;
+    }
+    // what follows the header stays in buf as the carry of the first record window
+    const size_t rest = b.buf.size() - p;
+    if (rest) memmove(b.buf.data(), b.buf.data() + p, rest);
+    b.buf.resize(rest);
+    b.carry = rest;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pmx_bam_open(const char *path, int nthreads, pmx_bam **out)
+{
+    if (!path || !out) return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_open: NULL argument");
+    *out = nullptr;
+    pmx_bam *b = new pmx_bam();
+    try {
+        b->file.open(path);
+        b->nthreads = pmx_io::pick_threads(nthreads);
+        parse_header(*b);
+    } catch (const pmx_io::Error &e) {
+        delete b;
+        return pmx_io::fail(e.code, std::string(path) + ": " + e.msg);
+    } catch (const std::exception &e) {
+        delete b;
+        return pmx_io::fail(PMX_IO_ERR_OPEN, std::string(path) + ": " + e.what());
+    }
+    *out = b;
+    return PMX_IO_OK;
+}
+
+void pmx_bam_close(pmx_bam *b) { delete b; }
+
+int32_t pmx_bam_nref(const pmx_bam *b) { return b ? (int32_t)b->ref_names.size() : 0; }
+
+const char *pmx_bam_ref_name(const pmx_bam *b, int32_t i)
+{
+    if (!b || i < 0 || (size_t)i >= b->ref_names.size()) return nullptr;
+    return b->ref_names[i].c_str();
+}
+
+int64_t pmx_bam_ref_len(const pmx_bam *b, int32_t i)
+{
+    if (!b || i < 0 || (size_t)i >= b->ref_lens.size()) return -1;
+    return b->ref_lens[i];
+}
+
+const char *pmx_bam_header_text(const pmx_bam *b, uint32_t *len)
+{
+    if (!b) return nullptr;
+    if (len) *len = (uint32_t)b->text.size();
+    return b->text.c_str();
+}
+
+int64_t pmx_bam_next_batch(pmx_bam *b, uint32_t mapq_min, uint32_t flag_exclude, int64_t cap,
+                           int32_t *ref_id, int32_t *pos1, int32_t *read_len, uint8_t *reverse)
+{
+    if (!b || cap <= 0 || !ref_id || !pos1 || !read_len || !reverse)
+        return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_next_batch: NULL argument or cap <= 0");
+    if (!b->filter_set) {
+        b->mapq_min = mapq_min;
+        b->flag_exclude = flag_exclude;
+        b->filter_set = true;
+    } else if (b->mapq_min != mapq_min || b->flag_exclude != flag_exclude) {
+        return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_next_batch: the filter must not change between calls");
+    }
+    try {
+        while (b->w_cursor == b->w_ref.size()) {
+            if (b->eof) {
+                if (b->carry) return pmx_io::fail(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
+                return 0;
+            }
+            const bool more = load_window(*b, WINDOW_BLOCKS);
+            if (more || b->carry) decode_window(*b);
+            if (!more && b->carry)
+                return pmx_io::fail(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
+        }
+    } catch (const pmx_io::Error &e) {
+        return pmx_io::fail(e.code, e.msg);
+    } catch (const std::exception &e) {
+        return pmx_io::fail(PMX_IO_ERR_FORMAT, e.what());
+    }
+    const size_t n = std::min<size_t>((size_t)cap, b->w_ref.size() - b->w_cursor);
+    const size_t c = b->w_cursor;
+    memcpy(ref_id, b->w_ref.data() + c, n * 4);
+    memcpy(pos1, b->w_pos.data() + c, n * 4);
+    memcpy(read_len, b->w_len.data() + c, n * 4);
+    memcpy(reverse, b->w_rev.data() + c, n);
+    b->w_cursor += n;
+    return (int64_t)n;
+}
+
+int pmx_bam_counters(const pmx_bam *b, uint64_t *records, uint64_t *kept, uint64_t *bytes_out, uint64_t *bytes_in)
+{
+    if (!b) return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_counters: NULL handle");
+    if (records) *records = b->n_records;
+    if (kept) *kept = b->n_kept;
+    if (bytes_out) *bytes_out = b->bytes_out;
+    if (bytes_in) *bytes_in = b->bytes_in;
+    return PMX_IO_OK;
+}
+
+}  // extern "C"

@@ -203,11 +203,16 @@ class MappabilityStats:
     def _calc_chrom(self, chrom: str) -> Tuple[int, ...]:
         ctx = self._context()
         logger.info("Calc {} mappable length...".format(chrom))
-        iv = [(b, e) for b, e, _v in self.feeder.fetch(MAPPABILITY_THRESHOLD, chrom)]
+        bulk = getattr(self.feeder, "fetch_arrays", None)
+        if bulk is not None:
+            begin, end, _v = bulk(MAPPABILITY_THRESHOLD, chrom)
+            arr = np.stack((begin.astype(np.int64), end.astype(np.int64)), axis=1)
+        else:
+            iv = [(b, e) for b, e, _v in self.feeder.fetch(MAPPABILITY_THRESHOLD, chrom)]
+            arr = np.asarray(iv, dtype=np.int64).reshape(-1, 2)
         nlag = self.max_shift + 1
-        if not iv:
+        if arr.shape[0] == 0:
             return tuple([0] * nlag)
-        arr = np.asarray(iv, dtype=np.int64).reshape(-1, 2)
         if (arr[:, 1] <= arr[:, 0]).any() or arr.min() < 0:
             raise ValueError("malformed mappability interval on {}".format(chrom))
         nbits = int(max(arr[:, 1].max(), self.chromsizes.get(chrom, 0))) + _PAD_BITS

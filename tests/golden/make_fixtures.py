@@ -10,6 +10,8 @@ Inputs (data files held by the reference's tests, no source code):
   tests/data/hg19_36mer-test.bedGraph        -> copied (mappability intervals, text twin of the bigwig)
   tests/data/hg19_36mer-test_mappability.json-> copied (lag table golden)
   tests/golden/ENCFF000RMB-test_{cc,mscc,nreads,stats}.tab -> copied (expected outputs)
+  tests/data/ENCFF000RMB-test.bam, tests/data/hg19_36mer-test.bigwig -> copied (binary twins of the .sam and the
+        .bedGraph above: inputs of the native readers' parity tests, tests/test_io_readers.py)
 """
 import os
 import re
@@ -41,6 +43,7 @@ def main():
         for r in rows:
             out.write("\t".join(str(x) for x in r) + "\n")
     for rel in ["data/hg19_36mer-test.bedGraph", "data/hg19_36mer-test_mappability.json",
+                "data/ENCFF000RMB-test.bam", "data/hg19_36mer-test.bigwig",
                 "golden/ENCFF000RMB-test_cc.tab", "golden/ENCFF000RMB-test_mscc.tab",
                 "golden/ENCFF000RMB-test_nreads.tab", "golden/ENCFF000RMB-test_stats.tab"]:
         shutil.copyfile(os.path.join(REF, rel), os.path.join(HERE, os.path.basename(rel)))

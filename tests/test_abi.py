@@ -10,8 +10,8 @@ from pymasc_amd import build, ffi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "pymasc_amd.h")).read()
+def header_symbols(name="pymasc_amd.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pmx_[a-z_0-9]+)\s*\(", text)))
 
@@ -33,11 +33,29 @@ def test_every_declared_symbol_is_exported():
     assert L.pmx_version() >= 100
 
 
+def test_io_library_builds_and_exports_its_header():
+    """libpymasc_io.so (host readers, include/pymasc_amd_io.h): every declared symbol, nothing undeclared bound."""
+    from pymasc_amd import bam
+    path = build.build_io()
+    assert os.path.exists(path)
+    L = bam.load_io_library()
+    syms = header_symbols("pymasc_amd_io.h")
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(bam.IO_EXPORTS) == syms
+    assert L.pmx_io_version() >= 1
+    text = open(os.path.join(ROOT, "include", "pymasc_amd_io.h")).read()
+    consts = dict(re.findall(r"#define\s+(PMX_BAM_FLAG_[A-Z0-9]+)\s+(0x[0-9a-fA-F]+)u", text))
+    for k, v in consts.items():
+        assert getattr(bam, k) == int(v, 16), k
+
+
 def test_header_constants_match_binding():
     text = open(os.path.join(ROOT, "include", "pymasc_amd.h")).read()
     consts = dict(re.findall(r"#define\s+(PMX_[A-Z_0-9]+)\s+(-?\d+)u?\b", text))
     for name in ("PMX_ROW_NCC_CCBINS", "PMX_ROW_MSCC_FSUM", "PMX_ROW_MSCC_RSUM", "PMX_ROW_MSCC_CCBINS",
-                 "PMX_ROW_MLEN", "PMX_ROW_SCALARS", "PMX_NROWS", "PMX_FLAG_SKIP_NCC", "PMX_FLAG_FORCE_DENSE",
+                 "PMX_ROW_MLEN", "PMX_ROW_SCALARS", "PMX_NROWS", "PMX_FLAG_SKIP_NCC", "PMX_FLAG_FORCE_DENSE", "PMX_FLAG_SKIP_MLEN",
                  "PMX_FLAG_FORCE_SPARSE", "PMX_PATH_DENSE", "PMX_PATH_SPARSE", "PMX_KERNEL_CC_DENSE",
                  "PMX_KERNEL_CC_SPARSE", "PMX_KERNEL_AUTOCORR"):
         assert int(consts[name]) == getattr(ffi, name), name
