@@ -7,6 +7,9 @@
 //   contiguous uncompressed bytes (+ the partial record carried from the previous window)
 //   --serial hop over block_size fields--> record offsets --parallel decode + filter--> compact arrays
 //
+// A producer thread runs that pipeline one window ahead of the consumer (pmx_bam_next_batch), so the serial hops
+// and the caller's own work (numpy, host->device copies, kernels) overlap the inflation of the next window.
+//
 // Formats: SAM/BAM spec v1 section 4.1 (BGZF: gzip members with a 'BC' extra subfield holding BSIZE, <= 64 KiB of
 // payload each) and 4.2 (BAM header and alignment records, little endian).  pysam/htslib are absent from this
 // image; what they would have returned for the fields used here is fixed by the spec, and the parity test replays
@@ -18,6 +21,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -26,7 +34,8 @@
 
 namespace {
 
-constexpr uint32_t WINDOW_BLOCKS = 4096;       // <= 256 MiB of uncompressed data per window
+constexpr uint32_t WINDOW_BLOCKS = 1024;       // <= 64 MiB of uncompressed data per window
+constexpr size_t QUEUE_DEPTH = 2;              // decoded windows waiting for the consumer
 constexpr size_t BGZF_HEADER = 18, BGZF_FOOTER = 8;
 
 struct Block {
@@ -35,6 +44,33 @@ struct Block {
     uint32_t isize;         // uncompressed size (footer)
     uint32_t crc;
     size_t out_off;
+};
+
+// Byte buffer that grows without zero-filling (std::vector::resize would memset every window).
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~RawBuf() { free(p); }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    void resize(size_t m)
+    {
+        if (m > cap) {
+            const size_t c = std::max(m, cap + cap / 2);
+            uint8_t *q = (uint8_t *)realloc(p, c);
+            if (!q) throw pmx_io::Error(PMX_IO_ERR_OPEN, "out of memory");
+            p = q;
+            cap = c;
+        }
+        n = m;
+    }
+};
+
+// decoded, filtered records of one window
+struct Window {
+    std::vector<int32_t> ref, pos, len;
+    std::vector<uint8_t> rev;
 };
 
 inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -53,22 +89,36 @@ struct pmx_bam {
     std::vector<std::string> ref_names;
     std::vector<int64_t> ref_lens;
 
-    std::vector<uint8_t> buf;       // [carry | inflated window]
+    RawBuf buf;                     // [carry | inflated window]
     size_t carry = 0;               // bytes of an incomplete record at the front of buf
     std::vector<Block> blocks;
     std::vector<size_t> rec_off;
 
-    // decoded, filtered records of the current window
-    std::vector<int32_t> w_ref, w_pos, w_len;
-    std::vector<uint8_t> w_rev;
+    // consumer side: the window being handed out
+    Window cur;
     size_t w_cursor = 0;
+
+    // producer thread and its hand-over queue (started by the first pmx_bam_next_batch, when the filter is known)
+    std::thread producer;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Window> queue;
+    bool done = false, stop = false;
+    int err_code = 0;
+    std::string err_msg;
 
     bool filter_set = false;
     uint32_t mapq_min = 0, flag_exclude = 0;
-    uint64_t n_records = 0, n_kept = 0, bytes_out = 0, bytes_in = 0;
+    std::atomic<uint64_t> n_records{0}, n_kept{0}, bytes_out{0}, bytes_in{0};
+    double t_scan = 0, t_alloc = 0, t_inflate = 0, t_walk = 0, t_decode = 0, t_concat = 0;   // PMX_IO_TIMING=1
 };
 
 namespace {
+
+inline double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // Parses the BGZF member at `off`; false at a clean end of file.  Throws on a malformed member.
 bool scan_block(const pmx_bam &b, size_t off, Block &blk, size_t &next)
@@ -132,6 +182,7 @@ bool load_window(pmx_bam &b, uint32_t max_blocks)
 {
     b.blocks.clear();
     size_t out = b.carry;
+    double t0 = now_s();
     while (b.blocks.size() < max_blocks) {
         Block blk;
         size_t next;
@@ -146,12 +197,17 @@ bool load_window(pmx_bam &b, uint32_t max_blocks)
         b.blocks.push_back(blk);
     }
     if (b.blocks.empty()) return false;
+    double t1 = now_s();
+    b.t_scan += t1 - t0;
     b.buf.resize(out);
     uint8_t *dst = b.buf.data();
+    t0 = now_s();
+    b.t_alloc += t0 - t1;
     const std::vector<Block> &blocks = b.blocks;
     parallel_for(b.nthreads, blocks.size(), 16, [&](size_t lo, size_t hi, size_t) {
         for (size_t i = lo; i < hi; i++) inflate_block(blocks[i], dst + blocks[i].out_off);
     });
+    b.t_inflate += now_s() - t0;
     b.bytes_out += out - b.carry;
     return true;
 }
@@ -247,12 +303,13 @@ void decode_range(const pmx_bam &b, size_t lo, size_t hi, Decoded &out)
 }
 
 // Decodes every complete record in buf into the window arrays and keeps the tail as carry.
-void decode_window(pmx_bam &b)
+void decode_window(pmx_bam &b, Window &w)
 {
     const uint8_t *buf = b.buf.data();
     const size_t n = b.buf.size();
     b.rec_off.clear();
     size_t p = 0;
+    double t0 = now_s();
     while (p + 4 <= n) {
         const uint32_t bs = le32(buf + p);
         if (bs < 32) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BAM record with block_size < 32");
@@ -264,30 +321,69 @@ void decode_window(pmx_bam &b)
     const size_t grain = 1 << 16;
     const size_t chunks = (nrec + grain - 1) / grain;
     std::vector<Decoded> parts(chunks);
+    double t1 = now_s();
+    b.t_walk += t1 - t0;
     parallel_for(b.nthreads, nrec, grain, [&](size_t lo, size_t hi, size_t c) { decode_range(b, lo, hi, parts[c]); });
+    t0 = now_s();
+    b.t_decode += t0 - t1;
     size_t kept = 0;
     for (auto &d : parts) kept += d.ref.size();
-    b.w_ref.resize(kept);
-    b.w_pos.resize(kept);
-    b.w_len.resize(kept);
-    b.w_rev.resize(kept);
+    w.ref.resize(kept);
+    w.pos.resize(kept);
+    w.len.resize(kept);
+    w.rev.resize(kept);
     size_t o = 0;
     for (auto &d : parts) {
         const size_t k = d.ref.size();
         if (!k) continue;
-        memcpy(b.w_ref.data() + o, d.ref.data(), k * 4);
-        memcpy(b.w_pos.data() + o, d.pos.data(), k * 4);
-        memcpy(b.w_len.data() + o, d.len.data(), k * 4);
-        memcpy(b.w_rev.data() + o, d.rev.data(), k);
+        memcpy(w.ref.data() + o, d.ref.data(), k * 4);
+        memcpy(w.pos.data() + o, d.pos.data(), k * 4);
+        memcpy(w.len.data() + o, d.len.data(), k * 4);
+        memcpy(w.rev.data() + o, d.rev.data(), k);
         o += k;
     }
-    b.w_cursor = 0;
     b.n_records += nrec;
     b.n_kept += kept;
     // carry the incomplete tail to the front
     b.carry = n - p;
     if (b.carry) memmove(b.buf.data(), b.buf.data() + p, b.carry);
     b.buf.resize(b.carry);
+    b.t_concat += now_s() - t0;
+}
+
+// Producer thread: windows -> queue, until end of file, an error or close().
+void produce(pmx_bam *b)
+{
+    try {
+        for (;;) {
+            if (b->eof) {
+                if (b->carry) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
+                break;
+            }
+            const bool more = load_window(*b, WINDOW_BLOCKS);
+            Window w;
+            if (more || b->carry) decode_window(*b, w);
+            if (!more && b->carry) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
+            std::unique_lock<std::mutex> lk(b->mu);
+            b->cv.wait(lk, [&] { return b->queue.size() < QUEUE_DEPTH || b->stop; });
+            if (b->stop) return;
+            if (!w.ref.empty()) {
+                b->queue.push_back(std::move(w));
+                b->cv.notify_all();
+            }
+        }
+    } catch (const pmx_io::Error &e) {
+        std::lock_guard<std::mutex> g(b->mu);
+        b->err_code = e.code;
+        b->err_msg = e.msg;
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> g(b->mu);
+        b->err_code = PMX_IO_ERR_FORMAT;
+        b->err_msg = e.what();
+    }
+    std::lock_guard<std::mutex> g(b->mu);
+    b->done = true;
+    b->cv.notify_all();
 }
 
 void parse_header(pmx_bam &b)
@@ -351,7 +447,22 @@ int pmx_bam_open(const char *path, int nthreads, pmx_bam **out)
     return PMX_IO_OK;
 }
 
-void pmx_bam_close(pmx_bam *b) { delete b; }
+void pmx_bam_close(pmx_bam *b)
+{
+    if (!b) return;
+    if (b->producer.joinable()) {
+        {
+            std::lock_guard<std::mutex> g(b->mu);
+            b->stop = true;
+        }
+        b->cv.notify_all();
+        b->producer.join();
+    }
+    if (getenv("PMX_IO_TIMING"))
+        fprintf(stderr, "[pmx_bam] scan %.3f alloc %.3f inflate %.3f walk %.3f decode %.3f concat %.3f s (%d threads)\n",
+                b->t_scan, b->t_alloc, b->t_inflate, b->t_walk, b->t_decode, b->t_concat, b->nthreads);
+    delete b;
+}
 
 int32_t pmx_bam_nref(const pmx_bam *b) { return b ? (int32_t)b->ref_names.size() : 0; }
 
@@ -386,28 +497,25 @@ int64_t pmx_bam_next_batch(pmx_bam *b, uint32_t mapq_min, uint32_t flag_exclude,
     } else if (b->mapq_min != mapq_min || b->flag_exclude != flag_exclude) {
         return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_next_batch: the filter must not change between calls");
     }
-    try {
-        while (b->w_cursor == b->w_ref.size()) {
-            if (b->eof) {
-                if (b->carry) return pmx_io::fail(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
-                return 0;
-            }
-            const bool more = load_window(*b, WINDOW_BLOCKS);
-            if (more || b->carry) decode_window(*b);
-            if (!more && b->carry)
-                return pmx_io::fail(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
+    if (!b->producer.joinable() && !b->done) b->producer = std::thread(produce, b);
+    while (b->w_cursor == b->cur.ref.size()) {
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv.wait(lk, [&] { return !b->queue.empty() || b->done; });
+        if (b->queue.empty()) {      // done: end of file or a failure
+            if (b->err_code) return pmx_io::fail(b->err_code, b->err_msg);
+            return 0;
         }
-    } catch (const pmx_io::Error &e) {
-        return pmx_io::fail(e.code, e.msg);
-    } catch (const std::exception &e) {
-        return pmx_io::fail(PMX_IO_ERR_FORMAT, e.what());
+        b->cur = std::move(b->queue.front());
+        b->queue.pop_front();
+        b->w_cursor = 0;
+        b->cv.notify_all();
     }
-    const size_t n = std::min<size_t>((size_t)cap, b->w_ref.size() - b->w_cursor);
+    const size_t n = std::min<size_t>((size_t)cap, b->cur.ref.size() - b->w_cursor);
     const size_t c = b->w_cursor;
-    memcpy(ref_id, b->w_ref.data() + c, n * 4);
-    memcpy(pos1, b->w_pos.data() + c, n * 4);
-    memcpy(read_len, b->w_len.data() + c, n * 4);
-    memcpy(reverse, b->w_rev.data() + c, n);
+    memcpy(ref_id, b->cur.ref.data() + c, n * 4);
+    memcpy(pos1, b->cur.pos.data() + c, n * 4);
+    memcpy(read_len, b->cur.len.data() + c, n * 4);
+    memcpy(reverse, b->cur.rev.data() + c, n);
     b->w_cursor += n;
     return (int64_t)n;
 }
@@ -415,10 +523,10 @@ int64_t pmx_bam_next_batch(pmx_bam *b, uint32_t mapq_min, uint32_t flag_exclude,
 int pmx_bam_counters(const pmx_bam *b, uint64_t *records, uint64_t *kept, uint64_t *bytes_out, uint64_t *bytes_in)
 {
     if (!b) return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_counters: NULL handle");
-    if (records) *records = b->n_records;
-    if (kept) *kept = b->n_kept;
-    if (bytes_out) *bytes_out = b->bytes_out;
-    if (bytes_in) *bytes_in = b->bytes_in;
+    if (records) *records = b->n_records.load();
+    if (kept) *kept = b->n_kept.load();
+    if (bytes_out) *bytes_out = b->bytes_out.load();
+    if (bytes_in) *bytes_in = b->bytes_in.load();
     return PMX_IO_OK;
 }
 

@@ -72,7 +72,7 @@ def test_synthetic_bam_records_straddling_blocks(tmp_path, block):
 
 
 def test_window_boundaries(tmp_path):
-    """More BGZF blocks than one reader window (4096) with records cut by the window edge."""
+    """More BGZF blocks than several reader windows (1024 each) with records cut by the window edge."""
     rng = np.random.default_rng(11)
     refs = [("c1", 2_000_000)]
     recs, meta = W.synth_bam_records(rng, refs, 9000)
