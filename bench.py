@@ -32,7 +32,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--max-shift", type=int, default=1000)
+    ap.add_argument("--workload", choices=["hg38", "stress"], default="hg38",
+                    help="hg38: BASELINE config 4 (default, the metric's configuration); stress: config 5, one "
+                         "synthetic 10 Gbp / 200-chromosome genome sharded over the ranks, max_shift 5000")
+    ap.add_argument("--max-shift", type=int, default=None, help="default 1000 (hg38) / 5000 (stress)")
     ap.add_argument("--read-len", type=int, default=36)
     ap.add_argument("--density", type=float, default=0.005, help="read start density per strand (BASELINE.md config 4)")
     ap.add_argument("--mode", choices=["both", "ncc"], default="both",
@@ -104,14 +107,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    stress = args.workload == "stress"
+    if args.max_shift is None:
+        args.max_shift = 5000 if stress else 1000
     S, L = args.max_shift, args.read_len
     with_m = args.mode == "both"
     flags = {"auto": 0, "dense": ffi.PMX_FLAG_FORCE_DENSE, "sparse": ffi.PMX_FLAG_FORCE_SPARSE}[args.path]
     ctx = ffi.Context(dev_index)
 
-    chroms = synth.HG38[:args.chroms]
-    # batch = `world` samples x chromosomes; LPT over ranks (identical on every rank)
-    jobs = [(s, i) for s in range(world) for i in range(len(chroms))]
+    chroms = synth.stress_genome() if stress else synth.HG38[:args.chroms]
+    # hg38: batch = `world` samples x chromosomes (weak scaling); stress: ONE genome over all ranks (strong scaling).
+    # LPT over ranks (identical on every rank)
+    jobs = [(s, i) for s in range(1 if stress else world) for i in range(len(chroms))]
     costs = [chroms[i][1] for (_s, i) in jobs]
     assignment = sharding.lpt_assign(costs, world)
     mine = assignment[rank]
@@ -191,7 +198,7 @@ def main():
     # default single-GPU workload it was collected on
     traffic, traffic_src = None, None
     try:
-        if world == 1 and args.chroms == 24 and args.density == 0.005 and S == 1000 and with_m:
+        if world == 1 and not stress and args.chroms == 24 and args.density == 0.005 and S == 1000 and with_m:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
             key = {ffi.PMX_KERNEL_CC_SPARSE: "k_cc_sparse", ffi.PMX_KERNEL_AUTOCORR: "k_autocorr_edges"}.get(dom)
             if key:
@@ -212,17 +219,19 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if stress else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE config 4: synthetic hg38-shaped F/R"
+            "workload": (("BASELINE config 5 (stress): synthetic 10 Gbp genome F/R" if stress else
+                          "BASELINE config 4: synthetic hg38-shaped F/R")
                          + ("+mappability" if with_m else "") + f" bit-vectors, {len(chroms)} chromosomes x "
-                         f"{world} sample(s), {total_bp / 1e9:.3f} Gbp total, max_shift={S}, read_len={L}, "
+                         f"{1 if stress else world} sample(s), {total_bp / 1e9:.3f} Gbp total, max_shift={S}, read_len={L}, "
                          f"read density {args.density}/strand, "
                          + ("NCC+MSCC" if with_m else "NCC only")
-                         + "; stands in for ENCFF000VPI.bam (configs 2-3), which is not available offline"),
+                         + ("" if stress else
+                            "; stands in for ENCFF000VPI.bam (configs 2-3), which is not available offline")),
             "mode": args.mode,
             "kernel_path": args.path,
             "parallelism": f"chromosome jobs LPT-sharded over {world} GPU(s); all-gather rows + all-reduce totals",

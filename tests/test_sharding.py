@@ -97,3 +97,81 @@ def test_single_process_exchange_is_identity():
     expect = np.stack([_rows_for(j) for j in range(len(LENGTHS))])
     np.testing.assert_array_equal(rows.numpy(), expect)
     np.testing.assert_array_equal(totals.numpy(), expect.sum(axis=0))
+
+
+# ---- from the input files: BAM + BigWig -> per-rank calculators -> gathered genome-wide result -> tables ----------
+def _write_inputs(tmp):
+    from tests import io_writers as W
+    rng = np.random.default_rng(77)
+    refs = [("c1", 40000), ("c2", 25000), ("c3", 31000), ("c4", 9000), ("c5", 18000)]
+    recs, _meta = W.synth_bam_records(rng, refs[:4], 900)          # c5 has no reads
+    bam = os.path.join(tmp, "s.bam")
+    W.write_bam(bam, refs, recs, block=3000)
+    tracks = {}
+    for name, size in refs[:3] + refs[4:]:                           # c4 has no mappability track
+        iv, p = [], int(rng.integers(0, 40))
+        while p < size - 300:
+            ln = int(rng.integers(20, 400))
+            iv.append((p, p + ln, float(rng.choice([0.5, 1.0, 1.0, 1.0]))))
+            p += ln + int(rng.integers(1, 90))
+        tracks[name] = iv
+    bw = os.path.join(tmp, "m.bw")
+    W.write_bigwig(bw, {n: s for n, s in refs if n in tracks}, tracks, items_per_block=40)
+    return bam, bw
+
+
+def _table_bytes(result, tmp, tag):
+    from pymasc_amd import tables
+    paths = tables.write_tables(os.path.join(tmp, tag + ".bam"), result)
+    return [open(p, "rb").read() for p in paths]
+
+
+def _file_worker(rank, world, port, q, bam, bw, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.fake_context import FakeContext
+        res = sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, context=FakeContext())
+        q.put((rank, _table_bytes(res, tmp, "rank%d" % rank), res.forward_sum, res.reverse_sum, res.genomelen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_run_from_files_matches_single_process(tmp_path):
+    from tests.fake_context import FakeContext
+    tmp = str(tmp_path)
+    bam, bw = _write_inputs(tmp)
+    single = sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, context=FakeContext())
+    assert set(single.chroms) == {"c1", "c2", "c3", "c4", "c5"}
+    expect = _table_bytes(single, tmp, "single")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_file_worker, args=(r, world, port, q, bam, bw, tmp)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, tabs, fsum, rsum, glen in got:
+        assert tabs == expect, rank                      # byte-identical _cc / _mscc / _nreads tables on every rank
+        assert (fsum, rsum, glen) == (single.forward_sum, single.reverse_sum, single.genomelen)
+
+
+@pytest.mark.gpu
+def test_run_from_files_gpu_matches_host_restatement(tmp_path):
+    """Same inputs through the HIP path (single rank) and through the oracle-backed stand-in: identical tables."""
+    from tests.fake_context import FakeContext
+    tmp = str(tmp_path)
+    bam, bw = _write_inputs(tmp)
+    host = sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, context=FakeContext())
+    gpu = sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, device=0)
+    assert _table_bytes(gpu, tmp, "gpu") == _table_bytes(host, tmp, "host")
+    for skip_ncc in (True,):
+        host = sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, skip_ncc=skip_ncc, context=FakeContext())
+        gpu = sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, skip_ncc=skip_ncc, device=0)
+        assert _table_bytes(gpu, tmp, "gpu2") == _table_bytes(host, tmp, "host2")
