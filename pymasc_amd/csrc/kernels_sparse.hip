@@ -82,10 +82,13 @@ struct SpLds {
     static constexpr u32 REC = PLR + (HAS_M ? SP_CAP : 0);          // per-slot record staging (4 dwords each)
     static constexpr u32 ACC = REC + 4 * SP_CAP;                    // [counter][plane][32]
     static constexpr u32 NCOUNTERS = HAS_M ? 4 : 1;
-    static constexpr u32 STAGE = ACC + NCOUNTERS * SP_NL * 32;      // [wave][plane][32]
-    static constexpr u32 MISC = STAGE + 256 * SP_NQ;
+    // fold staging [wave][SP_NS planes][32] ALIASES the record region: counter_to_lds runs at the top of a
+    // (tile, round) pass, after B0 retired the previous pass's records and before this pass builds its own
+    static constexpr u32 STAGE = REC;
+    static constexpr u32 MISC = ACC + NCOUNTERS * SP_NL * 32;
     static constexpr u32 TOTAL = MISC + 16;
 };
+static_assert(4 * SP_NS * 32 <= 4 * SP_CAP, "the fold staging must fit in the record region it aliases");
 
 struct Planes {
     u32 P[SP_NP];
