@@ -1,0 +1,174 @@
+"""GPU: the hot path at BASELINE.json's full sizes (config 4: 24 hg38-length chromosomes, max_shift 1000; one
+chromosome of config 5 at max_shift 5000), checked through properties that do not need the CPU oracle to finish:
+
+  * selected shifts recomputed independently with plain torch integer ops on the packed words (shift, AND, byte-table
+    popcount) -- every output row, several shifts including 0, read_len - 1, read_len and max_shift;
+  * scalars: popcount rows equal the torch popcounts; mappable_len at lag 0 equals popcount(M);
+  * the two kernel families (set-bit windows vs dense word-parallel) agree on a whole chromosome;
+  * one batched launch over the genome == per-chromosome launches (bit-exact).
+All integers, all exact."""
+import numpy as np
+import pytest
+import torch
+
+from pymasc_amd import ffi, synth
+
+pytestmark = pytest.mark.gpu
+
+S, L = 1000, 36
+ROWS = ffi.PMX_NROWS
+
+
+@pytest.fixture(scope="module")
+def env():
+    ctx = ffi.Context(0)
+    dev = torch.device("cuda", 0)
+    yield ctx, dev
+    ctx.close()
+
+
+_POP8 = None
+
+
+def _popcount(words: torch.Tensor) -> int:
+    """Population count of int64 words through a 256-entry byte table (torch has no popcount)."""
+    global _POP8
+    if _POP8 is None or _POP8.device != words.device:
+        _POP8 = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=words.device)
+    total = 0
+    flat = words.view(torch.uint8)
+    for lo in range(0, flat.numel(), 1 << 28):
+        total += int(_POP8[flat[lo:lo + (1 << 28)].long()].sum().item())
+    return total
+
+
+def _shr(words: torch.Tensor, d: int) -> torch.Tensor:
+    """Bit-vector >> d (bit i of the result = bit i + d of the input), zero fill."""
+    q, r = divmod(d, 64)
+    n = words.numel()
+    out = torch.zeros_like(words)
+    if q >= n:
+        return out
+    lo = words[q:]
+    if r == 0:
+        out[:n - q] = lo
+        return out
+    mask = (1 << (64 - r)) - 1                                  # arithmetic shift on int64: clear the sign fill
+    out[:n - q] = torch.bitwise_and(torch.bitwise_right_shift(lo, r), mask)
+    out[:n - q - 1] |= torch.bitwise_left_shift(lo[1:], 64 - r)
+    return out
+
+
+def _shl(words: torch.Tensor, d: int) -> torch.Tensor:
+    """Bit-vector << d (bit i of the result = bit i - d of the input)."""
+    q, r = divmod(d, 64)
+    n = words.numel()
+    out = torch.zeros_like(words)
+    if q >= n:
+        return out
+    hi = words[:n - q]
+    if r == 0:
+        out[q:] = hi
+        return out
+    mask = (1 << r) - 1
+    out[q:] = torch.bitwise_left_shift(hi, r)
+    out[q + 1:] |= torch.bitwise_and(torch.bitwise_right_shift(hi[:-1], 64 - r), mask)
+    return out
+
+
+def _torch_reference(v, d: int):
+    """mscc.pyx:288-317 for ONE shift with whole-vector torch ops: F[j] & R[j+d] & D_d[j], D_d[j] = M[j] & M[j+c-d]."""
+    c = L - 1
+    F, R, M = v.F, v.R, v.M
+    Rd = _shr(R, d)
+    k = c - d
+    Mk = _shr(M, k) if k >= 0 else _shl(M, -k)
+    D = M & Mk
+    return {
+        "ncc": _popcount(F & Rd),
+        "fsum": _popcount(F & D),
+        "rsum": _popcount(Rd & D),
+        "cc": _popcount(F & Rd & D),
+        "mlen": _popcount(D),
+    }
+
+
+def _run_batch(ctx, dev, vecs, max_shift, flags=0):
+    out = torch.zeros((len(vecs), ROWS, max_shift + 1), dtype=torch.int64, device=dev)
+    ctx.cc_batch_dev([v.F.data_ptr() for v in vecs], [v.R.data_ptr() for v in vecs], [v.M.data_ptr() for v in vecs],
+                     [v.nbits for v in vecs], max_shift, L, flags, [out[i].data_ptr() for i in range(len(vecs))])
+    ctx.sync()
+    return out.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def genome(env):
+    ctx, dev = env
+    vecs = synth.make_genome(ctx, dev, synth.HG38, S, L)
+    rows = _run_batch(ctx, dev, vecs, S)
+    return vecs, rows
+
+
+def test_full_genome_selected_shifts_against_torch(env, genome):
+    vecs, rows = genome
+    assert sum(v.length for v in vecs) == sum(l for _, l in synth.HG38)      # 3.088 Gbp
+    for i in (0, 7, 20, 23):                                                    # chr1, chr8, chr21, chrY
+        v = vecs[i]
+        for d in (0, 1, L - 1, L, 517, S):
+            ref = _torch_reference(v, d)
+            got = {"ncc": rows[i, ffi.PMX_ROW_NCC_CCBINS, d], "fsum": rows[i, ffi.PMX_ROW_MSCC_FSUM, d],
+                   "rsum": rows[i, ffi.PMX_ROW_MSCC_RSUM, d], "cc": rows[i, ffi.PMX_ROW_MSCC_CCBINS, d],
+                   "mlen": rows[i, ffi.PMX_ROW_MLEN, d]}
+            assert {k: int(x) for k, x in got.items()} == ref, (v.name, d)
+
+
+def test_full_genome_scalars_and_bounds(env, genome):
+    vecs, rows = genome
+    for i, v in enumerate(vecs):
+        sc = rows[i, ffi.PMX_ROW_SCALARS]
+        assert int(sc[3]) == ffi.PMX_PATH_SPARSE
+        if i in (2, 11, 22):
+            assert (int(sc[0]), int(sc[1]), int(sc[2])) == (_popcount(v.F), _popcount(v.R), _popcount(v.M))
+        assert 0 < sc[0] <= v.n_forward and 0 < sc[1] <= v.n_reverse           # duplicates collapse into one bit
+        mlen = rows[i, ffi.PMX_ROW_MLEN]
+        assert int(mlen[L - 1]) == int(sc[2])                                   # lag 0 <-> shift read_len - 1
+        assert (mlen <= sc[2]).all()
+        # masked counts never exceed the unmasked ones, nor the strand totals
+        assert (rows[i, ffi.PMX_ROW_MSCC_CCBINS] <= rows[i, ffi.PMX_ROW_NCC_CCBINS]).all()
+        assert (rows[i, ffi.PMX_ROW_MSCC_FSUM] <= sc[0]).all() and (rows[i, ffi.PMX_ROW_MSCC_RSUM] <= sc[1]).all()
+        # the planted fragment peak at +180 (synth.make_chromosome) dominates the naive curve
+        assert int(np.argmax(rows[i, ffi.PMX_ROW_NCC_CCBINS])) == 180
+
+
+def test_full_chromosome_dense_and_sparse_kernels_agree(env, genome):
+    ctx, dev = env
+    vecs, rows = genome
+    for i in (0, 18):                                                           # chr1 (longest), chr19
+        dense = _run_batch(ctx, dev, [vecs[i]], S, ffi.PMX_FLAG_FORCE_DENSE)[0]
+        assert int(dense[ffi.PMX_ROW_SCALARS, 3]) == ffi.PMX_PATH_DENSE
+        for r in range(5):
+            np.testing.assert_array_equal(dense[r], rows[i, r])
+        np.testing.assert_array_equal(dense[ffi.PMX_ROW_SCALARS, :3], rows[i, ffi.PMX_ROW_SCALARS, :3])
+
+
+def test_batched_launch_equals_single_launches(env, genome):
+    ctx, dev = env
+    vecs, rows = genome
+    for i in (1, 12, 23):
+        single = _run_batch(ctx, dev, [vecs[i]], S)[0]
+        np.testing.assert_array_equal(single, rows[i])
+
+
+def test_stress_chromosome_max_shift_5000(env):
+    """Config 5 shape: one 2.5e8-bp chromosome at max_shift 5000 (five 1024-shift chunks)."""
+    ctx, dev = env
+    S5 = 5000
+    name, length = max(synth.stress_genome(), key=lambda t: t[1])
+    v = synth.make_chromosome(ctx, dev, name, length, S5, L, 0xBADC0DE)
+    rows = _run_batch(ctx, dev, [v], S5)[0]
+    for d in (0, 1023, 1024, 2047, 2048, 3333, 4999, 5000):                     # chunk edges included
+        ref = _torch_reference(v, d)
+        got = {"ncc": rows[ffi.PMX_ROW_NCC_CCBINS, d], "fsum": rows[ffi.PMX_ROW_MSCC_FSUM, d],
+               "rsum": rows[ffi.PMX_ROW_MSCC_RSUM, d], "cc": rows[ffi.PMX_ROW_MSCC_CCBINS, d],
+               "mlen": rows[ffi.PMX_ROW_MLEN, d]}
+        assert {k: int(x) for k, x in got.items()} == ref, d
