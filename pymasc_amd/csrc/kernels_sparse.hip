@@ -796,11 +796,14 @@ struct AcLds {
     static constexpr u32 PL = D + AC_W;                  // positions of the edges (+ falling flag)
     static constexpr u32 REC = PL + SP_CAP;              // per-slot record staging (4 dwords each)
     static constexpr u32 ACC = REC + 4 * SP_CAP;         // [2][plane][32]
-    static constexpr u32 STAGE = ACC + 2 * SP_NL * 32;
-    static constexpr u32 MISC = STAGE + 256 * SP_NQ;
+    static constexpr u32 STAGE = REC;                    // aliases the records (same argument as in SpLds)
+    static constexpr u32 MISC = ACC + 2 * SP_NL * 32;
     static constexpr u32 TOTAL = MISC + 16;
 };
 #define AC_SEG_ROWS 3u               // P, N, scalars
+#ifndef AC_WAVES
+#define AC_WAVES 4
+#endif
 
 struct AcRegs {
     uint4 m, h;    // driver quad (unshifted) + (threads 0..8) the quad above the WINDOW tile
@@ -870,7 +873,7 @@ __device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 fi
 }
 
 template <bool CH>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, AC_WAVES)
 k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab)
 {
     typedef AcLds L;
@@ -1278,7 +1281,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         SpJobTable tab;
         memset(&tab, 0, sizeof tab);
         uint32_t total, tpw, nwg;
-        plan_launch(ctx, &vjobs[lo], n, true, 4, &tab, &total, &tpw, &nwg);
+        plan_launch(ctx, &vjobs[lo], n, true, AC_WAVES, &tab, &total, &tpw, &nwg);
         int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
         if (rc) return rc;
         pmx_timed_launch tl;
