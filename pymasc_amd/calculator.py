@@ -84,6 +84,9 @@ class CCHipCalculator:
         self._bwfeeder = bwfeeder
         self._progress = progress_bar
         self._kernel_flags = int(kernel_flags)
+        # the result block of the C ABI keeps four scalars in a row of max_shift + 1 words, so the kernels are run
+        # with at least 3 shifts; shifts are independent, rows are cut back to max_shift + 1 below
+        self._kshift = max(self.max_shift, 3)
         # lag tables known beforehand (the *_mappability.json cache, pymasc_amd/mappability.py): chromosomes
         # found here skip the autocorrelation pass
         self._known_mlen: Dict[str, Sequence[int]] = dict(chrom2mappable_len or {})
@@ -274,10 +277,11 @@ class CCHipCalculator:
             known = None
         if known is not None:
             flags |= ffi.PMX_FLAG_SKIP_MLEN
-        words = ffi.PMX_NROWS * (S + 1)
+        KS = self._kshift
+        words = ffi.PMX_NROWS * (KS + 1)
         d_out = self._device_out(words)
-        self._ctx.cc_dev(d_f, d_r, d_m, nbits, S, L, flags, d_out)
-        out = self._ctx.bits_download(d_out, words * 64).reshape(ffi.PMX_NROWS, S + 1)
+        self._ctx.cc_dev(d_f, d_r, d_m, nbits, KS, L, flags, d_out)
+        out = self._ctx.bits_download(d_out, words * 64).reshape(ffi.PMX_NROWS, KS + 1)
 
         if not self.skip_ncc:
             fsum = int(out[ffi.PMX_ROW_SCALARS, 0])
@@ -287,7 +291,7 @@ class CCHipCalculator:
             res = self.ref2ncc_result[chrom] = NCCResult(
                 max_shift=S, read_len=L, genomelen=glen, forward_sum=fsum, reverse_sum=rsum,
                 forward_read_len_sum=f_read_len_sum, reverse_read_len_sum=r_read_len_sum,
-                ccbins=[int(x) for x in out[ffi.PMX_ROW_NCC_CCBINS]])
+                ccbins=[int(x) for x in out[ffi.PMX_ROW_NCC_CCBINS, :S + 1]])
             res.calc_cc()
         if d_m is not None:
             by_shift = out[ffi.PMX_ROW_MLEN] if known is None else [known[abs(c - d)] for d in range(S + 1)]
@@ -301,10 +305,10 @@ class CCHipCalculator:
                     mlen.append(int(by_shift[d]))
             mres = self.ref2mscc_result[chrom] = MSCCResult(
                 max_shift=S, read_len=L, genomelen=glen,
-                forward_sum=[int(x) for x in out[ffi.PMX_ROW_MSCC_FSUM]],
-                reverse_sum=[int(x) for x in out[ffi.PMX_ROW_MSCC_RSUM]],
+                forward_sum=[int(x) for x in out[ffi.PMX_ROW_MSCC_FSUM, :S + 1]],
+                reverse_sum=[int(x) for x in out[ffi.PMX_ROW_MSCC_RSUM, :S + 1]],
                 forward_read_len_sum=f_read_len_sum, reverse_read_len_sum=r_read_len_sum,
-                ccbins=[int(x) for x in out[ffi.PMX_ROW_MSCC_CCBINS]], mappable_len=mlen)
+                ccbins=[int(x) for x in out[ffi.PMX_ROW_MSCC_CCBINS, :S + 1]], mappable_len=mlen)
             mres.calc_cc()
 
     def _fill_result(self, chrom: str):
@@ -329,9 +333,10 @@ class CCHipCalculator:
         except KeyError:
             return
         self._logging_info("Calc {} mappable length...".format(chrom))
-        d_out = self._device_out(ffi.PMX_NROWS * (S + 1))
-        self._ctx.mappable_len_dev(d_m, nbits, S, self._kernel_flags, d_out)
-        out = self._ctx.bits_download(d_out, (S + 1) * 64)
+        KS = self._kshift
+        d_out = self._device_out(ffi.PMX_NROWS * (KS + 1))
+        self._ctx.mappable_len_dev(d_m, nbits, KS, self._kernel_flags, d_out)
+        out = self._ctx.bits_download(d_out, (KS + 1) * 64)
         result.mappable_len = tuple(int(x) for x in out[:S + 1])
 
     # ---- lifecycle (mscc.pyx:173-179, :420-483) -----------------------------------------------------

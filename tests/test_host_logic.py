@@ -169,3 +169,33 @@ def test_calc_cc_formulas():
     m.calc_cc()
     np.testing.assert_array_equal(m.cc, oracle.mscc_cc([9, 8, 7, 6, 5, 4], [5, 6, 7, 8, 9, 9],
                                                        [1, 2, 3, 2, 1, 0], [500, 490, 480, 470], 5, 3))
+
+
+def _check_tiny_shift_ranges(context_factory):
+    """max_shift 0..2 (and shift ranges shorter than the read): legal in the reference; the kernels are run with
+    three shifts and the rows cut back (pymasc_amd/calculator.py)."""
+    names, lens, tracks, reads = _small_mscc_setup(seed=21)
+    for S in (0, 1, 2, 5, 35, 36, 70, 71, 72):
+        ctx = context_factory()
+        calc = CCHipCalculator(S, 36, names, lens, bwfeeder=DictFeeder(tracks), context=ctx)
+        ocalc = oracle.OracleCalculator(S, 36, names, lens, mappability={
+            c: [x for x in iv if np.float32(x[2]) >= 1] for c, iv in tracks.items()})
+        feed_all(calc, reads)
+        feed_all(ocalc, reads)
+        calc.finishup_calculation()
+        ocalc.finishup_calculation()
+        assert_matches_oracle(calc, ocalc, names)
+        r = calc.get_result("a")
+        assert len(r.chrom.ccbins) == S + 1 and len(r.chrom.cc) == S + 1
+        assert len(r.mappable_chrom.ccbins) == S + 1 and len(r.mappable_chrom.forward_sum) == S + 1
+        ctx.close()
+
+
+def test_tiny_shift_ranges_host():
+    _check_tiny_shift_ranges(FakeContext)
+
+
+@pytest.mark.gpu
+def test_tiny_shift_ranges_gpu():
+    from pymasc_amd import ffi
+    _check_tiny_shift_ranges(lambda: ffi.Context(0))
