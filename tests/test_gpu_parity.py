@@ -43,6 +43,8 @@ CASES = [
     (10, 90000, 5000, 100, 0.005, 0.02, True),  # -d 5000
     (11, 70000, 1024, 36, 0.01, 0.01, False),   # first shift of the second chunk, NCC only
     (12, 40000, 3000, 1024, 0.02, 0.01, True),  # longest supported read length
+    (13, 150000, 65535, 36, 0.004, 0.004, True),   # largest max_shift of the ABI: 64 chunks of 1024 shifts
+    (14, 20000, 40000, 50, 0.02, 0.02, True),   # shift range longer than the chromosome
 ]
 
 
