@@ -36,7 +36,7 @@ def parse():
                     help="hg38: BASELINE config 4 (default, the metric's configuration); stress: config 5, one "
                          "synthetic 10 Gbp / 200-chromosome genome sharded over the ranks, max_shift 5000")
     ap.add_argument("--max-shift", type=int, default=None, help="default 1000 (hg38) / 5000 (stress)")
-    ap.add_argument("--read-len", type=int, default=36)
+    ap.add_argument("--read-len", type=int, default=None, help="default 36 (hg38) / 100 (stress, BASELINE config 5)")
     ap.add_argument("--density", type=float, default=0.005, help="read start density per strand (BASELINE.md config 4)")
     ap.add_argument("--mode", choices=["both", "ncc"], default="both",
                     help="both = NCC + MaSC with mappability (config 4); ncc = naive CC only (config 2 shape)")
@@ -75,7 +75,13 @@ def cpu_baseline(ctx, vecs, S, L, with_m, sample_bp, threads):
         list(ex.map(lambda s: oracle.calc_correlation(s[0], s[1], s[2], s[3], S, L), slices))
     dt = time.perf_counter() - t0
     work = (S + 1) * sum(s[4] for s in slices)
+    # one slice alone on one core (SURVEY 8d asks for the 1-thread figure as well)
+    t1 = time.perf_counter()
+    s0 = slices[0]
+    oracle.calc_correlation(s0[0], s0[1], s0[2], s0[3], S, L)
+    dt1 = time.perf_counter() - t1
     return {"value": work / dt, "unit": "shifts*bp/s", "cores": threads, "kind": "port",
+            "one_thread_value": (S + 1) * s0[4] / dt1,
             "sample": f"{threads} slices x {slices[0][4] / 1e6:.1f} Mbp of the same synthetic chromosomes, "
                       f"{'NCC+MSCC' if with_m else 'NCC'}, max_shift={S}, one slice per thread, {dt:.1f}s wall",
             "seconds": dt}
@@ -110,6 +116,8 @@ def main():
     stress = args.workload == "stress"
     if args.max_shift is None:
         args.max_shift = 5000 if stress else 1000
+    if args.read_len is None:
+        args.read_len = 100 if stress else 36
     S, L = args.max_shift, args.read_len
     with_m = args.mode == "both"
     flags = {"auto": 0, "dense": ffi.PMX_FLAG_FORCE_DENSE, "sparse": ffi.PMX_FLAG_FORCE_SPARSE}[args.path]
@@ -210,6 +218,15 @@ def main():
     work_per_step = (S + 1) * total_bp
     value = work_per_step * args.steps / elapsed
 
+    # the bound that prices the DENSE formulation of the reference is integer VALU, not HBM:
+    # (S+1) * N/32 word-steps x (funnel shift + AND + popcount-accumulate = 3 lane-ops; MSCC: + 3 ANDs + 3 popcounts)
+    # against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.  The set-bit kernels skip the zero words those word-steps are
+    # counted on, so "achieved" may exceed the peak: it measures how much dense work the formulation avoids.
+    VALU_PEAK = 256 * 4 * 32 * 2.4e9
+    dense_lane_ops_per_step = (S + 1) * (sum(v.nbits for v in vecs) / 32.0) * (9 if with_m else 3)
+    kern_s_per_step = sum(t for t, _n in ktimes.values()) * 1e-3 / args.steps
+    valu_achieved = dense_lane_ops_per_step / kern_s_per_step if kern_s_per_step > 0 else 0.0
+
     result = {
         "metric": "shifts*genome-bp/sec (whole node), hg38 max_shift=1000; HBM-BW fraction",
         "value": value,
@@ -249,6 +266,13 @@ def main():
             "avg_launch_ms": avg_ms,
             "launches": dom_n,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+        },
+        "roofline_valu": {
+            "bound": "valu", "achieved": valu_achieved, "peak": VALU_PEAK, "unit": "lane-ops/s",
+            "frac": valu_achieved / VALU_PEAK,
+            "note": "dense-algorithm lane-ops of this rank's vectors (SURVEY 8d: (S+1)*N/32 word-steps x "
+                    + ("9" if with_m else "3") + " ops) / summed kernel time; > 1 means the set-bit formulation does "
+                    "less work than the dense word-step count this bound prices",
         },
         "kernel_ms_per_step": kernel_ms_per_step,
         "gen_seconds": round(t_gen, 2),
