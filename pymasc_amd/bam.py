@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Iterator, List, Optional, Sequence, Tuple
+from typing import Iterator, Optional, Sequence, Tuple
 
 import numpy as np
 

@@ -14,7 +14,7 @@ from typing import Dict, Iterator, Tuple
 
 import numpy as np
 
-from .bam import PmxIOError, _raise, load_io_library
+from .bam import PmxIOError, _raise, load_io_library  # noqa: F401  (PmxIOError re-exported)
 
 PMX_IO_ERR_NOTFOUND = -4
 

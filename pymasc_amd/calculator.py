@@ -19,7 +19,7 @@ There is no CPU compute fallback: constructing the calculator without a visible 
 from __future__ import annotations
 
 import logging
-from typing import Any, Dict, Iterable, List, Optional, Sequence
+from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 

@@ -17,7 +17,7 @@ from pymasc_amd.exceptions import ReadUnsortedError
 from pymasc_amd import tables as T
 from . import fixtures as fx
 from . import io_writers as W
-from .helpers import DictFeeder, assert_matches_oracle, feed_all
+from .helpers import assert_matches_oracle, feed_all
 
 BAM = os.path.join(fx.GOLDEN, "ENCFF000RMB-test.bam")
 BIGWIG = os.path.join(fx.GOLDEN, "hg19_36mer-test.bigwig")

@@ -15,7 +15,6 @@ import json
 import os
 import sys
 import time
-import zlib
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
