@@ -121,7 +121,11 @@ def main():
     S, L = args.max_shift, args.read_len
     with_m = args.mode == "both"
     flags = {"auto": 0, "dense": ffi.PMX_FLAG_FORCE_DENSE, "sparse": ffi.PMX_FLAG_FORCE_SPARSE}[args.path]
-    ctx = ffi.Context(dev_index)
+    # ONE stream for everything (vector builders, the hot-path kernels, torch's gather / RCCL collectives): steps queue
+    # back to back without host synchronisation between them; the HIP-event kernel timing is on this same stream
+    tstream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(tstream)
+    ctx = ffi.Context(dev_index, stream=tstream.cuda_stream)
 
     chroms = synth.stress_genome() if stress else synth.HG38[:args.chroms]
     # hg38: batch = `world` samples x chromosomes (weak scaling); stress: ONE genome over all ranks (strong scaling).
@@ -155,7 +159,6 @@ def main():
     def step():
         # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev), then the exchange
         ctx.cc_batch_dev(pF, pR, pM, pN, S, L, flags, pO)
-        ctx.sync()
         if world > 1 and backend != "nccl":
             return sharding.exchange_results(d_rows.cpu(), assignment, len(jobs))
         return sharding.exchange_results(d_rows, assignment, len(jobs))
