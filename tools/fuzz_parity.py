@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""GPU box: randomized parity sweep of the C-ABI hot path against the CPU oracle (test infrastructure).
+
+Draws chromosome length, max_shift, read_len, read densities, mappability run statistics and the kernel-path flag at
+random, runs pmx_calc_correlation / pmx_cc_batch_dev / pmx_mappable_len, and compares every output word with
+oracle/cc_oracle.c.  Sizes are kept small enough for the oracle to keep up; the point is coverage of odd geometry
+(tile edges, shift-chunk edges, S vs L vs chromosome length, empty / saturated vectors), not throughput.
+
+    python tools/fuzz_parity.py --seconds 240 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import model as oracle  # noqa: E402
+from pymasc_amd import ffi  # noqa: E402
+from tests import synth  # noqa: E402
+
+
+def draw_case(rng):
+    kind = rng.integers(0, 10)
+    S = int(rng.choice([3, 4, 31, 32, 33, 63, 64, 100, 300, 511, 512, 1000, 1023, 1024, 1025, 2047, 2048, 3000, 5000]))
+    if kind == 0:
+        S = int(rng.integers(3, 6000))
+    L = int(rng.choice([1, 2, 20, 36, 50, 100, 151, 250, 1000, 1024]))
+    if kind == 1:
+        L = int(rng.integers(1, 1025))
+    clen = int(rng.choice([1, 40, 900, 5000, 32768 - 200, 32768, 32768 + 7, 65536, 70001, 131072 + 31, 200003]))
+    if kind == 2:
+        clen = int(rng.integers(1, 250000))
+    fd = float(rng.choice([0.0, 0.0005, 0.005, 0.02, 0.1, 0.5, 1.0]))
+    rd = float(rng.choice([0.0, 0.0005, 0.005, 0.02, 0.1, 0.5, 1.0]))
+    with_m = bool(rng.random() < 0.75)
+    mean_on = float(rng.choice([1.5, 5, 30, 300, 3000, 1e6]))
+    mean_off = float(rng.choice([1.5, 5, 80, 500, 1e6]))
+    return S, L, clen, fd, rd, with_m, mean_on, mean_off
+
+
+def compare(out, ref, S, with_m, skip_ncc, tag):
+    ok = True
+    def chk(name, a, b):
+        nonlocal ok
+        if not np.array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64)):
+            bad = np.flatnonzero(np.asarray(a).astype(np.int64) != np.asarray(b).astype(np.int64))
+            print("MISMATCH", tag, name, "first bad shift", bad[:5], "of", bad.size, flush=True)
+            ok = False
+    if not skip_ncc:
+        chk("ncc", out[ffi.PMX_ROW_NCC_CCBINS, :S + 1], ref["ncc_ccbins"])
+        chk("popF", out[ffi.PMX_ROW_SCALARS, 0], ref["ncc_forward_sum"])
+        chk("popR", out[ffi.PMX_ROW_SCALARS, 1], ref["ncc_reverse_sum"])
+    if with_m:
+        chk("fsum", out[ffi.PMX_ROW_MSCC_FSUM], ref["mscc_forward_sum"])
+        chk("rsum", out[ffi.PMX_ROW_MSCC_RSUM], ref["mscc_reverse_sum"])
+        chk("cc", out[ffi.PMX_ROW_MSCC_CCBINS], ref["mscc_ccbins"])
+        chk("mlen", out[ffi.PMX_ROW_MLEN], ref["mappable_len_by_shift"])
+    return ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    oracle.lib()
+    t_end = time.time() + a.seconds
+    n = bad = 0
+    last = time.time()
+    with ffi.Context(0) as ctx:
+        while time.time() < t_end:
+            S, L, clen, fd, rd, with_m, mean_on, mean_off = draw_case(rng)
+            # keep the oracle's (S+1) * words * passes affordable
+            if (S + 1) * (clen + S + L + 100) > 1.5e9:
+                continue
+            case_seed = int(rng.integers(0, 2**31))
+            nbits, F, R, M = synth.make_case(case_seed, clen, S, L, fd, rd, with_m, mean_on=mean_on, mean_off=mean_off)
+            skip_ncc = with_m and rng.random() < 0.2
+            ref = oracle.calc_correlation(F, R, M, nbits, S, L, skip_ncc=skip_ncc)
+            for flags in (0, ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE):
+                if flags == ffi.PMX_FLAG_FORCE_DENSE and (S + 1) * nbits > 3e8:
+                    continue
+                fl = flags | (ffi.PMX_FLAG_SKIP_NCC if skip_ncc else 0)
+                tag = f"seed={case_seed} S={S} L={L} clen={clen} fd={fd} rd={rd} m={with_m}/{mean_on}/{mean_off} flags={fl}"
+                try:
+                    out = ctx.calc_correlation(F, R, M, nbits, S, L, fl)
+                except ffi.PmxError as e:
+                    print("ERROR", tag, e, flush=True)
+                    bad += 1
+                    continue
+                if not compare(out, ref, S, with_m, skip_ncc, tag):
+                    bad += 1
+            if with_m and rng.random() < 0.3:
+                lag = int(rng.choice([S, 300, 1023, 1024, 4000]))
+                if (lag + 1) * nbits < 1.5e9:
+                    want = oracle.mappable_len_readless(M, nbits, lag)
+                    got = ctx.mappable_len(M, nbits, lag, 0)
+                    if not np.array_equal(got.astype(np.int64), want.astype(np.int64)):
+                        print("MISMATCH mappable_len", case_seed, lag, flush=True)
+                        bad += 1
+            n += 1
+            if time.time() - last > 30:
+                print(f"[fuzz] {n} cases, {bad} bad", flush=True)
+                last = time.time()
+    print(f"[fuzz] done: {n} cases, {bad} bad")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
