@@ -65,6 +65,15 @@ const char *pmx_bam_header_text(const pmx_bam *b, uint32_t *len);
 int64_t pmx_bam_next_batch(pmx_bam *b, uint32_t mapq_min, uint32_t flag_exclude, int64_t cap,
                            int32_t *ref_id, int32_t *pos1, int32_t *read_len, uint8_t *reverse);
 
+/* .bai index (SAM spec 5.2): what the reference's multi-process mode requires (reader/bam.py:246-262) and uses
+ * through pysam's fetch(chrom) (handler/worker.py:106-132).  After pmx_bam_fetch_ref, pmx_bam_next_batch yields
+ * the records of that reference only (same filter, same fields) and returns 0 at the end of the reference; it
+ * may be called again for another reference, or with ref_id = -1 to go back to one pass over the whole file
+ * (no index needed for that).  A reference without records is an empty range, not an error. */
+int pmx_bam_index_load(pmx_bam *b, const char *bai_path);
+int pmx_bam_has_index(const pmx_bam *b);
+int pmx_bam_fetch_ref(pmx_bam *b, int32_t ref_id);
+
 /* Counters since open: alignment records decoded, records that passed the filter, uncompressed bytes inflated,
  * compressed bytes consumed. */
 int pmx_bam_counters(const pmx_bam *b, uint64_t *records, uint64_t *kept, uint64_t *bytes_out, uint64_t *bytes_in);

@@ -109,6 +109,20 @@ struct pmx_bam {
 
     bool filter_set = false;
     uint32_t mapq_min = 0, flag_exclude = 0;
+
+    // .bai index: per reference the virtual file offsets [beg, end) of its records (SAM spec 5.2)
+    struct RefRange {
+        bool has = false;
+        uint64_t beg = 0, end = 0;
+    };
+    std::vector<RefRange> index;
+    bool have_index = false;
+    // region mode (pmx_bam_fetch_ref): only records of want_ref, blocks up to the one holding the range's end
+    int32_t want_ref = -1;
+    size_t stop_block = SIZE_MAX;   // file offset of the last BGZF block that belongs to the region
+    size_t skip = 0;                // bytes of the first inflated block that precede the region
+    uint64_t data_beg = 0;          // virtual offset of the first alignment record (rewind target)
+    bool pristine = true;           // nothing read since open: a rewind has nothing to do
     std::atomic<uint64_t> n_records{0}, n_kept{0}, bytes_out{0}, bytes_in{0};
     double t_scan = 0, t_alloc = 0, t_inflate = 0, t_walk = 0, t_decode = 0, t_concat = 0;   // PMX_IO_TIMING=1
 };
@@ -186,7 +200,7 @@ bool load_window(pmx_bam &b, uint32_t max_blocks)
     while (b.blocks.size() < max_blocks) {
         Block blk;
         size_t next;
-        if (!scan_block(b, b.next_off, blk, next)) {
+        if (b.next_off > b.stop_block || !scan_block(b, b.next_off, blk, next)) {
             b.eof = true;
             break;
         }
@@ -290,6 +304,7 @@ void decode_range(const pmx_bam &b, size_t lo, size_t hi, Decoded &out)
             throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BAM record shorter than its name and CIGAR");
         if (ref >= nref) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BAM record refers to an unknown reference id");
         if ((flag & b.flag_exclude) || mapq < b.mapq_min || ref < 0) continue;
+        if (b.want_ref >= 0 && ref != b.want_ref) continue;
         const uint8_t *cig = rec + 32 + l_name;
         uint32_t n = n_cig;
         long_cigar(rec, rec_len, l_name, n_cig, l_seq, cig, n);
@@ -308,7 +323,8 @@ void decode_window(pmx_bam &b, Window &w)
     const uint8_t *buf = b.buf.data();
     const size_t n = b.buf.size();
     b.rec_off.clear();
-    size_t p = 0;
+    size_t p = b.skip < n ? b.skip : n;   // region mode: the first block starts before the region
+    b.skip -= p;
     double t0 = now_s();
     while (p + 4 <= n) {
         const uint32_t bs = le32(buf + p);
@@ -356,14 +372,16 @@ void produce(pmx_bam *b)
 {
     try {
         for (;;) {
+            const bool region = b->want_ref >= 0;   // a region ends inside a block: what follows is the next reference
             if (b->eof) {
-                if (b->carry) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
+                if (b->carry && !region) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
                 break;
             }
             const bool more = load_window(*b, WINDOW_BLOCKS);
             Window w;
             if (more || b->carry) decode_window(*b, w);
-            if (!more && b->carry) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
+            if (!more && b->carry && !region)
+                throw pmx_io::Error(PMX_IO_ERR_FORMAT, "file ends inside an alignment record");
             std::unique_lock<std::mutex> lk(b->mu);
             b->cv.wait(lk, [&] { return b->queue.size() < QUEUE_DEPTH || b->stop; });
             if (b->stop) return;
@@ -389,8 +407,10 @@ void produce(pmx_bam *b)
 void parse_header(pmx_bam &b)
 {
     // The header may span several BGZF blocks: inflate block by block until it is complete.
+    std::vector<std::pair<size_t, size_t>> loaded;   // (file offset, uncompressed start) of the header's blocks
     auto need = [&](size_t upto) {
         while (b.buf.size() < upto) {
+            loaded.emplace_back(b.next_off, b.buf.size());
             b.carry = b.buf.size();
             if (!load_window(b, 1)) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "file ends inside the BAM header");
         }
@@ -416,6 +436,8 @@ void parse_header(pmx_bam &b)
         b.ref_lens.push_back((int64_t)le32(b.buf.data() + p + 4 + l_name));
         p += 4 + (size_t)l_name + 4;
     }
+    for (const auto &blk : loaded)
+        if (blk.second <= p) b.data_beg = ((uint64_t)blk.first << 16) | (uint64_t)(p - blk.second);
     // what follows the header stays in buf as the carry of the first record window
     const size_t rest = b.buf.size() - p;
     if (rest) memmove(b.buf.data(), b.buf.data() + p, rest);
@@ -497,6 +519,7 @@ int64_t pmx_bam_next_batch(pmx_bam *b, uint32_t mapq_min, uint32_t flag_exclude,
     } else if (b->mapq_min != mapq_min || b->flag_exclude != flag_exclude) {
         return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_next_batch: the filter must not change between calls");
     }
+    b->pristine = false;
     if (!b->producer.joinable() && !b->done) b->producer = std::thread(produce, b);
     while (b->w_cursor == b->cur.ref.size()) {
         std::unique_lock<std::mutex> lk(b->mu);
@@ -518,6 +541,122 @@ int64_t pmx_bam_next_batch(pmx_bam *b, uint32_t mapq_min, uint32_t flag_exclude,
     memcpy(reverse, b->cur.rev.data() + c, n);
     b->w_cursor += n;
     return (int64_t)n;
+}
+
+int pmx_bam_index_load(pmx_bam *b, const char *bai_path)
+{
+    if (!b) return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_index_load: NULL handle");
+    try {
+        pmx_io::MappedFile f;
+        f.open(bai_path);
+        const uint8_t *d = f.data;
+        const size_t n = f.size;
+        auto need = [&](size_t p, size_t k) {
+            if (p > n || k > n - p) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "truncated BAM index");
+        };
+        need(0, 8);
+        if (memcmp(d, "BAI\1", 4) != 0) throw pmx_io::Error(PMX_IO_ERR_FORMAT, "not a BAM index (bad magic)");
+        const uint32_t n_ref = le32(d + 4);
+        if (n_ref != b->ref_names.size())
+            throw pmx_io::Error(PMX_IO_ERR_FORMAT, "BAM index lists a different number of references than the BAM header");
+        std::vector<pmx_bam::RefRange> idx(n_ref);
+        size_t p = 8;
+        auto le64 = [&](size_t q) { return (uint64_t)le32(d + q) | ((uint64_t)le32(d + q + 4) << 32); };
+        for (uint32_t r = 0; r < n_ref; r++) {
+            need(p, 4);
+            const uint32_t n_bin = le32(d + p);
+            p += 4;
+            uint64_t lo = UINT64_MAX, hi = 0;
+            bool pseudo = false;
+            for (uint32_t k = 0; k < n_bin; k++) {
+                need(p, 8);
+                const uint32_t bin = le32(d + p), n_chunk = le32(d + p + 4);
+                p += 8;
+                need(p, (size_t)n_chunk * 16);
+                if (bin == 37450 && n_chunk >= 1) {          // pseudo-bin: [ref_beg, ref_end) then the read counts
+                    idx[r].beg = le64(p);
+                    idx[r].end = le64(p + 8);
+                    pseudo = true;
+                } else {
+                    for (uint32_t c = 0; c < n_chunk; c++) {
+                        const uint64_t cb = le64(p + 16 * (size_t)c), ce = le64(p + 16 * (size_t)c + 8);
+                        if (cb < lo) lo = cb;
+                        if (ce > hi) hi = ce;
+                    }
+                }
+                p += (size_t)n_chunk * 16;
+            }
+            need(p, 4);
+            const uint32_t n_intv = le32(d + p);
+            p += 4;
+            need(p, (size_t)n_intv * 8);
+            p += (size_t)n_intv * 8;
+            if (pseudo) {
+                idx[r].has = idx[r].end > idx[r].beg;
+            } else if (hi > lo) {
+                idx[r].has = true;
+                idx[r].beg = lo;
+                idx[r].end = hi;
+            }
+        }
+        b->index.swap(idx);
+        b->have_index = true;
+    } catch (const pmx_io::Error &e) {
+        return pmx_io::fail(e.code, std::string(bai_path ? bai_path : "") + ": " + e.msg);
+    }
+    return PMX_IO_OK;
+}
+
+int pmx_bam_has_index(const pmx_bam *b) { return b && b->have_index ? 1 : 0; }
+
+int pmx_bam_fetch_ref(pmx_bam *b, int32_t ref_id)
+{
+    if (!b) return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_fetch_ref: NULL handle");
+    if (ref_id >= 0 && !b->have_index) return pmx_io::fail(PMX_IO_ERR_INVALID, "pmx_bam_fetch_ref: no index loaded");
+    if (ref_id < -1 || (ref_id >= 0 && (size_t)ref_id >= b->index.size()))
+        return pmx_io::fail(PMX_IO_ERR_NOTFOUND, "pmx_bam_fetch_ref: reference id out of range");
+    if (ref_id < 0 && b->pristine) return PMX_IO_OK;
+    b->pristine = false;
+    if (b->producer.joinable()) {     // retire the running pipeline
+        {
+            std::lock_guard<std::mutex> g(b->mu);
+            b->stop = true;
+        }
+        b->cv.notify_all();
+        b->producer.join();
+    }
+    b->queue.clear();
+    b->cur = Window();
+    b->w_cursor = 0;
+    b->stop = false;
+    b->err_code = 0;
+    b->err_msg.clear();
+    b->carry = 0;
+    b->buf.resize(0);
+    b->filter_set = false;
+    b->want_ref = ref_id;
+    if (ref_id < 0) {                 // back to one pass over the whole file
+        b->eof = false;
+        b->done = false;
+        b->next_off = (size_t)(b->data_beg >> 16);
+        b->skip = (size_t)(b->data_beg & 0xffffu);
+        b->stop_block = SIZE_MAX;
+        return PMX_IO_OK;
+    }
+    const pmx_bam::RefRange &rr = b->index[ref_id];
+    if (!rr.has) {                    // a reference without records
+        b->eof = true;
+        b->done = true;
+        return PMX_IO_OK;
+    }
+    b->eof = false;
+    b->done = false;
+    b->next_off = (size_t)(rr.beg >> 16);
+    b->skip = (size_t)(rr.beg & 0xffffu);
+    b->stop_block = (size_t)(rr.end >> 16);
+    if (b->next_off >= b->file.size)
+        return pmx_io::fail(PMX_IO_ERR_FORMAT, "pmx_bam_fetch_ref: the index points past the end of the file");
+    return PMX_IO_OK;
 }
 
 int pmx_bam_counters(const pmx_bam *b, uint64_t *records, uint64_t *kept, uint64_t *bytes_out, uint64_t *bytes_in)

@@ -104,9 +104,9 @@ def run_sharded(bam_path, max_shift: int, read_len: int, mapq_criteria: int, big
                 chrom2mappable_len=None, group=None):
     """BAM (+ BigWig) -> genome-wide result on every rank; chromosomes LPT-sharded over the ranks by length.
 
-    Every rank streams the BAM through the native reader and keeps its own chromosomes (decoding is ~30 M records/s
-    on 16 host threads, far below the cost of seeking per chromosome for the file sizes in question); the kernels
-    see only the rank's chromosomes; one object all-gather at the end, then the reference's aggregation
+    Every rank reads its own chromosomes through the .bai index when there is one (the reference requires it for
+    its multi-process mode, reader/bam.py:246-262), otherwise it streams the whole BAM through the native reader
+    (~30 M records/s on 16 host threads) and keeps its share; the kernels see only the rank's chromosomes; one object all-gather at the end, then the reference's aggregation
     (result.py:301-464 -> pymasc_amd.result.aggregate_results)."""
     from .bam import BamReader, feed_bam
     from .bigwig import BigWigReader

@@ -43,7 +43,7 @@ def main():
         for r in rows:
             out.write("\t".join(str(x) for x in r) + "\n")
     for rel in ["data/hg19_36mer-test.bedGraph", "data/hg19_36mer-test_mappability.json",
-                "data/ENCFF000RMB-test.bam", "data/hg19_36mer-test.bigwig",
+                "data/ENCFF000RMB-test.bam", "data/ENCFF000RMB-test.bam.bai", "data/hg19_36mer-test.bigwig",
                 "golden/ENCFF000RMB-test_cc.tab", "golden/ENCFF000RMB-test_mscc.tab",
                 "golden/ENCFF000RMB-test_nreads.tab", "golden/ENCFF000RMB-test_stats.tab"]:
         shutil.copyfile(os.path.join(REF, rel), os.path.join(HERE, os.path.basename(rel)))

@@ -236,3 +236,44 @@ def write_bigwig(path, chromsizes, tracks, kind="bedgraph", compress=True, items
     assert len(header) == 64 and len(rt_hdr) == 48
     with open(path, "wb") as fp:
         fp.write(header + bpt + data + rt_hdr + rt + struct.pack("<I", 0x888FFC26))
+
+
+def write_bam_indexed(path, refs, records, rec_refs, block: int = 0xff00, level: int = 6, pseudo_bin: bool = True,
+                      text=None):
+    """write_bam + a .bai next to it.  rec_refs[i] = reference id of records[i] (coordinate-sorted, -1 last).
+
+    The index holds, per reference with records, one real bin (bin 0, a single chunk spanning all its records), the
+    linear index left empty, and optionally the samtools pseudo-bin 37450 {ref_beg, ref_end, n_mapped, n_unmapped}."""
+    head = bam_header(refs, text)
+    data = head + b"".join(records)
+    blocks = [bgzf_block(data[i:i + block], level) for i in range(0, len(data), block)]
+    coff = [0]
+    for b in blocks:
+        coff.append(coff[-1] + len(b))
+    with open(path, "wb") as fp:
+        fp.write(b"".join(blocks) + BGZF_EOF)
+
+    def voff(u):          # uncompressed offset -> virtual offset (a position at a block end belongs to the next block)
+        k, r = divmod(u, block)
+        return (coff[k] << 16) | r
+
+    u = len(head)
+    spans = {}
+    for rec, rid in zip(records, rec_refs):
+        if rid >= 0:
+            beg, _ = spans.get(rid, (u, u))
+            spans[rid] = (beg, u + len(rec))
+        u += len(rec)
+    out = [b"BAI\1", struct.pack("<i", len(refs))]
+    for rid in range(len(refs)):
+        if rid not in spans:
+            out.append(struct.pack("<ii", 0, 0))
+            continue
+        vb, ve = voff(spans[rid][0]), voff(spans[rid][1])
+        bins = [struct.pack("<Ii", 0, 1) + struct.pack("<QQ", vb, ve)]
+        if pseudo_bin:
+            n = sum(1 for r in rec_refs if r == rid)
+            bins.append(struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", vb, ve, n, 0))
+        out.append(struct.pack("<i", len(bins)) + b"".join(bins) + struct.pack("<i", 0))
+    with open(str(path) + ".bai", "wb") as fp:
+        fp.write(b"".join(out))

@@ -317,3 +317,83 @@ def test_feed_bam_chromosome_filter_and_unsorted(tmp_path):
             calc = CCHipCalculator(50, 36, [n for n, _ in refs], [l for _, l in refs], context=FakeContext())
             with pytest.raises(ReadUnsortedError):
                 B.feed_bam(calc, bam, 0)
+
+
+# ---------------------------------------------------------------- BAM index -------------------------------------
+def test_reference_bam_index_fetch():
+    """tests/data/ENCFF000RMB-test.bam.bai (samtools index of the fixture BAM): fetch(chrom) == the chromosome's
+    reads of the full pass -- what a worker of the reference's -p mode reads (handler/worker.py:106-132)."""
+    with B.BamReader(BAM) as r:
+        assert r.has_index()
+        assert _all_fetch(r, "chr1", 10) == fx.load_reads(10)
+        assert _all_fetch(r, "chr2", 10) == [] and _all_fetch(r, "chrM", 0) == []
+        assert _all_fetch(r, "chr1", 0) == fx.load_reads(0)             # the filter may change between fetches
+        assert _all_reads(r, 10) == fx.load_reads(10)                     # and a plain pass still starts at the top
+        with pytest.raises(KeyError):
+            r.fetch("chrNope")
+    with B.BamReader(BAM, index=False) as r:
+        assert not r.has_index()
+        with pytest.raises(ValueError):
+            r.fetch("chr1")
+
+
+def _all_fetch(reader, name, mapq, **kw):
+    out = []
+    for ref, pos, rl, rev in reader.fetch(name, mapq, **kw):
+        out += [(bool(v), reader.references[a], int(p), int(l)) for a, p, l, v in zip(ref, pos, rl, rev)]
+    return out
+
+
+@pytest.mark.parametrize("block,pseudo", [(0xff00, True), (300, True), (300, False), (61, False)])
+def test_synthetic_index_fetch(tmp_path, block, pseudo):
+    rng = np.random.default_rng(block + pseudo)
+    refs = [("c1", 60000), ("c2", 5000), ("c3", 90000), ("c4", 70000), ("c5", 20000)]
+    recs, meta = W.synth_bam_records(rng, [refs[0], refs[2], refs[3]], 500)     # c2, c5: no reads
+    ids = [0, 2, 3]
+    rec_refs = [ids[int(m)] for m in meta[:, 0]]
+    # re-stamp the reference ids in the records (synth numbered them 0..2)
+    import struct as st
+    recs = [r[:4] + st.pack("<i", rid) + r[8:] for r, rid in zip(recs, rec_refs)]
+    meta = meta.copy()
+    meta[:, 0] = rec_refs
+    unmapped = [W.bam_record(-1, -1, 0, 4, []) for _ in range(5)]
+    path = tmp_path / "i.bam"
+    W.write_bam_indexed(path, refs, recs + unmapped, rec_refs + [-1] * 5, block=block, pseudo_bin=pseudo)
+    exp_all = _expected(meta, refs, 5)
+    with B.BamReader(path, threads=3) as r:
+        assert r.has_index()
+        assert _all_reads(r, 5) == exp_all
+        for name in ("c4", "c1", "c2", "c3", "c5", "c1"):                    # any order, repeats, empty references
+            assert _all_fetch(r, name, 5, batch=97) == [e for e in exp_all if e[1] == name], name
+        assert _all_reads(r, 5) == exp_all
+    # the feeding loop takes the index path when only some chromosomes are wanted, with identical results
+    from .fake_context import FakeContext
+    from oracle import model as oracle
+    want = ["c1", "c4"]
+    lens = dict(refs)
+    results = []
+    for use_index in (True, False):
+        with B.BamReader(path) as bam:
+            calc = CCHipCalculator(40, 36, want, [lens[c] for c in want], context=FakeContext())
+            fed = B.feed_bam(calc, bam, 5, references=want, use_index=use_index)
+            assert fed == sum(1 for e in exp_all if e[1] in want)
+            results.append({c: calc.get_result(c).chrom.ccbins for c in want})
+    assert results[0] == results[1]
+
+
+def test_bad_index_is_reported(tmp_path):
+    import shutil
+    p = tmp_path / "x.bam"
+    shutil.copy(BAM, p)
+    (tmp_path / "x.bam.bai").write_bytes(b"BAI\\2" + b"\\0" * 20)
+    with pytest.raises(B.PmxIOError, match="magic"):
+        B.BamReader(p)
+    raw = open(BAM + ".bai", "rb").read()
+    (tmp_path / "x.bam.bai").write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(B.PmxIOError, match="truncated"):
+        B.BamReader(p)
+    refs = [("only", 1000)]
+    W.write_bam(tmp_path / "y.bam", refs, [])
+    shutil.copy(BAM + ".bai", tmp_path / "y.bam.bai")
+    with pytest.raises(B.PmxIOError, match="different number of references"):
+        B.BamReader(tmp_path / "y.bam")
