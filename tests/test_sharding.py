@@ -104,9 +104,11 @@ def _write_inputs(tmp):
     from tests import io_writers as W
     rng = np.random.default_rng(77)
     refs = [("c1", 40000), ("c2", 25000), ("c3", 31000), ("c4", 9000), ("c5", 18000)]
-    recs, _meta = W.synth_bam_records(rng, refs[:4], 900)          # c5 has no reads
+    recs, meta = W.synth_bam_records(rng, refs[:4], 900)           # c5 has no reads
     bam = os.path.join(tmp, "s.bam")
-    W.write_bam(bam, refs, recs, block=3000)
+    # indexed: a rank that owns a subset of the chromosomes reads them through the .bai, the single-process run
+    # (all chromosomes) takes one pass over the file -- both must agree
+    W.write_bam_indexed(bam, refs, recs, [int(x) for x in meta[:, 0]], block=3000)
     tracks = {}
     for name, size in refs[:3] + refs[4:]:                           # c4 has no mappability track
         iv, p = [], int(rng.integers(0, 40))
