@@ -97,6 +97,7 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
 
 int pmx_ctx_sync(pmx_ctx *ctx)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx, "pmx_ctx_sync: ctx is NULL");
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
@@ -128,6 +129,7 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
 
 int pmx_ensure_scratch(pmx_ctx *ctx, size_t words)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     if (ctx->scratch_words >= words) return PMX_OK;
     if (ctx->d_scratch) {
         PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -143,6 +145,7 @@ int pmx_ensure_scratch(pmx_ctx *ctx, size_t words)
 
 int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     if (ctx->slab_words >= u32_words) return PMX_OK;
     if (ctx->d_slab) {
         PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -256,6 +259,7 @@ int pmx_ctx_reset_kernel_times(pmx_ctx *ctx)
 
 int pmx_ctx_kernel_time(pmx_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx, "pmx_ctx_kernel_time: ctx is NULL");
     REQUIRE(kernel_id >= 0 && kernel_id < PMX_KERNEL_COUNT_, "pmx_ctx_kernel_time: bad kernel_id");
     int rc = fold_timed(ctx);
@@ -306,6 +310,7 @@ int pmx_bits_alloc(pmx_ctx *ctx, uint64_t nbits, uint64_t **d_words)
 
 int pmx_bits_free(pmx_ctx *ctx, uint64_t *d_words)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx, "pmx_bits_free: ctx is NULL");
     if (!d_words) return PMX_OK;
     PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -315,6 +320,7 @@ int pmx_bits_free(pmx_ctx *ctx, uint64_t *d_words)
 
 int pmx_bits_clear(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words, "pmx_bits_clear: NULL argument");
     PMX_HIP(hipMemsetAsync(d_words, 0, words_for(nbits) * sizeof(uint64_t), ctx->stream));
     return PMX_OK;
@@ -322,6 +328,7 @@ int pmx_bits_clear(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits)
 
 int pmx_bits_upload(pmx_ctx *ctx, uint64_t *d_words, const uint64_t *h_words, uint64_t nbits)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && h_words, "pmx_bits_upload: NULL argument");
     PMX_HIP(hipMemcpyAsync(d_words, h_words, words_for(nbits) * sizeof(uint64_t), hipMemcpyHostToDevice,
                            ctx->stream));
@@ -331,6 +338,7 @@ int pmx_bits_upload(pmx_ctx *ctx, uint64_t *d_words, const uint64_t *h_words, ui
 
 int pmx_bits_download(pmx_ctx *ctx, const uint64_t *d_words, uint64_t *h_words, uint64_t nbits)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && h_words, "pmx_bits_download: NULL argument");
     PMX_HIP(hipMemcpyAsync(h_words, d_words, words_for(nbits) * sizeof(uint64_t), hipMemcpyDeviceToHost,
                            ctx->stream));
@@ -340,12 +348,14 @@ int pmx_bits_download(pmx_ctx *ctx, const uint64_t *d_words, uint64_t *h_words, 
 
 int pmx_bits_set_positions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_pos, uint64_t n)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && (d_pos || n == 0), "pmx_bits_set_positions_dev: NULL argument");
     return pmx_launch_set_positions(ctx, d_words, nbits, d_pos, n);
 }
 
 int pmx_bits_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *h_pos, uint64_t n)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && (h_pos || n == 0), "pmx_bits_set_positions: NULL argument");
     if (n == 0) return PMX_OK;
     for (uint64_t i = 0; i < n; i++)
@@ -366,6 +376,7 @@ int pmx_bits_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, cons
 int pmx_bits_set_regions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_from,
                              const int64_t *d_to, uint64_t n)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && ((d_from && d_to) || n == 0), "pmx_bits_set_regions_dev: NULL argument");
     return pmx_launch_set_regions(ctx, d_words, nbits, d_from, d_to, n);
 }
@@ -373,6 +384,7 @@ int pmx_bits_set_regions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, co
 int pmx_bits_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *h_from,
                          const int64_t *h_to, uint64_t n)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && ((h_from && h_to) || n == 0), "pmx_bits_set_regions: NULL argument");
     if (n == 0) return PMX_OK;
     for (uint64_t i = 0; i < n; i++) {
@@ -399,6 +411,7 @@ int pmx_bits_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const 
 
 int pmx_bits_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, uint64_t *h_count)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && h_count, "pmx_bits_count: NULL argument");
     int rc = pmx_ensure_scratch(ctx, 4096);
     if (rc) return rc;
@@ -430,6 +443,7 @@ static int check_shift_args(uint64_t nbits, uint32_t max_shift, const char *who)
 int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_shift, uint32_t flags,
                          uint64_t *d_out)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_M && d_out, "pmx_mappable_len_dev: NULL argument");
     int rc = check_shift_args(nbits, max_shift, "pmx_mappable_len_dev");
     if (rc) return rc;
@@ -480,6 +494,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
                      const uint64_t *const *d_M, const uint64_t *nbits, uint32_t max_shift, uint32_t read_len,
                      uint32_t flags, uint64_t *const *d_out)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_F && d_R && nbits && d_out, "pmx_cc_batch_dev: NULL argument");
     REQUIRE(read_len >= 1 && read_len <= 65535, "pmx_cc_batch_dev: read_len must be in [1, 65535]");
     REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
@@ -553,6 +568,7 @@ int pmx_cc_dev(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uin
 int pmx_calc_correlation(pmx_ctx *ctx, const uint64_t *h_F, const uint64_t *h_R, const uint64_t *h_M,
                          uint64_t nbits, uint32_t max_shift, uint32_t read_len, uint32_t flags, uint64_t *h_out)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && h_F && h_R && h_out, "pmx_calc_correlation: NULL argument");
     int rc = check_shift_args(nbits, max_shift, "pmx_calc_correlation");
     if (rc) return rc;
@@ -578,6 +594,7 @@ int pmx_calc_correlation(pmx_ctx *ctx, const uint64_t *h_F, const uint64_t *h_R,
 int pmx_mappable_len(pmx_ctx *ctx, const uint64_t *h_M, uint64_t nbits, uint32_t max_shift, uint32_t flags,
                      uint64_t *h_out)
 {
+    if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && h_M && h_out, "pmx_mappable_len: NULL argument");
     int rc = check_shift_args(nbits, max_shift, "pmx_mappable_len");
     if (rc) return rc;
