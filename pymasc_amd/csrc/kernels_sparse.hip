@@ -404,7 +404,8 @@ __device__ __forceinline__ u32 emit_reserve(const uint4 w, u32 *cursor)
 
 // Stage 1 of the compaction (phase A, divergent loops, so the body is kept minimal): position of every set bit,
 // with one flag bit (forward read mappable / falling edge), into an LDS list.
-__device__ __forceinline__ void emit_positions(const uint4 w, const uint4 flag_bits, u32 idx0, u32 round_lo, u32 *list, u32 tid)
+__device__ __forceinline__ void emit_positions(const uint4 w, const uint4 flag_bits, u32 idx0, u32 round_lo, u32 *list, u32 tid,
+                                               u32 base = 0)
 {
     u32 id = idx0 - round_lo;   // unsigned: entries before the round wrap to huge values
     const u32 ws[4] = {w.x, w.y, w.z, w.w};
@@ -415,7 +416,7 @@ __device__ __forceinline__ void emit_positions(const uint4 w, const uint4 flag_b
         while (ww) {
             const u32 b = __builtin_ctz(ww);
             ww &= ww - 1;
-            if (id < SP_CAP) list[id] = (128u * tid + 32u * k + b) | (((fs[k] >> b) & 1u) << 16);
+            if (id < SP_CAP) list[id] = (base + 128u * tid + 32u * k + b) | (((fs[k] >> b) & 1u) << 16);
             id++;
         }
     }
@@ -788,7 +789,12 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
 //     EE(k) = [U*U + D*D](k) - [U*D + D*U](k) = P(k) - N(k)
 // are window sums driven by the edges only (two edges per mappable run), computed with the same set-bit
 // machinery as k_cc_sparse.  k_autocorr_finish runs the integer recurrence.
-#define AC_W (SP_TBW + SP_RHI)       // dwords of U / D per tile
+#ifndef AC_NQ
+#define AC_NQ 2                      // driver quads per thread: the autocorrelation tile is AC_NQ x 32 Kbit (the pass is all
+#endif                               // per-tile overhead on sparse-edge tracks, so its tile is larger than k_cc_sparse's)
+#define AC_TBW (AC_NQ * SP_TBW)      // dwords per autocorrelation tile
+#define AC_TB (AC_NQ * SP_TB)
+#define AC_W (AC_TBW + SP_RHI)       // dwords of U / D per tile
 struct AcLds {
     static constexpr u32 ZERO = 0;
     static constexpr u32 U = 40;
@@ -806,27 +812,31 @@ struct AcLds {
 #endif
 
 struct AcRegs {
-    uint4 m, h;    // driver quad (unshifted) + (threads 0..8) the quad above the WINDOW tile
-    u32 below;     // dword just below the driver quad (for M[j-1])
+    uint4 m[AC_NQ], h;   // driver quads (unshifted; quad q covers dwords q*1024 + 4 tid ..) + (threads 0..8) the quad
+                         // above the WINDOW tile
+    u32 below[AC_NQ];    // dword just below each driver quad (for M[j-1])
     u32 hbelow;
-    uint4 mw;      // lag chunks > 0 only: main quad of the window tile, staged from +off dwords
-    u32 wbelow;
+    uint4 mw[AC_NQ];     // lag chunks > 0 only: main quads of the window tile, staged from +off dwords
+    u32 wbelow[AC_NQ];
 };
 
 template <bool GUARD, bool CH>
 __device__ __forceinline__ void ac_fetch(AcRegs &ar, const u32 *__restrict__ M, int64_t d0, int64_t off, uint64_t nbits, u32 tid)
 {
-    const int64_t j = d0 + 4 * (int64_t)tid;
-    ar.m = ld_quad<GUARD>(M, j, nbits);
-    ar.below = GUARD ? ld_dword_guarded(M, j - 1, nbits) : M[j - 1];
-    if (CH) {
-        ar.mw = ld_quad<GUARD>(M, j + off, nbits);
-        ar.wbelow = GUARD ? ld_dword_guarded(M, j + off - 1, nbits) : M[j + off - 1];
+#pragma unroll
+    for (int q = 0; q < AC_NQ; q++) {
+        const int64_t j = d0 + (int64_t)q * SP_TBW + 4 * (int64_t)tid;
+        ar.m[q] = ld_quad<GUARD>(M, j, nbits);
+        ar.below[q] = GUARD ? ld_dword_guarded(M, j - 1, nbits) : M[j - 1];
+        if (CH) {
+            ar.mw[q] = ld_quad<GUARD>(M, j + off, nbits);
+            ar.wbelow[q] = GUARD ? ld_dword_guarded(M, j + off - 1, nbits) : M[j + off - 1];
+        }
     }
     ar.h = make_uint4(0, 0, 0, 0);
     ar.hbelow = 0;
     if (tid < 9) {
-        const int64_t jh = d0 + off + SP_TBW + 4 * (int64_t)tid;
+        const int64_t jh = d0 + off + AC_TBW + 4 * (int64_t)tid;
         ar.h = ld_quad<GUARD>(M, jh, nbits);
         ar.hbelow = GUARD ? ld_dword_guarded(M, jh - 1, nbits) : M[jh - 1];
     }
@@ -835,9 +845,9 @@ __device__ __forceinline__ void ac_fetch(AcRegs &ar, const u32 *__restrict__ M, 
 template <bool CH>
 __device__ __forceinline__ void ac_fetch_job(AcRegs &ar, const SpJobDev &jb, u32 local_tile, u32 tid)
 {
-    const int64_t d0 = (int64_t)local_tile * SP_TBW;
+    const int64_t d0 = (int64_t)local_tile * AC_TBW;
     const int64_t off = CH ? (int64_t)(jb.d_off / 32) : 0;
-    const uint64_t hi = (uint64_t)(d0 + off) + SP_TBW + SP_RHI;
+    const uint64_t hi = (uint64_t)(d0 + off) + AC_TBW + SP_RHI;
     const bool interior = jb.aligned16 && local_tile > 0 && hi + 2 <= jb.nbits / 32;
     if (interior)
         ac_fetch<false, CH>(ar, jb.M, d0, off, jb.nbits, tid);
@@ -863,7 +873,7 @@ __device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 fi
         uint4 rec = make_uint4(0u, AcLds::ZERO * 4u, AcLds::ZERO * 4u, 0u);
         if (first + j < n) {
             const u32 e = pl[first + j];
-            const u32 pos = e & 0x7fffu;
+            const u32 pos = e & 0xffffu;
             const u32 au = (AcLds::U + (pos >> 5)) * 4u, ad = (AcLds::D + (pos >> 5)) * 4u;
             const bool fall = (e >> 16) != 0;
             rec = make_uint4(pos, fall ? ad : au, fall ? au : ad, 0u);
@@ -918,28 +928,44 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
         __syncthreads();   // B0: everyone is done with the previous tile's (round's) LDS
         if (have_tile && round_lo == 0) {
             // phase A: edges from the prefetched registers -> LDS tiles and records
-            uint4 U, D;
-            edge_quad(ar.m, ar.below, U, D);   // the drivers: edges inside this tile
-            if (CH) {                          // the windows start d_off bits above
-                uint4 Uw, Dw;
-                edge_quad(ar.mw, ar.wbelow, Uw, Dw);
-                reinterpret_cast<uint4 *>(lds + L::U)[tid] = Uw;
-                reinterpret_cast<uint4 *>(lds + L::D)[tid] = Dw;
-            } else {
-                reinterpret_cast<uint4 *>(lds + L::U)[tid] = U;
-                reinterpret_cast<uint4 *>(lds + L::D)[tid] = D;
+            uint4 E[AC_NQ], Dq[AC_NQ];
+            pendM = 0;
+            pendU = 0;
+            u32 nE = 0;
+#pragma unroll
+            for (int q = 0; q < AC_NQ; q++) {
+                uint4 U, D;
+                edge_quad(ar.m[q], ar.below[q], U, D);   // the drivers: edges inside this tile
+                if (CH) {                                // the windows start d_off bits above
+                    uint4 Uw, Dw;
+                    edge_quad(ar.mw[q], ar.wbelow[q], Uw, Dw);
+                    reinterpret_cast<uint4 *>(lds + L::U + q * SP_TBW)[tid] = Uw;
+                    reinterpret_cast<uint4 *>(lds + L::D + q * SP_TBW)[tid] = Dw;
+                } else {
+                    reinterpret_cast<uint4 *>(lds + L::U + q * SP_TBW)[tid] = U;
+                    reinterpret_cast<uint4 *>(lds + L::D + q * SP_TBW)[tid] = D;
+                }
+                E[q] = make_uint4(U.x | D.x, U.y | D.y, U.z | D.z, U.w | D.w);
+                Dq[q] = D;
+                pendM += __popc(ar.m[q].x) + __popc(ar.m[q].y) + __popc(ar.m[q].z) + __popc(ar.m[q].w);
+                pendU += __popc(U.x) + __popc(U.y) + __popc(U.z) + __popc(U.w);
+                nE += __popc(E[q].x) + __popc(E[q].y) + __popc(E[q].z) + __popc(E[q].w);
             }
-            const uint4 E = make_uint4(U.x | D.x, U.y | D.y, U.z | D.z, U.w | D.w);
-            pendM = __popc(ar.m.x) + __popc(ar.m.y) + __popc(ar.m.z) + __popc(ar.m.w);
-            pendU = __popc(U.x) + __popc(U.y) + __popc(U.z) + __popc(U.w);
             if (tid < 9) {
                 uint4 Uh, Dh;
                 edge_quad(ar.h, ar.hbelow, Uh, Dh);
-                reinterpret_cast<uint4 *>(lds + L::U + SP_TBW)[tid] = Uh;
-                reinterpret_cast<uint4 *>(lds + L::D + SP_TBW)[tid] = Dh;
+                reinterpret_cast<uint4 *>(lds + L::U + AC_TBW)[tid] = Uh;
+                reinterpret_cast<uint4 *>(lds + L::D + AC_TBW)[tid] = Dh;
             }
-            i0 = emit_reserve(E, &cursor[par]);
-            emit_positions(E, D, i0, 0, lds + L::PL, tid);   // flag = falling edge
+            i0 = nE ? atomicAdd(&cursor[par], nE) : 0u;
+            {
+                u32 at = i0;
+#pragma unroll
+                for (int q = 0; q < AC_NQ; q++) {   // flag = falling edge
+                    emit_positions(E[q], Dq[q], at, 0, lds + L::PL, tid, q * SP_TB);
+                    at += __popc(E[q].x) + __popc(E[q].y) + __popc(E[q].z) + __popc(E[q].w);
+                }
+            }
             if (tid == 0) cursor[par ^ 1] = 0;
             jn = ji;
             if (g + 1 < g1) {
@@ -952,10 +978,16 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
         } else if (have_tile) {
             // rare: more than SP_CAP edges in one tile -> recompute its edge words, emit the next round
             AcRegs cur;
-            ac_fetch<true, false>(cur, jobs.j[ji].M, (int64_t)(g - jobs.j[ji].tile0) * SP_TBW, 0, jobs.j[ji].nbits, tid);
-            uint4 U2, D2;
-            edge_quad(cur.m, cur.below, U2, D2);
-            emit_positions(make_uint4(U2.x | D2.x, U2.y | D2.y, U2.z | D2.z, U2.w | D2.w), D2, i0, round_lo, lds + L::PL, tid);
+            ac_fetch<true, false>(cur, jobs.j[ji].M, (int64_t)(g - jobs.j[ji].tile0) * AC_TBW, 0, jobs.j[ji].nbits, tid);
+            u32 at = i0;
+#pragma unroll
+            for (int q = 0; q < AC_NQ; q++) {
+                uint4 U2, D2;
+                edge_quad(cur.m[q], cur.below[q], U2, D2);
+                const uint4 E2 = make_uint4(U2.x | D2.x, U2.y | D2.y, U2.z | D2.z, U2.w | D2.w);
+                emit_positions(E2, D2, at, round_lo, lds + L::PL, tid, q * SP_TB);
+                at += __popc(E2.x) + __popc(E2.y) + __popc(E2.z) + __popc(E2.w);
+            }
             __syncthreads();
         }
         u32 nr = 0;
@@ -1134,7 +1166,8 @@ static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr,
         SpJobDev &d = tab->j[i];
         const pmx_job &jb = *vj[i].job;
         const uint64_t bits = jb.nbits + (autocorr ? 1 : 0);   // edges live on [0, nbits]
-        uint64_t nt = (bits + SP_TB - 1) / SP_TB;
+        const uint64_t tile_bits = autocorr ? AC_TB : SP_TB;
+        uint64_t nt = (bits + tile_bits - 1) / tile_bits;
         if (nt < 1) nt = 1;
         d.F = (const u32 *)jb.d_F;
         d.R = (const u32 *)jb.d_R;
