@@ -498,8 +498,12 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 #ifndef SP_WAVES
 #define SP_WAVES 3
 #endif
+#ifndef SP_WAVES_NCC
+#define SP_WAVES_NCC 6             // waves per SIMD of the NCC-only instantiation (1 counter; measured 4: 0.334, 5: 0.309,
+                                   // 6: 0.300, 7: 0.311, 8: 0.473 ms on the benchmark genome)
+#endif
 template <bool HAS_M, bool DO_NCC, bool CH>
-__global__ void __launch_bounds__(256, CH ? 2 : SP_WAVES)
+__global__ void __launch_bounds__(256, CH ? 2 : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
 k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
             u32 *__restrict__ slab)
 {
@@ -1251,7 +1255,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         SpJobTable tab;
         memset(&tab, 0, sizeof tab);
         uint32_t total, tpw, nwg;
-        plan_launch(ctx, &vjobs[lo], n, false, chunked ? 2 : (has_m ? SP_WAVES : 4), &tab, &total, &tpw, &nwg);
+        plan_launch(ctx, &vjobs[lo], n, false, chunked ? 2 : (has_m ? SP_WAVES : SP_WAVES_NCC), &tab, &total, &tpw, &nwg);
         int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 8 * 2 + 64);
         if (rc) return rc;
         pmx_timed_launch tl;
