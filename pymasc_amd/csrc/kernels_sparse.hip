@@ -498,12 +498,18 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 #ifndef SP_WAVES
 #define SP_WAVES 3
 #endif
+#ifndef SP_WAVES_CH
+#define SP_WAVES_CH 3              // shift-chunked instantiations (max_shift > 1023) with / without mappability; measured on
+#endif                             // config 5 (10 Gbp, max_shift 5000): 2 -> 3 waves 21.5 -> 16.9 ms; NCC-only 2: 9.05,
+#ifndef SP_WAVES_CH_NCC            // 4: 5.70, 5: 5.49, 6: 5.19, 7: 5.82 ms
+#define SP_WAVES_CH_NCC 6
+#endif
 #ifndef SP_WAVES_NCC
 #define SP_WAVES_NCC 6             // waves per SIMD of the NCC-only instantiation (1 counter; measured 4: 0.334, 5: 0.309,
                                    // 6: 0.300, 7: 0.311, 8: 0.473 ms on the benchmark genome)
 #endif
 template <bool HAS_M, bool DO_NCC, bool CH>
-__global__ void __launch_bounds__(256, CH ? 2 : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
+__global__ void __launch_bounds__(256, CH ? (HAS_M ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
 k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
             u32 *__restrict__ slab)
 {
@@ -814,6 +820,9 @@ struct AcLds {
 #ifndef AC_WAVES
 #define AC_WAVES 4
 #endif
+#ifndef AC_WAVES_CH
+#define AC_WAVES_CH 4                // lag-chunked instantiation (max lag > 1023)
+#endif
 
 struct AcRegs {
     uint4 m[AC_NQ], h;   // driver quads (unshifted; quad q covers dwords q*1024 + 4 tid ..) + (threads 0..8) the quad
@@ -887,7 +896,7 @@ __device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 fi
 }
 
 template <bool CH>
-__global__ void __launch_bounds__(256, AC_WAVES)
+__global__ void __launch_bounds__(256, CH ? AC_WAVES_CH : AC_WAVES)
 k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab)
 {
     typedef AcLds L;
@@ -1255,7 +1264,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         SpJobTable tab;
         memset(&tab, 0, sizeof tab);
         uint32_t total, tpw, nwg;
-        plan_launch(ctx, &vjobs[lo], n, false, chunked ? 2 : (has_m ? SP_WAVES : SP_WAVES_NCC), &tab, &total, &tpw, &nwg);
+        plan_launch(ctx, &vjobs[lo], n, false, chunked ? (has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (has_m ? SP_WAVES : SP_WAVES_NCC), &tab, &total, &tpw, &nwg);
         int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 8 * 2 + 64);
         if (rc) return rc;
         pmx_timed_launch tl;
@@ -1318,7 +1327,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         SpJobTable tab;
         memset(&tab, 0, sizeof tab);
         uint32_t total, tpw, nwg;
-        plan_launch(ctx, &vjobs[lo], n, true, AC_WAVES, &tab, &total, &tpw, &nwg);
+        plan_launch(ctx, &vjobs[lo], n, true, chunked ? AC_WAVES_CH : AC_WAVES, &tab, &total, &tpw, &nwg);
         int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
         if (rc) return rc;
         pmx_timed_launch tl;
