@@ -1,9 +1,17 @@
 """Result payloads of the calculator boundary.
 
-Field-for-field value-equal to the reference's dataclasses (PyMaSC/result.py:68-118 per-chromosome,
-:121-126 BothChromResult, :144-257 empty placeholders, :260-298 genome-wide) so that the callers
-(PyMaSC/handler/calc.py:159-161, handler/worker.py:226-234, stats.py:424-451) can consume them
-unchanged; all are plain picklable dataclasses (they cross a multiprocessing.Queue, worker.py:234).
+Inside a PyMaSC installation (``import PyMaSC.result`` works) the names exported here ARE the reference's own
+classes -- ``PyMaSC.result.NCCResult / MSCCResult / BothChromResult / Empty* / *GenomeWideResult`` and its
+``aggregate_results`` -- because the reference's consumers dispatch on nominal types:
+``PyMaSC/stats.py:384-395,433,610-627`` (``isinstance(..., NCCResultModel / MSCCResultModel / Empty*Result /
+*GenomeWideResultModel)``), ``PyMaSC/handler/calc.py:218`` (``assert isinstance(obj, ChromResult)`` on what a
+worker reports) and ``PyMaSC/result.py:329-351`` (``aggregate_results``).  What ``CCHipCalculator`` returns is then
+exactly what ``CCBitArrayCalculator`` returns, type included (tests/test_reference_consumers.py).
+
+Stand-alone (no PyMaSC on the path, e.g. the GPU box) the same names are the dataclasses below: field-for-field
+value-equal to the reference's (PyMaSC/result.py:68-118 per chromosome, :121-126 BothChromResult, :144-257 empty
+placeholders, :260-298 genome-wide), plain and picklable (they cross a multiprocessing.Queue, worker.py:234).
+``REFERENCE_TYPES`` says which of the two is bound.
 
 The integer fields come from the GPU; ``calc_cc`` turns them into float64 on the host with the SAME
 operation order as PyMaSC/result.py:42-65 (binomial-variance normalisation), which is what holds the
@@ -197,3 +205,21 @@ def aggregate_results(results: Mapping[str, Any]) -> GenomeWideResult:
     if isinstance(first, MSCCResult):
         return _sum_mscc(results)
     raise TypeError(f"Unknown result type: {type(first)}")
+
+
+# ---- inside a PyMaSC installation: emit the reference's own types ------------------------------------------------
+REFERENCE_TYPES = False
+try:
+    import PyMaSC.result as _ref
+except Exception:          # stand-alone: the dataclasses above
+    _ref = None
+if _ref is not None:
+    _standalone = {k: v for k, v in globals().items() if isinstance(v, type) and v.__module__ == __name__}
+    NCCResult, MSCCResult, BothChromResult = _ref.NCCResult, _ref.MSCCResult, _ref.BothChromResult
+    EmptyResult, EmptyNCCResult, EmptyMSCCResult = _ref.EmptyResult, _ref.EmptyNCCResult, _ref.EmptyMSCCResult
+    EmptyBothChromResult = _ref.EmptyBothChromResult
+    NCCGenomeWideResult, MSCCGenomeWideResult = _ref.NCCGenomeWideResult, _ref.MSCCGenomeWideResult
+    BothGenomeWideResult = _ref.BothGenomeWideResult
+    GenomeWideResult = Union[NCCGenomeWideResult, MSCCGenomeWideResult, BothGenomeWideResult]
+    aggregate_results = _ref.aggregate_results
+    REFERENCE_TYPES = True
