@@ -6,12 +6,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (pmx_cc_dev per chromosome) over a batch of N synthetic
-samples x 24 hg38-length chromosomes whose F/R/M bit-vectors are already resident in HBM, the
-chromosome jobs LPT-sharded over the N ranks (one sample's worth of work per GPU: weak scaling),
-followed by the result exchange (all-gather of per-chromosome rows + all-reduce of totals over RCCL).
-Rank 0 prints ONE JSON line.  ENCFF000VPI.bam (BASELINE configs 2-3) is not available offline, so the
-same-shape synthetic workload stands in, as BASELINE.md section 4 prescribes.
+One "step" = one pass of the hot path (pmx_cc_batch_dev) over ONE synthetic hg38-shaped genome (24 chromosomes,
+3.09 Gbp) whose F/R/M bit-vectors are already resident in HBM, the chromosome jobs LPT-sharded over the N ranks
+(BASELINE config 4: "sharded 1/2/4/8 GPUs": strong scaling, the default; --scaling weak = N genomes, one per GPU),
+followed by the result exchange (all-gather of per-chromosome rows + all-reduce of totals over RCCL), which runs
+on its own HIP stream and overlaps the next step's kernels.  Rank 0 prints ONE JSON line.
+`python bench.py --gpus N` without a launcher starts the N ranks itself (pymasc_amd/launch.py: fresh child
+processes before anything touches the GPU -- what the reference's `-p N` does, handler/calc.py:163-192).
+ENCFF000VPI.bam (BASELINE configs 2-3) is not available offline, so the same-shape synthetic workload stands in,
+as BASELINE.md section 4 prescribes.
 """
 import argparse
 import json
@@ -35,6 +38,9 @@ def parse():
     ap.add_argument("--workload", choices=["hg38", "stress"], default="hg38",
                     help="hg38: BASELINE config 4 (default, the metric's configuration); stress: config 5, one "
                          "synthetic 10 Gbp / 200-chromosome genome sharded over the ranks, max_shift 5000")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="hg38 only: strong = ONE genome LPT-sharded over the ranks (BASELINE config 4, default); "
+                         "weak = one genome per rank")
     ap.add_argument("--max-shift", type=int, default=None, help="default 1000 (hg38) / 5000 (stress)")
     ap.add_argument("--read-len", type=int, default=None, help="default 36 (hg38) / 100 (stress, BASELINE config 5)")
     ap.add_argument("--density", type=float, default=0.005, help="read start density per strand (BASELINE.md config 4)")
@@ -45,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mbp", type=float, default=128.0, help="bp per CPU-baseline slice, in Mbp")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-positions -> rows leg (SURVEY 8d)")
     return ap.parse_args()
 
 
