@@ -87,15 +87,47 @@ def cpu_baseline(ctx, vecs, S, L, with_m, sample_bp, threads):
     s0 = slices[0]
     oracle.calc_correlation(s0[0], s0[1], s0[2], s0[3], S, L)
     dt1 = time.perf_counter() - t1
-    return {"value": work / dt, "unit": "shifts*bp/s", "cores": threads, "kind": "port",
+    return {"value": work / dt, "unit": "shifts*bp/s", "cores": threads, "kind": "port", "sampled": True,
+            "cpu_model": cpu_model(),
             "one_thread_value": (S + 1) * s0[4] / dt1,
-            "sample": f"{threads} slices x {slices[0][4] / 1e6:.1f} Mbp of the same synthetic chromosomes, "
+            "sample": f"SAMPLE, not the whole genome: {threads} slices x {slices[0][4] / 1e6:.1f} Mbp of the same synthetic chromosomes, "
                       f"{'NCC+MSCC' if with_m else 'NCC'}, max_shift={S}, one slice per thread, {dt:.1f}s wall",
             "seconds": dt}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def pipe_utilisation(kernel, default_workload):
+    """Measured VALU-issue / LDS-pipe utilisation of the dominant kernel from the committed PMC summary
+    (tools/tools_pmc_summary.py -> profiles/r2_pmc_summary.json: rocprofv3 --pmc passes of this same command).
+    Only valid for the workload it was collected on."""
+    if not default_workload:
+        return None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_summary.json")))
+        k = prof["kernels"][kernel]
+        return {"valu_issue": k["valu_issue_util"], "lds_pipe": k["lds_pipe_util"], "waves_per_simd": k.get("waves_per_simd"),
+                "source": "profiles/r2_pmc_summary.json (" + prof.get("how", "rocprofv3 --pmc") + ")"}
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
+    from pymasc_amd import launch
+    if launch.needs_spawn(args.gpus):
+        # `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything touches the GPU
+        # (fresh child processes, the reference's `-p N`: handler/calc.py:163-192); rank 0 prints the JSON line
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
     import torch
     import torch.distributed as dist
     from pymasc_amd import ffi, sharding, synth
@@ -121,6 +153,7 @@ def main():
             dist.init_process_group(backend)
 
     stress = args.workload == "stress"
+    strong = stress or args.scaling == "strong"
     if args.max_shift is None:
         args.max_shift = 5000 if stress else 1000
     if args.read_len is None:
@@ -128,47 +161,65 @@ def main():
     S, L = args.max_shift, args.read_len
     with_m = args.mode == "both"
     flags = {"auto": 0, "dense": ffi.PMX_FLAG_FORCE_DENSE, "sparse": ffi.PMX_FLAG_FORCE_SPARSE}[args.path]
-    # ONE stream for everything (vector builders, the hot-path kernels, torch's gather / RCCL collectives): steps queue
-    # back to back without host synchronisation between them; the HIP-event kernel timing is on this same stream
+    # Two streams: the vector builders and the hot-path kernels run on `tstream` (the context's stream, where the
+    # HIP-event kernel timing is taken); the result exchange (gather index ops / RCCL collectives) runs on `xstream`
+    # and overlaps the next step's kernels.  Steps queue back to back without host synchronisation between them.
     tstream = torch.cuda.Stream(device)
+    xstream = torch.cuda.Stream(device)
     torch.cuda.set_stream(tstream)
     ctx = ffi.Context(dev_index, stream=tstream.cuda_stream)
 
     chroms = synth.stress_genome() if stress else synth.HG38[:args.chroms]
-    # hg38: batch = `world` samples x chromosomes (weak scaling); stress: ONE genome over all ranks (strong scaling).
+    # strong: ONE genome LPT-sharded over all ranks (BASELINE configs 4 and 5); weak: `world` genomes, one per rank.
     # LPT over ranks (identical on every rank)
-    jobs = [(s, i) for s in range(1 if stress else world) for i in range(len(chroms))]
+    nsamples = 1 if strong else world
+    jobs = [(s, i) for s in range(nsamples) for i in range(len(chroms))]
     costs = [chroms[i][1] for (_s, i) in jobs]
     assignment = sharding.lpt_assign(costs, world)
     mine = assignment[rank]
     max_slots = max(len(a) for a in assignment)
 
+    e2e = not args.no_end_to_end
     t_gen = time.perf_counter()
     vecs = []
     for j in mine:
         s, i = jobs[j]
         name, length = chroms[i]
         vecs.append(synth.make_chromosome(ctx, device, f"{name}.s{s}", length, S, L, 0xC0FFEE + i + 1000 * s,
-                                          density=args.density, with_m=with_m))
+                                          density=args.density, with_m=with_m, keep_host=e2e))
     t_gen = time.perf_counter() - t_gen
-    local_bp = sum(v.length for v in vecs)
     total_bp = sum(costs)
 
     stride = S + 1
-    d_rows = torch.zeros((max_slots, ffi.PMX_NROWS, stride), dtype=torch.int64, device=device)
+    d_rows = [torch.zeros((max_slots, ffi.PMX_NROWS, stride), dtype=torch.int64, device=device) for _ in range(2)]
 
     pF = [v.F.data_ptr() for v in vecs]
     pR = [v.R.data_ptr() for v in vecs]
     pM = [v.M.data_ptr() for v in vecs] if with_m else None
     pN = [v.nbits for v in vecs]
-    pO = [d_rows[slot].data_ptr() for slot in range(len(vecs))]
+    pO = [[buf[slot].data_ptr() for slot in range(len(vecs))] for buf in d_rows]
+    ev_done = [torch.cuda.Event() for _ in range(2)]     # kernels of the step wrote d_rows[b]
+    ev_free = [torch.cuda.Event() for _ in range(2)]     # the exchange of the step has read d_rows[b]
+    nstep = [0]
 
     def step():
-        # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev), then the exchange
-        ctx.cc_batch_dev(pF, pR, pM, pN, S, L, flags, pO)
-        if world > 1 and backend != "nccl":
-            return sharding.exchange_results(d_rows.cpu(), assignment, len(jobs))
-        return sharding.exchange_results(d_rows, assignment, len(jobs))
+        # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev) on tstream, then the exchange
+        # on xstream (double-buffered result blocks)
+        b = nstep[0] & 1
+        if nstep[0] >= 2:
+            tstream.wait_event(ev_free[b])
+        nstep[0] += 1
+        if vecs:
+            ctx.cc_batch_dev(pF, pR, pM, pN, S, L, flags, pO[b])
+        ev_done[b].record(tstream)
+        with torch.cuda.stream(xstream):
+            xstream.wait_event(ev_done[b])
+            if world > 1 and backend != "nccl":
+                out = sharding.exchange_results(d_rows[b].cpu(), assignment, len(jobs))
+            else:
+                out = sharding.exchange_results(d_rows[b], assignment, len(jobs))
+            ev_free[b].record(xstream)
+        return out
 
     def fence():
         torch.cuda.synchronize(device)
@@ -212,30 +263,58 @@ def main():
     kernel_ms_per_step = {ctx.kernel_name(k): round(ktimes[k][0] / args.steps, 4) for k in ktimes if ktimes[k][1]}
 
     # HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
-    # rocprofv3 passes of this same command: tools_profile.sh -> profiles/r1_traffic.json); only valid for the
+    # rocprofv3 passes of this same command: tools_profile.sh -> profiles/r2_traffic.json); only valid for the
     # default single-GPU workload it was collected on
+    default_workload = (world == 1 and not stress and args.chroms == 24 and args.density == 0.005 and S == 1000
+                        and L == 36 and with_m and args.path == "auto")
     traffic, traffic_src = None, None
     try:
-        if world == 1 and not stress and args.chroms == 24 and args.density == 0.005 and S == 1000 and with_m:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        if default_workload:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
             key = {ffi.PMX_KERNEL_CC_SPARSE: "k_cc_sparse", ffi.PMX_KERNEL_AUTOCORR: "k_autocorr_edges"}.get(dom)
             if key:
                 traffic = prof["mode_both"][key]["hbm_bytes"]
-                traffic_src = "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                traffic_src = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     except Exception:
         traffic, traffic_src = None, None
 
     work_per_step = (S + 1) * total_bp
     value = work_per_step * args.steps / elapsed
 
-    # the bound that prices the DENSE formulation of the reference is integer VALU, not HBM:
-    # (S+1) * N/32 word-steps x (funnel shift + AND + popcount-accumulate = 3 lane-ops; MSCC: + 3 ANDs + 3 popcounts)
-    # against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.  The set-bit kernels skip the zero words those word-steps are
-    # counted on, so "achieved" may exceed the peak: it measures how much dense work the formulation avoids.
-    VALU_PEAK = 256 * 4 * 32 * 2.4e9
-    dense_lane_ops_per_step = (S + 1) * (sum(v.nbits for v in vecs) / 32.0) * (9 if with_m else 3)
-    kern_s_per_step = sum(t for t, _n in ktimes.values()) * 1e-3 / args.steps
-    valu_achieved = dense_lane_ops_per_step / kern_s_per_step if kern_s_per_step > 0 else 0.0
+    # ---- end to end: reads + intervals in HOST memory -> pmx_bits_set_positions / _regions (H2D + builder
+    # kernels) -> the same kernels -> rows back in host memory.  Never `value`; reported beside it.
+    end_to_end = None
+    if e2e:
+        def e2e_step():
+            for v in vecs:
+                ctx.bits_clear(v.F.data_ptr(), v.nbits)
+                ctx.bits_clear(v.R.data_ptr(), v.nbits)
+                ctx.bits_set_positions(v.F.data_ptr(), v.nbits, v.h_fpos)
+                ctx.bits_set_positions(v.R.data_ptr(), v.nbits, v.h_rpos)
+                if with_m:
+                    ctx.bits_clear(v.M.data_ptr(), v.nbits)
+                    ctx.bits_set_regions(v.M.data_ptr(), v.nbits, v.h_first, v.h_last)
+            rws, _tot = step()
+            xstream.synchronize()
+            return rws.cpu()
+        e2e_step()
+        fence()
+        n_e2e = 3
+        t1 = time.perf_counter()
+        for _ in range(n_e2e):
+            host_rows = e2e_step()
+        fence()
+        dt = (time.perf_counter() - t1) / n_e2e
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert torch.equal(host_rows, rows.cpu()), "end-to-end rows differ from the resident-vector rows"
+        h2d = sum(v.h_fpos.nbytes + v.h_rpos.nbytes + (v.h_first.nbytes + v.h_last.nbytes if with_m else 0) for v in vecs)
+        end_to_end = {"value": work_per_step / dt, "unit": "shifts*bp/s", "ms_per_step": dt * 1e3, "steps": n_e2e,
+                      "h2d_bytes_this_rank": h2d, "d2h_bytes": int(host_rows.numel() * 8),
+                      "what": "positions + intervals in host memory -> pmx_bits_set_positions/_regions (H2D copy + "
+                              "builder kernels) -> k_cc_sparse + k_autocorr -> exchange -> rows in host memory"}
 
     result = {
         "metric": "shifts*genome-bp/sec (whole node), hg38 max_shift=1000; HBM-BW fraction",
@@ -246,7 +325,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if stress else "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
@@ -254,14 +333,15 @@ def main():
             "workload": (("BASELINE config 5 (stress): synthetic 10 Gbp genome F/R" if stress else
                           "BASELINE config 4: synthetic hg38-shaped F/R")
                          + ("+mappability" if with_m else "") + f" bit-vectors, {len(chroms)} chromosomes x "
-                         f"{1 if stress else world} sample(s), {total_bp / 1e9:.3f} Gbp total, max_shift={S}, read_len={L}, "
+                         f"{nsamples} genome(s), {total_bp / 1e9:.3f} Gbp total, max_shift={S}, read_len={L}, "
                          f"read density {args.density}/strand, "
                          + ("NCC+MSCC" if with_m else "NCC only")
                          + ("" if stress else
                             "; stands in for ENCFF000VPI.bam (configs 2-3), which is not available offline")),
             "mode": args.mode,
             "kernel_path": args.path,
-            "parallelism": f"chromosome jobs LPT-sharded over {world} GPU(s); all-gather rows + all-reduce totals",
+            "parallelism": f"chromosome jobs of {nsamples} genome(s) LPT-sharded over {world} GPU(s), one process per "
+                           "GPU; all-gather rows + all-reduce totals on a second stream",
             "inputs_resident_in_hbm": True,
         },
         "roofline": {
@@ -277,14 +357,10 @@ def main():
             "launches": dom_n,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
         },
-        "roofline_valu": {
-            "bound": "valu", "achieved": valu_achieved, "peak": VALU_PEAK, "unit": "lane-ops/s",
-            "frac": valu_achieved / VALU_PEAK,
-            "note": "dense-algorithm lane-ops of this rank's vectors (SURVEY 8d: (S+1)*N/32 word-steps x "
-                    + ("9" if with_m else "3") + " ops) / summed kernel time; > 1 means the set-bit formulation does "
-                    "less work than the dense word-step count this bound prices",
-        },
+        "pipe_utilisation": pipe_utilisation(ctx.kernel_name(dom), default_workload),
         "kernel_ms_per_step": kernel_ms_per_step,
+        "value_end_to_end": end_to_end["value"] if end_to_end else None,
+        "end_to_end": end_to_end,
         "gen_seconds": round(t_gen, 2),
     }
 

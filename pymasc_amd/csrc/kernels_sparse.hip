@@ -63,11 +63,32 @@ struct SpJobDev {
     u32 d_off, d_n;        // first shift and number of shifts of this chunk
     u64 *out;              // result block of the job
     u64 *out2;             // autocorrelation: per-job scratch (P, N, scalars, A)
+    u32 flag0, pad_;       // autocorrelation: index of the job's first tile in the dense-tile flag array
 };
 
 struct SpJobTable {
     SpJobDev j[SP_MAXJOBS];
 };
+
+// The fields of the job whose tiles are being prefetched, held in (scalar) registers: the table lives in the kernel
+// argument segment, and indexing it per tile cost a chain of four dependent scalar loads (~0.5 us) in every tile.
+struct SpJobRegs {
+    const u32 *F, *R, *M;
+    u64 nbits;
+    u32 tile0, tile_end, aligned16, d_off;
+};
+
+__device__ __forceinline__ void load_job(SpJobRegs &r, const SpJobDev &j)
+{
+    r.F = j.F;
+    r.R = j.R;
+    r.M = j.M;
+    r.nbits = j.nbits;
+    r.tile0 = j.tile0;
+    r.tile_end = j.tile0 + j.ntiles;
+    r.aligned16 = j.aligned16;
+    r.d_off = j.d_off;
+}
 
 // ---- LDS layouts (dwords) ----------------------------------------------------------------------------------
 template <bool HAS_M>
@@ -314,7 +335,7 @@ __device__ __forceinline__ void tile_fetch(TileRegs &tr, TileRegsX &tx, const u3
 }
 
 template <bool HAS_M, bool CH>
-__device__ __forceinline__ void tile_fetch_job(TileRegs &tr, TileRegsX &tx, const SpJobDev &jb, u32 local_tile, u32 tid)
+__device__ __forceinline__ void tile_fetch_job(TileRegs &tr, TileRegsX &tx, const SpJobRegs &jb, u32 local_tile, u32 tid)
 {
     // edge tiles (or unaligned vectors) take the guarded loader
     const int64_t d0 = (int64_t)local_tile * SP_TBW;
@@ -481,7 +502,7 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 
 // ---- the cross-correlation kernel ---------------------------------------------------------------------------
 #ifdef SP_STAMPS   // diagnostic build: where does a tile's time go (never defined in the shipped library)
-#define SP_NSTAMP 8
+#define SP_NSTAMP 12
 #define SP_STAMP(i)                                                                                    \
     {                                                                                                  \
         unsigned long long t_;                                                                         \
@@ -545,13 +566,15 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
 
 #ifdef SP_STAMPS
-    unsigned long long stamp_acc[SP_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_acc[SP_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
     TileRegs tr;
     TileRegsX tx;
-    tile_fetch_job<HAS_M, CH>(tr, tx, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
+    SpJobRegs pj;   // job of the tile being prefetched (index jn)
+    load_job(pj, jobs.j[ji]);
+    tile_fetch_job<HAS_M, CH>(tr, tx, pj, g0 - pj.tile0, tid);
     if (tid < 4) cursor[tid] = 0;   // [2 par + 0] = F records, [2 par + 1] = R records; parity alternates per tile
     u32 par = 0;
     const u32 G = 1u << lgG;
@@ -575,18 +598,23 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             SP_STAMP(2)
             if (!HAS_M) pendR = __popc(tr.r.x) + __popc(tr.r.y) + __popc(tr.r.z) + __popc(tr.r.w);
             iF = emit_reserve(tr.f, &cursor[2 * par]);
+            SP_STAMP(8)
             if (HAS_M) iR = emit_reserve(tr.r, &cursor[2 * par + 1]);
+            SP_STAMP(9)
 #ifndef SP_ABL_NOEMIT
             emit_positions(tr.f, HAS_M ? tr.m : tr.f, iF, 0, lds + L::PLF, tid);
+            SP_STAMP(10)
             if (HAS_M) emit_positions(tr.r, tr.r, iR, 0, lds + L::PLR, tid);
 #endif
             if (tid < 2) cursor[2 * (par ^ 1) + tid] = 0;   // next tile's cursors (last read before B0)
             SP_STAMP(3)
             // fetch the next tile into the (now free) registers; consumed after the next tile's B0
-            jn = ji;
             if (g + 1 < g1) {
-                if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
-                tile_fetch_job<HAS_M, CH>(tr, tx, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
+                if (g + 1 >= pj.tile_end) {   // rare: the next tile belongs to the next job
+                    jn = ji + 1;
+                    load_job(pj, jobs.j[jn]);
+                }
+                tile_fetch_job<HAS_M, CH>(tr, tx, pj, g + 1 - pj.tile0, tid);
             }
             SP_STAMP(4)
             __syncthreads();   // B1: tile and records visible
@@ -744,13 +772,16 @@ struct ReduceSpec {
     u32 is_scalar[5];   // the scalar row: 2 sums, the rest of the row zero-filled, [3] = path marker; chunk 0 only
     u32 out_stride;
     u32 use_out2;       // autocorrelation: rows go to out2 (per-job scratch) instead of the result block
+    u32 accumulate;     // ... and are ADDED to what the pair pass left there
     u32 nzero;          // rows of the result block this batch does not produce: written as zeros (chunk 0 only)
     u32 zero_row[5];
 };
 
 __global__ void __launch_bounds__(256)
-k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_rows, ReduceSpec rs)
+k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_rows, ReduceSpec rs,
+                  const u32 *__restrict__ gate)
 {
+    const bool live = !gate || *gate != 0;   // gate == 0: the producing kernel did not run, every sum is zero
     // 32 consecutive elements x 8 workgroup phases per block: every load is a full 128-B line
     __shared__ u64 part[8][32];
     const u32 r = blockIdx.y, job = blockIdx.z;
@@ -768,7 +799,7 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
     if (scalar && !(jb.flags & 1u)) return;
     const u32 n = scalar ? 2u : jb.d_n;
     u64 sum = 0;
-    if (i < n) {
+    if (i < n && live) {
         const size_t stride = (size_t)seg_rows * 1024;
         const u32 *p = slab + (size_t)rs.src_row[r] * 1024 + i;
         for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 8) sum += p[(size_t)(w + job) * stride];
@@ -780,7 +811,10 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
 #pragma unroll
     for (u32 k = 0; k < 8; k++) t += part[k][e];
     if (rs.use_out2) {
-        if (i < n) jb.out2[(size_t)rs.dst_row[r] + (scalar ? 0u : jb.d_off) + i] = t;
+        if (i < n) {
+            u64 *dst = jb.out2 + (size_t)rs.dst_row[r] + (scalar ? 0u : jb.d_off) + i;
+            *dst = rs.accumulate ? *dst + t : t;
+        }
     } else if (scalar) {
         u64 *dst = jb.out + (size_t)rs.dst_row[r] * rs.out_stride;
         for (u32 k = i; k < rs.out_stride; k += gridDim.x * 32)   // [0],[1] sums, [3] path, everything else zero
@@ -855,9 +889,26 @@ __device__ __forceinline__ void ac_fetch(AcRegs &ar, const u32 *__restrict__ M, 
     }
 }
 
+// flags != null: only the tiles the pair kernel flagged as dense are processed; the others read as all-zero words
+// (no edges, no set bits: they contribute nothing) without touching memory
 template <bool CH>
-__device__ __forceinline__ void ac_fetch_job(AcRegs &ar, const SpJobDev &jb, u32 local_tile, u32 tid)
+__device__ __forceinline__ void ac_fetch_job(AcRegs &ar, const SpJobDev &jb, u32 local_tile, u32 tid,
+                                             const unsigned char *__restrict__ flags)
 {
+    if (flags && !flags[jb.flag0 + local_tile]) {
+#pragma unroll
+        for (int q = 0; q < AC_NQ; q++) {
+            ar.m[q] = make_uint4(0, 0, 0, 0);
+            ar.below[q] = 0;
+            if (CH) {
+                ar.mw[q] = make_uint4(0, 0, 0, 0);
+                ar.wbelow[q] = 0;
+            }
+        }
+        ar.h = make_uint4(0, 0, 0, 0);
+        ar.hbelow = 0;
+        return;
+    }
     const int64_t d0 = (int64_t)local_tile * AC_TBW;
     const int64_t off = CH ? (int64_t)(jb.d_off / 32) : 0;
     const uint64_t hi = (uint64_t)(d0 + off) + AC_TBW + SP_RHI;
@@ -897,9 +948,11 @@ __device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 fi
 
 template <bool CH>
 __global__ void __launch_bounds__(256, CH ? AC_WAVES_CH : AC_WAVES)
-k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab)
+k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab,
+                 const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged)
 {
     typedef AcLds L;
+    if (n_flagged && *n_flagged == 0) return;   // the pair kernel took every tile (uniform over the whole grid)
     __shared__ __align__(16) u32 lds[L::TOTAL];
     u32 *const cursor = lds + L::MISC;
     u32 *const acc = lds + L::ACC;
@@ -926,7 +979,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
 
     AcRegs ar;
-    ac_fetch_job<CH>(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid);
+    ac_fetch_job<CH>(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid, tile_flags);
     if (tid < 2) cursor[tid] = 0;   // record cursors, parity alternates per tile
     u32 par = 0;
     const u32 G = 1u << lgG;
@@ -983,7 +1036,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
             jn = ji;
             if (g + 1 < g1) {
                 if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
-                ac_fetch_job<CH>(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid);
+                ac_fetch_job<CH>(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid, tile_flags);
             }
             __syncthreads();   // B1: tiles and records visible
             n = cursor[par];
@@ -1079,6 +1132,295 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Sparse-edge tiles: PAIR enumeration instead of windows.  A mappability track with long runs has a few dozen
+// run edges per 64-Kbit tile; for those the window machinery above is all per-tile overhead (tiles of U / D in LDS,
+// records, bit-sliced counters for ~50 entries).  EE(k) = P(k) - N(k) is just a histogram over edge PAIRS:
+//     P(k) = #{(e1, e2): same sign, e2 - e1 = k},  N(k) likewise for opposite signs,  0 <= k <= max_lag
+// (k = 0 pairs every edge with itself).  Per tile: edge words from the prefetched registers -> positions into ONE LDS
+// list IN POSITION ORDER (block-wide scans of the per-thread edge counts; drivers = edges inside the tile, partners =
+// drivers + the edges of the next max_lag bits) -> for every driver the following entries until the distance exceeds
+// max_lag, one LDS atomic per hit, into histograms that live in LDS for the workgroup's whole tile range.
+// Nothing else is staged, so six workgroups fit a CU and the pass runs close to the rate M streams from HBM.
+// A tile with more than AP_CAP edges (dense-edge regions of real tracks) is NOT processed here: its flags are set and
+// k_autocorr_edges, launched behind this kernel over the same tiles, picks up exactly the flagged ones.
+#ifndef AP_NQ
+#define AP_NQ 4                      // driver quads per thread: a pair tile is AP_NQ x 32 Kbit = AP_NQ / AC_NQ window-kernel tiles
+#endif
+#define AP_TBW (AP_NQ * SP_TBW)
+#define AP_TB (AP_NQ * SP_TB)
+#define AP_CAP 256u                  // list capacity = dense-tile threshold (edges of one pair tile + the lags above it)
+#define AP_MAX_LAGS 8192u            // histograms of 2 x (max_lag + 1) u32 must fit in LDS beside the other workgroups' share
+#ifndef AP_WAVES
+#define AP_WAVES 5
+#endif
+
+struct ApRegs {
+    uint4 m[AP_NQ], h;   // driver quads (quad q covers dwords q*1024 + 4 tid ..) + (threads 0..nh-1) a quad above the tile
+    u32 below[AP_NQ], hbelow;
+};
+
+template <bool GUARD>
+__device__ __forceinline__ void ap_fetch(ApRegs &ar, const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid, u32 nh)
+{
+#pragma unroll
+    for (int q = 0; q < AP_NQ; q++) {
+        const int64_t j = d0 + (int64_t)q * SP_TBW + 4 * (int64_t)tid;
+        ar.m[q] = ld_quad<GUARD>(M, j, nbits);
+        ar.below[q] = GUARD ? ld_dword_guarded(M, j - 1, nbits) : M[j - 1];
+    }
+    ar.h = make_uint4(0, 0, 0, 0);
+    ar.hbelow = 0;
+    if (tid < nh) {
+        const int64_t jh = d0 + AP_TBW + 4 * (int64_t)tid;
+        ar.h = ld_quad<GUARD>(M, jh, nbits);
+        ar.hbelow = GUARD ? ld_dword_guarded(M, jh - 1, nbits) : M[jh - 1];
+    }
+}
+
+__device__ __forceinline__ void ap_fetch_job(ApRegs &ar, const SpJobDev &jb, u32 local_tile, u32 tid, u32 nh)
+{
+    const int64_t d0 = (int64_t)local_tile * AP_TBW;
+    const uint64_t hi = (uint64_t)d0 + AP_TBW + 4 * (uint64_t)nh;
+    const bool interior = jb.aligned16 && local_tile > 0 && hi + 2 <= jb.nbits / 32;
+    if (interior)
+        ap_fetch<false>(ar, jb.M, d0, jb.nbits, tid, nh);
+    else
+        ap_fetch<true>(ar, jb.M, d0, jb.nbits, tid, nh);
+}
+
+// edge word of each dword of a quad: bit i set iff M[i] != M[i-1] (`below` = the dword preceding m.x)
+__device__ __forceinline__ uint4 edge_words(const uint4 m, u32 below)
+{
+    return make_uint4(m.x ^ __builtin_amdgcn_alignbit(m.x, below, 31), m.y ^ __builtin_amdgcn_alignbit(m.y, m.x, 31),
+                      m.z ^ __builtin_amdgcn_alignbit(m.z, m.y, 31), m.w ^ __builtin_amdgcn_alignbit(m.w, m.z, 31));
+}
+
+__device__ __forceinline__ u32 popc4(const uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+
+// inclusive add-scan over the 64 lanes of a wave (DPP: four row shifts, two row broadcasts)
+__device__ __forceinline__ u32 wave_inclusive_scan(u32 v)
+{
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// list entry: bits 0..17 tile-relative position, bit 31 = falling edge (M is 0 at the edge position).  The four
+// edge words of a quad are walked as two 64-bit words: two loops per quad instead of four (on sparse-edge tiles
+// every loop costs its ~25 instructions of control flow whether or not one of the 64 lanes has a bit).
+__device__ __forceinline__ void ap_emit(const uint4 e, const uint4 m, u32 idx, u32 base_bit, u32 *list)
+{
+    const u64 es[2] = {(u64)e.x | ((u64)e.y << 32), (u64)e.z | ((u64)e.w << 32)};
+    const u64 ms[2] = {(u64)m.x | ((u64)m.y << 32), (u64)m.z | ((u64)m.w << 32)};
+#pragma unroll
+    for (u32 k = 0; k < 2; k++) {
+        u64 ww = es[k];
+        while (ww) {
+            const u32 b = (u32)__builtin_ctzll(ww);
+            ww &= ww - 1;
+            list[idx] = (base_bit + 64u * k + b) | ((u32)((~ms[k] >> b) & 1ull) << 31);
+            idx++;
+        }
+    }
+}
+
+// segment of a (workgroup, job) pair in the pair slab: [P: nl][N: nl][scalars: 16] u32
+__global__ void __launch_bounds__(256, AP_WAVES)
+k_autocorr_pairs(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 max_lag, u32 nl, u32 nh,
+                 u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags, u32 *__restrict__ n_flagged)
+{
+    extern __shared__ __align__(16) u32 ap_lds[];
+    u32 *const hP = ap_lds;                 // [nl]
+    u32 *const hN = ap_lds + nl;            // [nl]
+    u32 *const lists = hN + nl;             // [2][AP_CAP]: the tile's edges in POSITION order, parity alternates per tile
+    u32 *const wtot = lists + 2 * AP_CAP;   // [2][4 waves][4]: per-wave edge counts (rows 0|1, rows 2|3, above the tile)
+    u32 *const misc = wtot + 32;            // [0..7] scalar reduction when leaving a job
+
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 g0 = blockIdx.x * tiles_per_wg;
+    const u32 g1 = g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles;
+    if (g0 >= g1) return;
+    for (u32 i = tid; i < 2 * nl; i += 256) ap_lds[i] = 0;
+
+    u32 ji = 0;
+    while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
+    u32 jn = ji;
+    ApRegs ar;
+    ap_fetch_job(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid, nh);
+    const size_t seg_stride = 2 * (size_t)nl + 16;
+    u32 cntM = 0, cntU = 0, par = 0;
+    __syncthreads();
+
+    for (u32 g = g0; g < g1; g++) {
+        // ---- edge words of this tile (and of the max_lag bits above it) from the prefetched registers ----
+        uint4 E[AP_NQ], Eh;
+        u32 c[AP_NQ], pendM = 0, pendU = 0;
+#pragma unroll
+        for (int q = 0; q < AP_NQ; q++) {
+            E[q] = edge_words(ar.m[q], ar.below[q]);
+            c[q] = popc4(E[q]);
+            pendM += popc4(ar.m[q]);
+            // run starts = rising edges; rising - falling = M[last bit of the quad] - M[bit before it]
+            pendU += (c[q] + (ar.m[q].w >> 31) - (ar.below[q] >> 31)) >> 1;
+        }
+        Eh = edge_words(ar.h, ar.hbelow);   // zero registers (threads >= nh) give no edges
+        const u32 ch = popc4(Eh);
+        // ---- position order = (row q, thread, word, bit): exclusive offsets from three packed block scans ----
+        const u32 s01 = wave_inclusive_scan(c[0] | (c[1] << 16));   // a row holds <= 32768 edges: 16-bit fields do not carry
+        const u32 s23 = AP_NQ > 2 ? wave_inclusive_scan(c[AP_NQ > 2 ? 2 : 0] | (c[AP_NQ > 2 ? 3 : 0] << 16)) : 0u;
+        const u32 sh = wave_inclusive_scan(ch);
+        u32 *const wt = wtot + par * 16;
+        if (lane == 63) {
+            wt[wave * 4 + 0] = s01;
+            wt[wave * 4 + 1] = s23;
+            wt[wave * 4 + 2] = sh;
+        }
+        __syncthreads();   // Bs: per-wave totals visible (and every wave is done with the previous tile's pair search)
+        u32 b01 = 0, b23 = 0, bh = 0, t01 = 0, t23 = 0, th = 0;
+#pragma unroll
+        for (u32 w = 0; w < 4; w++) {
+            const u32 x01 = wt[w * 4 + 0], x23 = wt[w * 4 + 1], xh = wt[w * 4 + 2];
+            if (w < wave) {
+                b01 += x01;
+                b23 += x23;
+                bh += xh;
+            }
+            t01 += x01;
+            t23 += x23;
+            th += xh;
+        }
+        const u32 T0 = t01 & 0xffffu, T1 = t01 >> 16, T2 = AP_NQ > 2 ? t23 & 0xffffu : 0u, T3 = AP_NQ > 2 ? t23 >> 16 : 0u;
+        const u32 nd = __builtin_amdgcn_readfirstlane(T0 + T1 + T2 + T3);   // drivers: edges inside the tile
+        const u32 n = __builtin_amdgcn_readfirstlane(nd + th);             // + partners above it
+        const bool dense = n > AP_CAP;
+        u32 *const list = lists + par * AP_CAP;
+#ifdef AP_ABL_NOEMIT
+        if (max_lag == 0xffffffffu)
+#else
+        if (!dense)
+#endif
+        {
+            const u32 e01 = b01 + s01 - (c[0] | (c[1] << 16));   // exclusive, per row
+            ap_emit(E[0], ar.m[0], e01 & 0xffffu, 0 * SP_TB + 128u * tid, list);
+            ap_emit(E[1], ar.m[1], T0 + (e01 >> 16), 1 * SP_TB + 128u * tid, list);
+            if (AP_NQ > 2) {
+                const u32 e23 = b23 + s23 - (c[AP_NQ > 2 ? 2 : 0] | (c[AP_NQ > 2 ? 3 : 0] << 16));
+                ap_emit(E[AP_NQ > 2 ? 2 : 0], ar.m[AP_NQ > 2 ? 2 : 0], T0 + T1 + (e23 & 0xffffu), 2 * SP_TB + 128u * tid, list);
+                ap_emit(E[AP_NQ > 2 ? 3 : 0], ar.m[AP_NQ > 2 ? 3 : 0], T0 + T1 + T2 + (e23 >> 16), 3 * SP_TB + 128u * tid, list);
+            }
+            ap_emit(Eh, ar.h, nd + bh + sh - ch, AP_TB + 128u * tid, list);
+            cntM += pendM;
+            cntU += pendU;
+        } else if (tid == 0) {
+            // dense tile: left to the window kernel (which also counts its set bits and run starts): both of its tiles
+            const u32 f = jobs.j[ji].flag0 + (AP_NQ / AC_NQ) * (g - jobs.j[ji].tile0);
+            for (u32 i = 0; i < AP_NQ / AC_NQ; i++) tile_flags[f + i] = 1;   // (the flag array is padded per job)
+            atomicAdd(n_flagged, 1u);
+        }
+        // ---- prefetch the next tile into the (now free) registers ----
+        if (g + 1 < g1) {
+            if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
+            ap_fetch_job(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid, nh);
+        }
+        __syncthreads();   // B1: the list is complete
+        par ^= 1;
+#ifdef AP_ABL_NOPAIRS
+        if (max_lag == 0xffffffffu)
+#else
+        if (!dense)
+#endif
+        {
+            // ---- pairs: the list is sorted, so the partners of entry i are i, i+1, ... until the distance exceeds
+            // max_lag.  Wave w takes the offsets o = w, w+4, ...; lanes take the drivers; a wave stops at the first
+            // offset without a hit (larger offsets only increase every distance).
+            u32 pi[AP_CAP / 64];
+#pragma unroll
+            for (u32 h = 0; h < AP_CAP / 64; h++) pi[h] = lane + 64 * h < nd ? list[lane + 64 * h] : 0u;
+            for (u32 o = wave; o < n; o += 4) {
+                bool any = false;
+#pragma unroll
+                for (u32 h = 0; h < AP_CAP / 64; h++) {
+                    const u32 i = lane + 64 * h;
+                    if (64 * h < nd && i < nd && i + o < n) {
+                        const u32 ej = list[i + o];
+                        const u32 k = (ej & 0x3ffffu) - (pi[h] & 0x3ffffu);
+                        if (k <= max_lag) {
+                            atomicAdd(((pi[h] ^ ej) >> 31) ? &hN[k] : &hP[k], 1u);
+                            any = true;
+                        }
+                    }
+                }
+                if (!__builtin_amdgcn_readfirstlane(__ballot(any) != 0)) break;
+            }
+        }
+        const bool leaving = jn != ji || g + 1 == g1;
+        if (leaving) {
+            // histograms + scalars of this (workgroup, job) -> its slab segment; cleared for the next job
+            __syncthreads();
+            u32 *seg = slab + (size_t)(blockIdx.x + ji) * seg_stride;
+            for (u32 i = tid; i < 2 * nl; i += 256) {
+                seg[i] = ap_lds[i];
+                ap_lds[i] = 0;
+            }
+            u32 vm = cntM, vu = cntU;
+            for (int off = 32; off > 0; off >>= 1) {
+                vm += __shfl_down(vm, off, 64);
+                vu += __shfl_down(vu, off, 64);
+            }
+            if (lane == 0) {
+                misc[wave] = vm;
+                misc[4 + wave] = vu;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                seg[2 * nl + 0] = misc[0] + misc[1] + misc[2] + misc[3];   // popcount(M) of my (non-dense) tiles
+                seg[2 * nl + 1] = misc[4] + misc[5] + misc[6] + misc[7];   // runs starting in them
+            }
+            cntM = 0;
+            cntU = 0;
+            __syncthreads();
+        }
+        ji = jn;
+    }
+}
+
+// out2[row][i] (+)= sum over the workgroups that touched the job of their pair-slab segments (see k_reduce_segments):
+// 32 consecutive elements x 8 workgroup phases per block
+__global__ void __launch_bounds__(256)
+k_reduce_pairs(const u32 *__restrict__ slab, const SpJobTable jobs, u32 nl, u32 max_lag, u32 lagcap, u32 accumulate)
+{
+    __shared__ u64 part[8][32];
+    const u32 job = blockIdx.z, row = blockIdx.y;          // row 0: P, 1: N, 2: scalars
+    const SpJobDev &jb = jobs.j[job];
+    const u32 e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const u32 n = row == 2 ? 2u : max_lag + 1;
+    const size_t seg_stride = 2 * (size_t)nl + 16;
+    for (u32 i0 = blockIdx.x * 32; i0 < n; i0 += gridDim.x * 32) {   // uniform trip count over the block
+        const u32 i = i0 + e;
+        u64 sum = 0;
+        if (i < n) {
+            const u32 *p = slab + (row == 2 ? 2 * (size_t)nl : (size_t)row * nl) + i;
+            for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 8) sum += p[(size_t)(w + job) * seg_stride];
+        }
+        part[g][e] = sum;
+        __syncthreads();
+        if (g == 0 && i < n) {
+            u64 t = 0;
+#pragma unroll
+            for (u32 k = 0; k < 8; k++) t += part[k][e];
+            u64 *dst = jb.out2 + (row == 2 ? 2 * (size_t)lagcap : (size_t)row * lagcap) + i;
+            *dst = accumulate ? *dst + t : t;
+        }
+        __syncthreads();
+    }
+}
+
 // A(k) from EE(k) = P(k) - N(k), one block per chromosome.  A(k+1) = 2 A(k) - A(k-1) - EE(k) is a double prefix sum:
 // with Delta(k) = A(k+1) - A(k):  Delta(0) = -#runs, Delta(k) = Delta(k-1) - EE(k);  A(k) = A(0) + sum_{i<k} Delta(i).
 // Per-job scratch out2 (u64): P[lagcap], N[lagcap], scalars[16], A[lagcap].  All arithmetic in signed 64-bit.
@@ -1168,18 +1510,19 @@ uint32_t pmx_sparse_max_jobs(void) { return SP_MAXJOBS; }
 struct VJob {
     const pmx_job *job;
     u32 d_off, d_n;
+    u32 flag0;   // autocorrelation: index of the chromosome's first tile in the dense-tile flag array
 };
 
 // Cuts the global tile sequence of a launch into per-workgroup ranges and fills the device job table.
 static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr, uint32_t wg_per_cu, SpJobTable *tab,
-                        uint32_t *total_tiles, uint32_t *tiles_per_wg, uint32_t *nwg)
+                        uint32_t *total_tiles, uint32_t *tiles_per_wg, uint32_t *nwg, uint64_t autocorr_tile_bits = 0)
 {
     uint32_t t = 0;
     for (uint32_t i = 0; i < n; i++) {
         SpJobDev &d = tab->j[i];
         const pmx_job &jb = *vj[i].job;
         const uint64_t bits = jb.nbits + (autocorr ? 1 : 0);   // edges live on [0, nbits]
-        const uint64_t tile_bits = autocorr ? AC_TB : SP_TB;
+        const uint64_t tile_bits = autocorr ? (autocorr_tile_bits ? autocorr_tile_bits : AC_TB) : SP_TB;
         uint64_t nt = (bits + tile_bits - 1) / tile_bits;
         if (nt < 1) nt = 1;
         d.F = (const u32 *)jb.d_F;
@@ -1195,6 +1538,7 @@ static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr,
         d.d_n = vj[i].d_n;
         d.out = (u64 *)jb.d_out;
         d.out2 = (u64 *)jb.d_out2;
+        d.flag0 = vj[i].flag0;
         t += (u32)nt;
     }
     uint64_t want = (uint64_t)ctx->num_cus * wg_per_cu;
@@ -1213,7 +1557,8 @@ static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr,
 }
 
 // (chromosome x chunk-of-1024-shifts) jobs of a batch, in launches of at most SP_MAXJOBS
-static void expand_chunks(const pmx_job *jobs, uint32_t njobs, uint32_t nshifts, std::vector<VJob> &out)
+static void expand_chunks(const pmx_job *jobs, uint32_t njobs, uint32_t nshifts, std::vector<VJob> &out,
+                          const uint32_t *flag0 = nullptr)
 {
     for (uint32_t i = 0; i < njobs; i++)
         for (uint32_t off = 0; off < nshifts; off += 1024) {
@@ -1221,6 +1566,7 @@ static void expand_chunks(const pmx_job *jobs, uint32_t njobs, uint32_t nshifts,
             v.job = &jobs[i];
             v.d_off = off;
             v.d_n = nshifts - off < 1024 ? nshifts - off : 1024;
+            v.flag0 = flag0 ? flag0[i] : 0;
             out.push_back(v);
         }
 }
@@ -1265,7 +1611,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         memset(&tab, 0, sizeof tab);
         uint32_t total, tpw, nwg;
         plan_launch(ctx, &vjobs[lo], n, false, chunked ? (has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (has_m ? SP_WAVES : SP_WAVES_NCC), &tab, &total, &tpw, &nwg);
-        int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 8 * 2 + 64);
+        int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
         if (rc) return rc;
         pmx_timed_launch tl;
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl);
@@ -1288,7 +1634,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         if (rc) return rc;
         // sum the per-workgroup slab segments into the result blocks
         hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab,
-                           (u32)SP_SEG_ROWS, rs);
+                           (u32)SP_SEG_ROWS, rs, (const u32 *)nullptr);
         PMX_CHECK_LAUNCH("k_reduce_segments");
     }
     return PMX_OK;
@@ -1309,9 +1655,71 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
     if (njobs == 0) return PMX_OK;
     const bool chunked = max_lag > 1023;
     const u32 lagcap = (u32)(((size_t)max_lag + 1 + 1023) / 1024 * 1024);
-    std::vector<VJob> vjobs;
-    expand_chunks(jobs, njobs, max_lag + 1, vjobs);
     const u32 lgG = chunked ? 5u : lg_slot_lanes(max_lag + 1);
+
+    // Pass 1 (sparse-edge tiles): pair enumeration over every chromosome; tiles with more than AP_CAP edges are flagged.
+    // PMX_AUTOCORR_PAIRS=0 in the environment keeps everything on the window kernel (A/B measurements, tests).
+    static const bool pairs_enabled = [] {
+        const char *e = getenv("PMX_AUTOCORR_PAIRS");
+        return !(e && e[0] == '0');
+    }();
+    const bool use_pairs = pairs_enabled && max_lag + 1 <= AP_MAX_LAGS;
+    std::vector<uint32_t> flag0(njobs, 0);
+    unsigned char *d_flags = nullptr;
+    u32 *d_nflagged = nullptr;
+    const u32 nl = (max_lag + 1 + 63) / 64 * 64;
+    if (use_pairs) {
+        uint64_t total_flags = 0;
+        for (uint32_t i = 0; i < njobs; i++) {
+            flag0[i] = (uint32_t)total_flags;
+            total_flags += (jobs[i].nbits + 1 + AC_TB - 1) / AC_TB + AP_NQ / AC_NQ;   // padding: a pair tile flags AP_NQ / AC_NQ window tiles
+        }
+        const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
+        int rc = pmx_ensure_flags(ctx, flag_bytes + 16);
+        if (rc) return rc;
+        d_flags = ctx->d_flags;
+        d_nflagged = (u32 *)(ctx->d_flags + flag_bytes);
+        PMX_HIP(hipMemsetAsync(ctx->d_flags, 0, flag_bytes + 16, ctx->stream));
+        const u32 nh = (max_lag + 1 + 127) / 128;   // quads above a tile that hold partners of its drivers
+        const size_t lds_bytes = (2 * (size_t)nl + 2 * AP_CAP + 32 + 16) * sizeof(u32);
+        const size_t seg_stride = 2 * (size_t)nl + 16;
+        // workgroups per CU: 8 by registers; the histograms may allow fewer
+        u32 per_cu = (u32)((160u * 1024u) / (lds_bytes + 512));
+        if (per_cu > AP_WAVES) per_cu = AP_WAVES;
+        if (per_cu < 1) per_cu = 1;
+        for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS) {
+            const uint32_t n = njobs - lo < SP_MAXJOBS ? njobs - lo : SP_MAXJOBS;
+            std::vector<VJob> vj(n);
+            for (uint32_t i = 0; i < n; i++) {
+                vj[i].job = &jobs[lo + i];
+                vj[i].d_off = 0;
+                vj[i].d_n = max_lag + 1;
+                vj[i].flag0 = flag0[lo + i];
+            }
+            SpJobTable tab;
+            memset(&tab, 0, sizeof tab);
+            uint32_t total, tpw, nwg;
+            plan_launch(ctx, vj.data(), n, true, per_cu, &tab, &total, &tpw, &nwg, AP_TB);
+            rc = pmx_ensure_slab2(ctx, (size_t)(nwg + n) * seg_stride);
+            if (rc) return rc;
+            pmx_timed_launch tl;
+            rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_autocorr_pairs, dim3(nwg), dim3(256), lds_bytes, ctx->stream, tab, n, total, tpw, max_lag, nl,
+                               nh, ctx->d_slab2, d_flags, d_nflagged);
+            PMX_CHECK_LAUNCH("k_autocorr_pairs");
+            rc = pmx_prof_end(ctx, &tl);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_reduce_pairs, dim3((max_lag + 1 + 31) / 32 < 64 ? (max_lag + 1 + 31) / 32 : 64, 3, n), dim3(256), 0, ctx->stream,
+                               (const u32 *)ctx->d_slab2, tab, nl, max_lag, lagcap, 0u);
+            PMX_CHECK_LAUNCH("k_reduce_pairs");
+        }
+    }
+
+    // Pass 2 (window kernel): every tile, or -- behind the pair pass -- only the tiles it flagged as dense (the whole
+    // grid returns at once when there are none); its sums are ADDED to what the pair pass left in the per-job scratch.
+    std::vector<VJob> vjobs;
+    expand_chunks(jobs, njobs, max_lag + 1, vjobs, flag0.data());
 
     ReduceSpec rs;
     memset(&rs, 0, sizeof rs);
@@ -1320,6 +1728,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
     rs.src_row[1] = 1; rs.dst_row[1] = lagcap;       // N
     rs.src_row[2] = 2; rs.dst_row[2] = 2 * lagcap; rs.is_scalar[2] = 1;
     rs.use_out2 = 1;
+    rs.accumulate = use_pairs ? 1 : 0;
     rs.out_stride = out_stride;
 
     for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS) {
@@ -1335,15 +1744,15 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         if (rc) return rc;
         if (chunked)
             hipLaunchKernelGGL(k_autocorr_edges<true>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,
-                               ctx->d_slab);
+                               ctx->d_slab, (const unsigned char *)d_flags, (const u32 *)d_nflagged);
         else
             hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,
-                               ctx->d_slab);
+                               ctx->d_slab, (const unsigned char *)d_flags, (const u32 *)d_nflagged);
         PMX_CHECK_LAUNCH("k_autocorr_edges");
         rc = pmx_prof_end(ctx, &tl);
         if (rc) return rc;
         hipLaunchKernelGGL(k_reduce_segments, dim3(32, 3, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab,
-                           (u32)AC_SEG_ROWS, rs);
+                           (u32)AC_SEG_ROWS, rs, (const u32 *)d_nflagged);
         PMX_CHECK_LAUNCH("k_reduce_segments");
     }
     // the recurrence needs every chunk of a chromosome: run it once all launches are queued (same stream)

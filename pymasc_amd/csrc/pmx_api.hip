@@ -69,6 +69,10 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->scratch_words = 0;
     ctx->d_slab = nullptr;
     ctx->slab_words = 0;
+    ctx->d_slab2 = nullptr;
+    ctx->slab2_words = 0;
+    ctx->d_flags = nullptr;
+    ctx->flags_bytes = 0;
     ctx->d_out_stage = nullptr;
     ctx->out_stage_words = 0;
     for (int i = 0; i < 3; i++) {
@@ -115,6 +119,8 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_slab) (void)hipFree(ctx->d_slab);
+    if (ctx->d_slab2) (void)hipFree(ctx->d_slab2);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_out_stage) (void)hipFree(ctx->d_out_stage);
     for (int i = 0; i < 3; i++)
         if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
@@ -155,6 +161,35 @@ int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words)
     }
     PMX_HIP(hipMalloc((void **)&ctx->d_slab, u32_words * sizeof(u32)));
     ctx->slab_words = u32_words;
+    return PMX_OK;
+}
+
+int pmx_ensure_slab2(pmx_ctx *ctx, size_t u32_words)
+{
+    if (ctx->slab2_words >= u32_words) return PMX_OK;
+    if (ctx->d_slab2) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(ctx->d_slab2));
+        ctx->d_slab2 = nullptr;
+        ctx->slab2_words = 0;
+    }
+    PMX_HIP(hipMalloc((void **)&ctx->d_slab2, u32_words * sizeof(u32)));
+    ctx->slab2_words = u32_words;
+    return PMX_OK;
+}
+
+int pmx_ensure_flags(pmx_ctx *ctx, size_t bytes)
+{
+    if (ctx->flags_bytes >= bytes) return PMX_OK;
+    if (ctx->d_flags) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(ctx->d_flags));
+        ctx->d_flags = nullptr;
+        ctx->flags_bytes = 0;
+    }
+    const size_t want = bytes < 65536 ? 65536 : bytes * 2;
+    PMX_HIP(hipMalloc((void **)&ctx->d_flags, want));
+    ctx->flags_bytes = want;
     return PMX_OK;
 }
 

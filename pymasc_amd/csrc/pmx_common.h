@@ -53,6 +53,11 @@ struct pmx_ctx {
     // per-workgroup partial result slabs of the set-bit kernels (u32)
     u32 *d_slab;
     size_t slab_words;
+    // the pair-enumeration autocorrelation pass: its own slab, and the dense-tile flags (+ counter) it hands to the window pass
+    u32 *d_slab2;
+    size_t slab2_words;
+    unsigned char *d_flags;
+    size_t flags_bytes;
     // staging for the host-pointer entry points
     uint64_t *d_stage[3];
     size_t stage_words[3];
@@ -95,6 +100,8 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag,
                                     uint32_t mode, uint32_t read_len, uint32_t max_shift, uint32_t out_stride);
 int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words);
+int pmx_ensure_slab2(pmx_ctx *ctx, size_t u32_words);
+int pmx_ensure_flags(pmx_ctx *ctx, size_t bytes);
 size_t pmx_autocorr_scratch_words(uint32_t max_lag);
 // out[k] += sum_j M[j] & M[j+k], k = 0..max_lag
 int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_out);

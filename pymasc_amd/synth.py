@@ -42,6 +42,11 @@ class ChromVectors:
     M: Optional[torch.Tensor]
     n_forward: int
     n_reverse: int
+    # host copies of what the vectors were built from (keep_host=True): read positions and set(first, last) intervals
+    h_fpos: Optional["numpy.ndarray"] = None
+    h_rpos: Optional["numpy.ndarray"] = None
+    h_first: Optional["numpy.ndarray"] = None
+    h_last: Optional["numpy.ndarray"] = None
 
 
 def nwords(nbits: int) -> int:
@@ -50,7 +55,7 @@ def nwords(nbits: int) -> int:
 
 def make_chromosome(ctx, device, name: str, length: int, max_shift: int, read_len: int, seed: int,
                     density: float = 0.005, with_m: bool = True, peak_frac: float = 0.3, peak_shift: int = 180,
-                    mean_on: float = 2000.0, mean_off: float = 500.0) -> ChromVectors:
+                    mean_on: float = 2000.0, mean_off: float = 500.0, keep_host: bool = False) -> ChromVectors:
     g = torch.Generator(device=device).manual_seed(seed)
     nbits = length + read_len + max_shift + 100
     nw = nwords(nbits)
@@ -65,6 +70,9 @@ def make_chromosome(ctx, device, name: str, length: int, max_shift: int, read_le
     torch.cuda.current_stream(device).synchronize()
     ctx.bits_set_positions_dev(F.data_ptr(), nbits, fpos.data_ptr(), fpos.numel())
     ctx.bits_set_positions_dev(R.data_ptr(), nbits, rpos.data_ptr(), rpos.numel())
+    host = {}
+    if keep_host:
+        host.update(h_fpos=fpos.cpu().numpy(), h_rpos=rpos.cpu().numpy())
     M = None
     if with_m:
         M = torch.zeros(nw, dtype=torch.int64, device=device)
@@ -80,8 +88,10 @@ def make_chromosome(ctx, device, name: str, length: int, max_shift: int, read_le
         last = torch.clamp(ends[keep], max=length).contiguous()
         torch.cuda.current_stream(device).synchronize()
         ctx.bits_set_regions_dev(M.data_ptr(), nbits, first.data_ptr(), last.data_ptr(), first.numel())
+        if keep_host:
+            host.update(h_first=first.cpu().numpy(), h_last=last.cpu().numpy())
     ctx.sync()
-    return ChromVectors(name, length, nbits, F, R, M, int(fpos.numel()), int(rpos.numel()))
+    return ChromVectors(name, length, nbits, F, R, M, int(fpos.numel()), int(rpos.numel()), **host)
 
 
 def make_genome(ctx, device, chroms, max_shift: int, read_len: int, seed_base: int = 0xC0FFEE,

@@ -17,9 +17,9 @@ for d in ['pmcx1','pmcx2','pmcx3']:
     if not fs: print(d,'missing'); continue
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
     for r in csv.DictReader(open(fs[0])):
-        k=r['Kernel_Name'][:28]
+        k=r['Kernel_Name'][:24]
         agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
     for k,v in agg.items():
-        if 'sparse' in k or 'autocorr_edges' in k:
+        if 'sparse' in k or 'autocorr' in k:
             print(d,k,' '.join(f'{c}={x:.4g}' for c,x in sorted(v.items())))
 PY

@@ -32,21 +32,19 @@ if with_m:
 ctx.cc_batch_dev(args[0], args[1], None if not with_m else args[2], args[3], S, L, 0, args[7])
 ctx.sync()
 off = (nwg + len(vecs)) * 5 * 1024 * 4
-buf = np.zeros(nwg * 4 * 8, dtype=np.uint64)
+NS = 12
+buf = np.zeros(nwg * 4 * NS, dtype=np.uint64)
 Lb = ffi.load_library()
 Lb.pmx_debug_read_slab.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
 rc = Lb.pmx_debug_read_slab(ctx._h, off, buf.ctypes.data, buf.nbytes)
 assert rc == 0
-a = buf.reshape(nwg, 4, 8).astype(np.float64)
-names = ["B0 wait", "fold check", "tile_store+dec", "emit", "prefetch issue", "B1 wait", "process", "job/loop tail"]
+a = buf.reshape(nwg, 4, NS).astype(np.float64)
 tot = a.sum(axis=2).mean()
 print(f"mode={mode} nwg={nwg} tiles/wg={tpw} cycles per wave lifetime={tot:.0f}  per tile={tot / tpw:.0f}")
-for i, n in enumerate([names[7]] + names[:7]):
-    idx = (i - 1) % 8 if i else 7
-for i in range(8):
-    label = names[i - 1] if i >= 1 else "B0 wait"
 print("  stamp -> phase share")
 lab = {0: "B0 barrier wait", 1: "fold/convert check", 2: "tile_store + decimate", 3: "emit (reserve + records)", 4: "prefetch issue",
-       5: "B1 barrier wait", 6: "process (pads + F + R loops)", 7: "loop tail / job change"}
-for i in range(8):
+       5: "B1 barrier wait", 6: "process (pads + F + R loops)", 7: "loop tail / job change",
+       8: "  emit: reserve F (atomic)", 9: "  emit: reserve R (atomic)", 10: "  emit: positions F", 11: "-"}
+lab[3] = "emit: positions R + cursor reset"
+for i in range(NS):
     print(f"  {lab[i]:32s} {a[:, :, i].mean() / tpw:9.0f} cyc/tile  {100 * a[:, :, i].sum() / a.sum():5.1f} %")
