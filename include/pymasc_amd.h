@@ -53,8 +53,12 @@ extern "C" {
 #define PMX_FLAG_SKIP_MLEN    8u  /* the caller holds mappable_len already (the *_mappability.json cache,
                                    * handler/mappability.py:239-259): no autocorrelation pass; row 4 and
                                    * scalars[2] are written as zeros */
-/* default (neither): set-bit kernels (3 <= max_shift <= 65535, read_len <= 1024; shifts beyond 1023 are
- * processed in chunks of 1024), dense kernels otherwise */
+/* default (neither): the set-bit kernels for read_len <= 1024 (shifts beyond 1023 are processed in chunks of
+ * 1024), the dense kernels for longer reads.
+ * Limits of every entry point below: max_shift <= 65535 (the reference takes any -d, mscc.pyx:288, default 1000;
+ * larger values return PMX_ERR_INVALID), read_len <= 65535, nbits < 2^40.
+ * max_shift < 3: a row of max_shift + 1 words cannot hold the four scalars, so the scalar row is cut to its first
+ * max_shift + 1 entries (popcount(F)[, popcount(R)[, popcount(M)]]); all other rows are complete. */
 
 #define PMX_PATH_DENSE  1
 #define PMX_PATH_SPARSE 2

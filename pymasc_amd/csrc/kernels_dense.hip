@@ -42,14 +42,10 @@ template <bool HAS_M, bool DO_NCC>
 __global__ void __launch_bounds__(256) k_cc_dense(const u64 *__restrict__ F, const u64 *__restrict__ R,
                                                   const u64 *__restrict__ M, uint64_t nbits, uint64_t nwords,
                                                   u32 max_shift, int32_t c, u32 ntiles, u64 *__restrict__ out,
-                                                  u32 out_stride, const u64 *__restrict__ select, u32 select_mode)
+                                                  u32 out_stride, const u64 *__restrict__ select, u32 select_mode,
+                                                  u32 *__restrict__ slab)
 {
-    // select_mode 1: run only when the occupancy vectors are NOT sparse (the set-bit kernel takes the other
-    // case); select[0..1] = popcount(F), popcount(R) written earlier on this stream.  2: mark the path taken.
-    if (select_mode == 1) {
-        const u64 nset = select[0] + select[1];
-        if (nset * 8 <= nbits) return;
-    }
+    // select_mode != 0: mark the path taken in the scalar row of the result block
     if (select_mode && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         out[(size_t)PMX_ROW_SCALARS * out_stride + 3] = PMX_PATH_DENSE;
 
@@ -107,14 +103,29 @@ __global__ void __launch_bounds__(256) k_cc_dense(const u64 *__restrict__ F, con
         }
     }
 
-    if (d <= max_shift) {
-        if (DO_NCC && a_ncc) atomicAdd(&out[(size_t)PMX_ROW_NCC_CCBINS * out_stride + d], (u64)a_ncc);
-        if (HAS_M) {
-            if (a_fs) atomicAdd(&out[(size_t)PMX_ROW_MSCC_FSUM * out_stride + d], (u64)a_fs);
-            if (a_rs) atomicAdd(&out[(size_t)PMX_ROW_MSCC_RSUM * out_stride + d], (u64)a_rs);
-            if (a_mc) atomicAdd(&out[(size_t)PMX_ROW_MSCC_CCBINS * out_stride + d], (u64)a_mc);
-        }
+    // per-workgroup partial sums -> this workgroup's slab segment [4 rows][gridDim.y * 256 shifts] (no atomics:
+    // k_reduce_dense sums the gridDim.x segments of every shift block)
+    const u32 ncols = gridDim.y * 256u;
+    u32 *seg = slab + (size_t)blockIdx.x * 4 * ncols + d;
+    seg[0 * (size_t)ncols] = a_ncc;
+    if (HAS_M) {
+        seg[1 * (size_t)ncols] = a_fs;
+        seg[2 * (size_t)ncols] = a_rs;
+        seg[3 * (size_t)ncols] = a_mc;
     }
+}
+
+// out[row][d] = sum over the gx workgroup segments; rows: NCC_CCBINS, MSCC_FSUM, MSCC_RSUM, MSCC_CCBINS (= 0..3)
+__global__ void __launch_bounds__(256)
+k_reduce_dense(const u32 *__restrict__ slab, u32 gx, u32 ncols, u32 max_shift, u32 row_mask, u64 *__restrict__ out,
+               u32 out_stride)
+{
+    const u32 d = blockIdx.x * 256u + threadIdx.x, row = blockIdx.y;
+    if (d > max_shift || !((row_mask >> row) & 1u)) return;
+    u64 sum = 0;
+    const u32 *p = slab + (size_t)row * ncols + d;
+    for (u32 x = 0; x < gx; x++) sum += p[(size_t)x * 4 * ncols];
+    out[(size_t)row * out_stride + d] = sum;
 }
 
 __global__ void k_mlen_map(const u64 *__restrict__ autocorr, u32 max_shift, int32_t c, u64 *__restrict__ mlen)
@@ -150,20 +161,29 @@ int pmx_launch_cc_dense(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, 
     const int32_t c = (int32_t)read_len - 1;
     const u64 *F = (const u64 *)d_F, *R = (const u64 *)d_R, *M = (const u64 *)d_M;
     if (!d_M && !do_ncc) return PMX_OK;
+    const u32 ncols = grid.y * 256u;
+    int rc = pmx_ensure_slab(ctx, (size_t)grid.x * 4 * ncols);
+    if (rc) return rc;
     pmx_timed_launch tl;
-    int rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_DENSE, &tl);
+    rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_DENSE, &tl);
     if (rc) return rc;
     if (d_M && do_ncc)
         hipLaunchKernelGGL((k_cc_dense<true, true>), grid, dim3(256), 0, ctx->stream, F, R, M, nbits, nwords,
-                           max_shift, c, ntiles, d_out, out_stride, d_select, select_mode);
+                           max_shift, c, ntiles, d_out, out_stride, d_select, select_mode, ctx->d_slab);
     else if (d_M)
         hipLaunchKernelGGL((k_cc_dense<true, false>), grid, dim3(256), 0, ctx->stream, F, R, M, nbits, nwords,
-                           max_shift, c, ntiles, d_out, out_stride, d_select, select_mode);
+                           max_shift, c, ntiles, d_out, out_stride, d_select, select_mode, ctx->d_slab);
     else
         hipLaunchKernelGGL((k_cc_dense<false, true>), grid, dim3(256), 0, ctx->stream, F, R, M, nbits, nwords,
-                           max_shift, c, ntiles, d_out, out_stride, d_select, select_mode);
+                           max_shift, c, ntiles, d_out, out_stride, d_select, select_mode, ctx->d_slab);
     PMX_CHECK_LAUNCH("k_cc_dense");
-    return pmx_prof_end(ctx, &tl);
+    rc = pmx_prof_end(ctx, &tl);
+    if (rc) return rc;
+    const u32 row_mask = (do_ncc ? 1u : 0u) | (d_M ? 14u : 0u);
+    hipLaunchKernelGGL(k_reduce_dense, dim3(grid.y, 4), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, grid.x, ncols,
+                       max_shift, row_mask, d_out, out_stride);
+    PMX_CHECK_LAUNCH("k_reduce_dense");
+    return PMX_OK;
 }
 
 int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_out)
@@ -173,14 +193,22 @@ int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits,
     dim3 grid;
     dense_grid(ctx, nwords, max_lag, &ntiles, &grid);
     const u64 *M = (const u64 *)d_M;
-    pmx_timed_launch tl;
-    int rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
+    const u32 ncols = grid.y * 256u;
+    int rc = pmx_ensure_slab(ctx, (size_t)grid.x * 4 * ncols);
     if (rc) return rc;
-    // row PMX_ROW_NCC_CCBINS (= 0) of an out block with stride 0 offset: out[k] += sum_j M[j] & M[j+k]
+    pmx_timed_launch tl;
+    rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
+    if (rc) return rc;
+    // row 0 of the slab segments: out[k] = sum_j M[j] & M[j+k]
     hipLaunchKernelGGL((k_cc_dense<false, true>), grid, dim3(256), 0, ctx->stream, M, M, (const u64 *)nullptr,
-                       nbits, nwords, max_lag, 0, ntiles, d_out, max_lag + 1, (const u64 *)nullptr, 0u);
+                       nbits, nwords, max_lag, 0, ntiles, d_out, max_lag + 1, (const u64 *)nullptr, 0u, ctx->d_slab);
     PMX_CHECK_LAUNCH("k_cc_dense(autocorr)");
-    return pmx_prof_end(ctx, &tl);
+    rc = pmx_prof_end(ctx, &tl);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_reduce_dense, dim3(grid.y, 1), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, grid.x, ncols,
+                       max_lag, 1u, d_out, max_lag + 1);
+    PMX_CHECK_LAUNCH("k_reduce_dense");
+    return PMX_OK;
 }
 
 int pmx_launch_mlen_map(pmx_ctx *ctx, const u64 *d_autocorr, uint32_t max_shift, uint32_t read_len, u64 *d_mlen)

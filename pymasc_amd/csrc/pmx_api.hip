@@ -75,6 +75,8 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->flags_bytes = 0;
     ctx->d_out_stage = nullptr;
     ctx->out_stage_words = 0;
+    ctx->d_pad_stage = nullptr;
+    ctx->pad_stage_words = 0;
     for (int i = 0; i < 3; i++) {
         ctx->d_stage[i] = nullptr;
         ctx->stage_words[i] = 0;
@@ -122,6 +124,7 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (ctx->d_slab2) (void)hipFree(ctx->d_slab2);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_out_stage) (void)hipFree(ctx->d_out_stage);
+    if (ctx->d_pad_stage) (void)hipFree(ctx->d_pad_stage);
     for (int i = 0; i < 3; i++)
         if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -534,8 +537,35 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
     REQUIRE(read_len >= 1 && read_len <= 65535, "pmx_cc_batch_dev: read_len must be in [1, 65535]");
     REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
             "pmx_cc_batch_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
-    REQUIRE(max_shift >= 3, "pmx_cc_batch_dev: max_shift must be >= 3");
     if (njobs == 0) return PMX_OK;
+    if (max_shift < 3) {
+        // The kernels write four scalars into a row of max_shift + 1 words, so they run with at least 3 shifts: compute
+        // 4 columns wide into staging blocks and copy the leading max_shift + 1 columns of every row (shifts are
+        // independent, mscc.pyx:288; the scalar row is cut to max_shift + 1 entries, include/pymasc_amd.h).
+        const uint32_t kstride = 4, stride = max_shift + 1;
+        const size_t words = (size_t)njobs * PMX_NROWS * kstride;
+        if (ctx->pad_stage_words < words) {
+            if (ctx->d_pad_stage) {
+                PMX_HIP(hipStreamSynchronize(ctx->stream));
+                PMX_HIP(hipFree(ctx->d_pad_stage));
+                ctx->d_pad_stage = nullptr;
+                ctx->pad_stage_words = 0;
+            }
+            PMX_HIP(hipMalloc((void **)&ctx->d_pad_stage, words * sizeof(u64)));
+            ctx->pad_stage_words = words;
+        }
+        std::vector<uint64_t *> wide(njobs);
+        for (uint32_t i = 0; i < njobs; i++) {
+            REQUIRE(d_out[i], "pmx_cc_batch_dev: NULL output in the batch");
+            wide[i] = (uint64_t *)ctx->d_pad_stage + (size_t)i * PMX_NROWS * kstride;
+        }
+        int rc = pmx_cc_batch_dev(ctx, njobs, d_F, d_R, d_M, nbits, 3, read_len, flags, wide.data());
+        if (rc) return rc;
+        for (uint32_t i = 0; i < njobs; i++)
+            PMX_HIP(hipMemcpy2DAsync(d_out[i], stride * sizeof(u64), wide[i], kstride * sizeof(u64), stride * sizeof(u64),
+                                     PMX_NROWS, hipMemcpyDeviceToDevice, ctx->stream));
+        return PMX_OK;
+    }
     const bool has_m = d_M != nullptr && d_M[0] != nullptr;
     for (uint32_t i = 0; i < njobs; i++) {
         REQUIRE(d_F[i] && d_R[i] && d_out[i], "pmx_cc_batch_dev: NULL vector or output in the batch");

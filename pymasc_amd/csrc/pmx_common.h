@@ -63,6 +63,9 @@ struct pmx_ctx {
     size_t stage_words[3];
     u64 *d_out_stage;
     size_t out_stage_words;
+    // result blocks of max_shift < 3 are computed 4 columns wide here and narrowed into the caller's blocks
+    u64 *d_pad_stage;
+    size_t pad_stage_words;
 };
 
 // profiling helpers (pmx_api.hip)
@@ -78,7 +81,8 @@ int pmx_launch_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, cons
 int pmx_launch_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, u64 *d_count /* += */);
 
 // dense cross-correlation (kernels_dense.hip)
-// rows of d_out (stride = out_stride) receive += partial sums; caller zeroes d_out first.
+// rows NCC_CCBINS / MSCC_FSUM / MSCC_RSUM / MSCC_CCBINS of d_out (stride = out_stride) are overwritten (per-workgroup
+// partial sums go through the context's slab, no atomics).
 int pmx_launch_cc_dense(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M,
                         uint64_t nbits, uint32_t max_shift, uint32_t read_len, bool do_ncc,
                         u64 *d_out, uint32_t out_stride, const u64 *d_select, uint32_t select_mode);
@@ -103,7 +107,7 @@ int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_slab2(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_flags(pmx_ctx *ctx, size_t bytes);
 size_t pmx_autocorr_scratch_words(uint32_t max_lag);
-// out[k] += sum_j M[j] & M[j+k], k = 0..max_lag
+// out[k] = sum_j M[j] & M[j+k], k = 0..max_lag
 int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_out);
 // mlen_by_shift[d] = autocorr[|read_len - 1 - d|], d = 0..max_shift
 int pmx_launch_mlen_map(pmx_ctx *ctx, const u64 *d_autocorr, uint32_t max_shift, uint32_t read_len, u64 *d_mlen);

@@ -64,6 +64,17 @@ def test_job_boundaries_inside_workgroup_ranges(ctx):
         check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
 
 
+def test_job_boundaries_inside_workgroup_ranges_ncc_only(ctx):
+    # the NCC-only instantiation (one counter, 6 waves per SIMD, its own popcount(R) path) over ranges that span jobs
+    S, L = 1000, 36
+    lens = [12_000_000, 5_000_001, 12_500_000]
+    cases = [synth.make_case(400 + i, n, S, L, 0.004, 0.004, False, full_range=(i == 1)) for i, n in enumerate(lens)]
+    outs = run_batch(ctx, cases, S, L, False)
+    for (nbits, F, R, M), out in zip(cases, outs):
+        check_block(out, oracle.calc_correlation(F, R, None, nbits, S, L), S, False)
+        assert int(out[ffi.PMX_ROW_SCALARS, 3]) == ffi.PMX_PATH_SPARSE
+
+
 def test_more_jobs_than_one_job_table(ctx):
     S, L = 64, 20
     cases = [synth.make_case(300 + i, 3000 + 517 * i, S, L, 0.02, 0.02, True) for i in range(45)]

@@ -76,11 +76,13 @@ def _shl(words: torch.Tensor, d: int) -> torch.Tensor:
     return out
 
 
-def _torch_reference(v, d: int):
+def _torch_reference(v, d: int, read_len: int = L):
     """mscc.pyx:288-317 for ONE shift with whole-vector torch ops: F[j] & R[j+d] & D_d[j], D_d[j] = M[j] & M[j+c-d]."""
-    c = L - 1
+    c = read_len - 1
     F, R, M = v.F, v.R, v.M
     Rd = _shr(R, d)
+    if M is None:
+        return {"ncc": _popcount(F & Rd)}
     k = c - d
     Mk = _shr(M, k) if k >= 0 else _shl(M, -k)
     D = M & Mk
@@ -93,10 +95,12 @@ def _torch_reference(v, d: int):
     }
 
 
-def _run_batch(ctx, dev, vecs, max_shift, flags=0):
-    out = torch.zeros((len(vecs), ROWS, max_shift + 1), dtype=torch.int64, device=dev)
-    ctx.cc_batch_dev([v.F.data_ptr() for v in vecs], [v.R.data_ptr() for v in vecs], [v.M.data_ptr() for v in vecs],
-                     [v.nbits for v in vecs], max_shift, L, flags, [out[i].data_ptr() for i in range(len(vecs))])
+def _run_batch(ctx, dev, vecs, max_shift, flags=0, read_len=L):
+    out = torch.full((len(vecs), ROWS, max_shift + 1), -1, dtype=torch.int64, device=dev)   # garbage: must be overwritten
+    with_m = vecs[0].M is not None
+    ctx.cc_batch_dev([v.F.data_ptr() for v in vecs], [v.R.data_ptr() for v in vecs],
+                     [v.M.data_ptr() for v in vecs] if with_m else None,
+                     [v.nbits for v in vecs], max_shift, read_len, flags, [out[i].data_ptr() for i in range(len(vecs))])
     ctx.sync()
     return out.cpu().numpy()
 
@@ -172,3 +176,68 @@ def test_stress_chromosome_max_shift_5000(env):
                "rsum": rows[ffi.PMX_ROW_MSCC_RSUM, d], "cc": rows[ffi.PMX_ROW_MSCC_CCBINS, d],
                "mlen": rows[ffi.PMX_ROW_MLEN, d]}
         assert {k: int(x) for k, x in got.items()} == ref, d
+
+
+def test_full_genome_ncc_only(env):
+    """BASELINE config 2's shape: naive CC only over the whole hg38-sized genome, max_shift 1000 -- the NCC-only
+    instantiation of the set-bit kernel (one counter, 6 waves per SIMD, popcount(R) counted per thread)."""
+    ctx, dev = env
+    vecs = synth.make_genome(ctx, dev, synth.HG38, S, L, with_m=False)
+    rows = _run_batch(ctx, dev, vecs, S)
+    for i, v in enumerate(vecs):
+        sc = rows[i, ffi.PMX_ROW_SCALARS]
+        assert int(sc[3]) == ffi.PMX_PATH_SPARSE and int(sc[2]) == 0
+        assert not rows[i, ffi.PMX_ROW_MSCC_FSUM:ffi.PMX_ROW_MLEN + 1].any()
+        assert 0 < sc[0] <= v.n_forward and 0 < sc[1] <= v.n_reverse
+        assert (rows[i, ffi.PMX_ROW_NCC_CCBINS] <= min(int(sc[0]), int(sc[1]))).all()
+        assert int(np.argmax(rows[i, ffi.PMX_ROW_NCC_CCBINS])) == 180
+    for i in (0, 5, 16, 21, 23):                                                # chr1, chr6, chr17, chr22, chrY
+        v = vecs[i]
+        assert (int(rows[i, ffi.PMX_ROW_SCALARS, 0]), int(rows[i, ffi.PMX_ROW_SCALARS, 1])) == (_popcount(v.F), _popcount(v.R))
+        for d in (0, 1, 31, 32, 180, 999, S):
+            assert int(rows[i, ffi.PMX_ROW_NCC_CCBINS, d]) == _torch_reference(v, d)["ncc"], (v.name, d)
+    # the dense kernels agree on one whole chromosome, and a single launch equals its slot of the batch
+    dense = _run_batch(ctx, dev, [vecs[20]], S, ffi.PMX_FLAG_FORCE_DENSE)[0]
+    np.testing.assert_array_equal(dense[ffi.PMX_ROW_NCC_CCBINS], rows[20, ffi.PMX_ROW_NCC_CCBINS])
+    np.testing.assert_array_equal(_run_batch(ctx, dev, [vecs[7]], S)[0], rows[7])
+
+
+@pytest.mark.parametrize("with_m", [True, False])
+def test_stress_genome_as_specified(env, with_m):
+    """BASELINE config 5 as specified: 10 Gbp, 200 chromosomes, max_shift 5000, read_len 100 -- 1000 (chromosome x
+    1024-shift chunk) jobs, i.e. 7 batches of <= 32 chromosomes x 5 launches that reuse one slab.  Chunk-edge shifts
+    are recomputed with torch on chromosomes of different batches; every row is checked for the invariants that do not
+    need a reference."""
+    ctx, dev = env
+    S5, L5 = 5000, 100
+    chroms = synth.stress_genome()
+    assert len(chroms) == 200 and abs(sum(l for _, l in chroms) - 1e10) < 1e6
+    vecs = synth.make_genome(ctx, dev, chroms, S5, L5, seed_base=0xBADC0DE, with_m=with_m)
+    rows = _run_batch(ctx, dev, vecs, S5, read_len=L5)
+    assert (rows >= 0).all()                                                    # every word of every block was written
+    for i, v in enumerate(vecs):
+        sc = rows[i, ffi.PMX_ROW_SCALARS]
+        assert int(sc[3]) == ffi.PMX_PATH_SPARSE
+        assert 0 < sc[0] <= v.n_forward and 0 < sc[1] <= v.n_reverse
+        assert int(np.argmax(rows[i, ffi.PMX_ROW_NCC_CCBINS])) == 180          # the planted fragment peak
+        if with_m:
+            mlen = rows[i, ffi.PMX_ROW_MLEN]
+            assert int(mlen[L5 - 1]) == int(sc[2]) and (mlen <= sc[2]).all()
+            assert (rows[i, ffi.PMX_ROW_MSCC_CCBINS] <= rows[i, ffi.PMX_ROW_NCC_CCBINS]).all()
+            assert (rows[i, ffi.PMX_ROW_MSCC_FSUM] <= sc[0]).all() and (rows[i, ffi.PMX_ROW_MSCC_RSUM] <= sc[1]).all()
+        else:
+            assert not rows[i, ffi.PMX_ROW_MSCC_FSUM:ffi.PMX_ROW_MLEN + 1].any()
+    longest = max(range(200), key=lambda i: vecs[i].length)
+    shortest = min(range(200), key=lambda i: vecs[i].length)
+    for i in sorted({3, 40, 77, 150, 199, longest, shortest}):                  # launches of five different batches
+        v = vecs[i]
+        for d in (0, L5 - 1, L5, 1023, 1024, 2047, 2048, 4095, 4096, 4999, S5):
+            ref = _torch_reference(v, d, L5)
+            got = {"ncc": rows[i, ffi.PMX_ROW_NCC_CCBINS, d]}
+            if with_m:
+                got.update(fsum=rows[i, ffi.PMX_ROW_MSCC_FSUM, d], rsum=rows[i, ffi.PMX_ROW_MSCC_RSUM, d],
+                           cc=rows[i, ffi.PMX_ROW_MSCC_CCBINS, d], mlen=rows[i, ffi.PMX_ROW_MLEN, d])
+            assert {k: int(x) for k, x in got.items()} == ref, (v.name, d)
+    # a chromosome alone == its slot of the 200-chromosome batch (job table reuse across launches)
+    for i in (31, 32, 199):
+        np.testing.assert_array_equal(_run_batch(ctx, dev, [vecs[i]], S5, read_len=L5)[0], rows[i])

@@ -63,6 +63,91 @@ def test_calc_correlation_matches_oracle(ctx, case, flags):
         assert int(out[ffi.PMX_ROW_SCALARS, 2]) == int(oracle.lib().pmo_count(oracle._p(M), M.size))
 
 
+# bits anywhere in [0, nbits): reads longer than read_len, a track longer than the BAM's chromosome, bit 0, bit nbits-1
+FULL_RANGE_CASES = [
+    # seed, chrom_len, S, L, fd, rd, with_m, mean_on, mean_off
+    (21, 32768 - 1000 - 36 - 100 + 7, 1000, 36, 0.01, 0.01, True, 300, 80),    # the vector ends 7 bits into a new tile
+    (22, 65536 - 300 - 36 - 100, 300, 36, 0.02, 0.02, True, 2000, 500),        # nbits = 65536: full last dword, sparse edges
+    (23, 70001, 1000, 50, 0.005, 0.02, True, 30, 5),                            # partial last dword, dense edges
+    (24, 40000, 2500, 100, 0.01, 0.01, True, 300, 80),                          # shift chunks
+    (25, 90011, 1023, 36, 0.02, 0.01, False, 300, 80),                          # NCC-only instantiation
+    (26, 131072 + 31, 5000, 100, 0.01, 0.01, False, 300, 80),                   # NCC-only, shift chunks
+    (27, 500, 300, 36, 0.3, 0.3, True, 5, 5),                                   # everything inside one tile
+]
+
+
+@pytest.mark.parametrize("flags", [ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE, 0])
+@pytest.mark.parametrize("case", FULL_RANGE_CASES, ids=[f"seed{c[0]}" for c in FULL_RANGE_CASES])
+def test_bits_anywhere_in_the_vector(ctx, case, flags):
+    seed, clen, S, L, fd, rd, with_m, mean_on, mean_off = case
+    nbits, F, R, M = synth.make_case(seed, clen, S, L, fd, rd, with_m, mean_on=mean_on, mean_off=mean_off,
+                                     full_range=True)
+    for w in (F, R) + ((M,) if with_m else ()):
+        assert (int(w[(nbits - 1) >> 6]) >> ((nbits - 1) & 63)) & 1 and int(w[0]) & 1
+    ref = oracle.calc_correlation(F, R, M, nbits, S, L)
+    out = ctx.calc_correlation(F, R, M, nbits, S, L, flags)
+    check_block(out, ref, S, with_m)
+
+
+@pytest.mark.parametrize("with_m", [True, False])
+@pytest.mark.parametrize("read_len", [1025, 1500])
+def test_reads_longer_than_1024_take_the_dense_kernels(ctx, read_len, with_m):
+    """read_len > 1024: beyond the staged halo of the set-bit kernels; the default path must pick the dense kernels
+    (and say so), FORCE_SPARSE must refuse."""
+    S = 300
+    nbits, F, R, M = synth.make_case(31, 60000, S, read_len, 0.01, 0.01, with_m, full_range=True)
+    ref = oracle.calc_correlation(F, R, M, nbits, S, read_len)
+    out = ctx.calc_correlation(F, R, M, nbits, S, read_len, 0)
+    check_block(out, ref, S, with_m)
+    assert int(out[ffi.PMX_ROW_SCALARS, 3]) == ffi.PMX_PATH_DENSE
+    with pytest.raises(ffi.PmxError):
+        ctx.calc_correlation(F, R, M, nbits, S, read_len, ffi.PMX_FLAG_FORCE_SPARSE)
+
+
+@pytest.mark.parametrize("flags", [ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE, 0])
+@pytest.mark.parametrize("max_shift", [0, 1, 2])
+def test_max_shift_below_three(ctx, max_shift, flags):
+    """The reference takes any -d (mscc.pyx:288); the kernels need 3 shifts for their scalar row, the ABI pads
+    internally and cuts the scalar row to max_shift + 1 entries (include/pymasc_amd.h)."""
+    L = 36
+    nbits, F, R, M = synth.make_case(41, 50000, max_shift, L, 0.02, 0.02, True, full_range=True)
+    ref = oracle.calc_correlation(F, R, M, nbits, max_shift, L)
+    out = ctx.calc_correlation(F, R, M, nbits, max_shift, L, flags)
+    assert out.shape == (ffi.PMX_NROWS, max_shift + 1)
+    np.testing.assert_array_equal(out[ffi.PMX_ROW_NCC_CCBINS].astype(np.int64), ref["ncc_ccbins"])
+    np.testing.assert_array_equal(out[ffi.PMX_ROW_MSCC_FSUM].astype(np.int64), ref["mscc_forward_sum"])
+    np.testing.assert_array_equal(out[ffi.PMX_ROW_MSCC_RSUM].astype(np.int64), ref["mscc_reverse_sum"])
+    np.testing.assert_array_equal(out[ffi.PMX_ROW_MSCC_CCBINS].astype(np.int64), ref["mscc_ccbins"])
+    np.testing.assert_array_equal(out[ffi.PMX_ROW_MLEN].astype(np.int64), ref["mappable_len_by_shift"])
+    scal = [ref["ncc_forward_sum"], ref["ncc_reverse_sum"], int(oracle.lib().pmo_count(oracle._p(M), M.size))]
+    assert [int(x) for x in out[ffi.PMX_ROW_SCALARS]] == scal[:max_shift + 1]
+
+
+def test_max_shift_limit_is_an_error_not_a_wrong_answer(ctx):
+    nbits, F, R, M = synth.make_case(42, 5000, 100, 36)
+    with pytest.raises(ffi.PmxError):
+        ctx.calc_correlation(F, R, M, nbits, 65536, 36, 0)
+
+
+def test_mappable_len_sparse_and_dense_edge_regions_in_one_track(ctx):
+    """The autocorrelation runs a pair-enumeration pass over sparse-edge tiles and the window kernel over the tiles
+    it flags as dense: a track with both kinds of regions (and a dense region straddling tile boundaries) must add up."""
+    S, L, G = 1000, 36, 700000
+    nbits = G + L + S + 100
+    rng = np.random.default_rng(77)
+    M = synth.run_bits(rng, nbits, 3000, 900, 1, G + 1)                       # long runs: ~35 edges per 64-Kbit tile
+    for lo, hi in ((60000, 140000), (300000, 310000), (520000, 660000)):     # dense-edge islands
+        island = synth.run_bits(rng, nbits, 6, 4, lo, hi)
+        keep = synth.run_bits(np.random.default_rng(1), nbits, 10**9, 1, lo, hi)   # ones on [lo, hi)
+        M = (M & ~keep) | island
+    ref = oracle.mappable_len_readless(M, nbits, S)
+    np.testing.assert_array_equal(ctx.mappable_len(M, nbits, S, 0).astype(np.int64), ref)
+    nb2, F, R, _ = synth.make_case(5, G, S, L, 0.004, 0.004, False)
+    assert nb2 == nbits
+    out = ctx.calc_correlation(F, R, M, nbits, S, L, 0)
+    check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
+
+
 def test_skip_ncc(ctx):
     nbits, F, R, M = synth.make_case(11, 30000, 200, 36)
     ref = oracle.calc_correlation(F, R, M, nbits, 200, 36, skip_ncc=True)

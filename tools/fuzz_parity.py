@@ -28,7 +28,7 @@ def draw_case(rng):
     S = int(rng.choice([3, 4, 31, 32, 33, 63, 64, 100, 300, 511, 512, 1000, 1023, 1024, 1025, 2047, 2048, 3000, 5000]))
     if kind == 0:
         S = int(rng.integers(3, 6000))
-    L = int(rng.choice([1, 2, 20, 36, 50, 100, 151, 250, 1000, 1024]))
+    L = int(rng.choice([1, 2, 20, 36, 50, 100, 151, 250, 1000, 1024, 1025, 1500]))
     if kind == 1:
         L = int(rng.integers(1, 1025))
     clen = int(rng.choice([1, 40, 900, 5000, 32768 - 200, 32768, 32768 + 7, 65536, 70001, 131072 + 31, 200003]))
@@ -40,6 +40,11 @@ def draw_case(rng):
     mean_on = float(rng.choice([1.5, 5, 30, 300, 3000, 1e6]))
     mean_off = float(rng.choice([1.5, 5, 80, 500, 1e6]))
     return S, L, clen, fd, rd, with_m, mean_on, mean_off
+
+
+def draw_full_range(rng):
+    """Half of the cases put bits anywhere in [0, nbits) (tests/synth.py:make_case)."""
+    return bool(rng.random() < 0.5)
 
 
 def compare(out, ref, S, with_m, skip_ncc, tag):
@@ -79,14 +84,18 @@ def main():
             if (S + 1) * (clen + S + L + 100) > 1.5e9:
                 continue
             case_seed = int(rng.integers(0, 2**31))
-            nbits, F, R, M = synth.make_case(case_seed, clen, S, L, fd, rd, with_m, mean_on=mean_on, mean_off=mean_off)
+            full = draw_full_range(rng)
+            nbits, F, R, M = synth.make_case(case_seed, clen, S, L, fd, rd, with_m, mean_on=mean_on, mean_off=mean_off,
+                                             full_range=full)
             skip_ncc = with_m and rng.random() < 0.2
             ref = oracle.calc_correlation(F, R, M, nbits, S, L, skip_ncc=skip_ncc)
             for flags in (0, ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE):
                 if flags == ffi.PMX_FLAG_FORCE_DENSE and (S + 1) * nbits > 3e8:
                     continue
+                if flags == ffi.PMX_FLAG_FORCE_SPARSE and L > 1024:
+                    continue                       # reads longer than 1024 take the dense kernels
                 fl = flags | (ffi.PMX_FLAG_SKIP_NCC if skip_ncc else 0)
-                tag = f"seed={case_seed} S={S} L={L} clen={clen} fd={fd} rd={rd} m={with_m}/{mean_on}/{mean_off} flags={fl}"
+                tag = f"seed={case_seed} S={S} L={L} clen={clen} fd={fd} rd={rd} m={with_m}/{mean_on}/{mean_off} full={full} flags={fl}"
                 try:
                     out = ctx.calc_correlation(F, R, M, nbits, S, L, fl)
                 except ffi.PmxError as e:
