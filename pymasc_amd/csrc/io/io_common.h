@@ -6,10 +6,13 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include "../../../include/pymasc_amd_io.h"
 
 namespace pmx_io {
 
@@ -57,6 +60,14 @@ void parallel_for(int nthreads, size_t n, size_t grain, F fn)
             } catch (const Error &e) {
                 std::lock_guard<std::mutex> g(mu);
                 if (!failed.exchange(true)) first = e;
+                return;
+            } catch (const std::exception &e) {   // bad_alloc / length_error from a growing vector: an exception that
+                std::lock_guard<std::mutex> g(mu);   // leaves a std::thread body ends the process (and its GPU context)
+                if (!failed.exchange(true)) first = Error(PMX_IO_ERR_FORMAT, std::string("worker thread: ") + e.what());
+                return;
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu);
+                if (!failed.exchange(true)) first = Error(PMX_IO_ERR_FORMAT, "worker thread: unknown exception");
                 return;
             }
         }

@@ -94,11 +94,20 @@ def read_stats(path, need_shift: int, references: Iterable[str]) -> Dict[str, An
 
 
 def write_stats(path, max_shift: int, whole: Sequence[int], per_chrom: Mapping[str, Sequence[int]]) -> None:
-    """The cache file, laid out like the reference's (handler/mappability.py:294-301)."""
-    with open(path, "w") as fp:
-        json.dump({"max_shift": max_shift, "__whole__": list(whole),
-                   "references": {c: list(v) for c, v in per_chrom.items()}},
-                  fp, indent=4, sort_keys=True, cls=_IntEncoder)
+    """The cache file, laid out like the reference's (handler/mappability.py:294-301).  Written to a temporary file in
+    the same directory and renamed into place, so a concurrent reader (another rank, another run) sees either the old
+    file or the complete new one, never a truncated one."""
+    path = str(path)
+    tmp = "{}.tmp.{}".format(path, os.getpid())
+    try:
+        with open(tmp, "w") as fp:
+            json.dump({"max_shift": max_shift, "__whole__": list(whole),
+                       "references": {c: list(v) for c, v in per_chrom.items()}},
+                      fp, indent=4, sort_keys=True, cls=_IntEncoder)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
 
 
 class MappabilityStats:

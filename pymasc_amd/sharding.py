@@ -11,7 +11,7 @@ xGMI on the GPU box; the same code runs on "gloo" with CPU tensors in the tests.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple  # noqa: F401
 
 import torch
 import torch.distributed as dist
@@ -80,18 +80,43 @@ def exchange_results(local_rows: torch.Tensor, assignment: List[List[int]], njob
 # process per GPU instead of one per chromosome task.
 # ---------------------------------------------------------------------------------------------------------------
 
-def gather_chromosome_results(local: Dict[str, object], order: Sequence[str], group=None) -> Dict[str, object]:
+def _collective_device_setup(device, group=None):
+    """With a GPU backend (nccl = RCCL) object collectives stage their payload on torch's CURRENT device, which is
+    cuda:0 in every fresh process: bind it to this rank's GPU first, or two ranks collide on one device."""
+    if not (dist.is_available() and dist.is_initialized()) or device is None:
+        return
+    try:
+        backend = str(dist.get_backend(group))
+    except Exception:
+        return
+    if "nccl" in backend and torch.cuda.is_available():
+        torch.cuda.set_device(int(device))
+
+
+def gather_chromosome_results(local: Dict[str, object], order: Sequence[str], group=None,
+                              error: BaseException = None) -> Dict[str, object]:
     """Every rank's {chromosome: BothChromResult} -> the union on every rank, in ``order``.
 
     The payload is a few KB of integers per chromosome (what the reference pushes through a multiprocessing.Queue,
-    worker.py:234); the fixed-shape tensor exchange used by the benchmark is ``exchange_results`` above."""
+    worker.py:234); the fixed-shape tensor exchange used by the benchmark is ``exchange_results`` above.
+    ``error``: this rank failed -- every rank learns about it from the same collective and raises, instead of the
+    healthy ranks waiting for a peer that never arrives (the reference's '__ERROR__' report, worker.py:91-99 ->
+    handler/calc.py:205-206)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        parts = [local]
+        if error is not None:
+            raise error
+        parts = [(None, local)]
     else:
         parts = [None] * dist.get_world_size(group)
-        dist.all_gather_object(parts, local, group=group)
+        mine = (None if error is None else "{}: {}".format(type(error).__name__, error), None if error else local)
+        dist.all_gather_object(parts, mine, group=group)
+    failed = [(r, p[0]) for r, p in enumerate(parts) if p[0] is not None]
+    if failed:
+        if error is not None:
+            raise error                                    # the failing rank re-raises its own exception (type kept)
+        raise RuntimeError("Worker error on rank(s): " + "; ".join("{} [{}]".format(r, msg) for r, msg in failed))
     merged: Dict[str, object] = {}
-    for p in parts:
+    for _err, p in parts:
         for chrom, res in p.items():
             if chrom in merged:
                 raise RuntimeError("chromosome {} was calculated by two ranks".format(chrom))
@@ -99,15 +124,39 @@ def gather_chromosome_results(local: Dict[str, object], order: Sequence[str], gr
     return {c: merged[c] for c in order if c in merged}
 
 
+def reconcile_chromosome_sizes(bam_sizes: Dict[str, int], external_sizes: Dict[str, int]) -> Dict[str, int]:
+    """The reference's rule when a mappability track is given (reader/bam.py:217-255 via handler/calc.py:100-115):
+    for chromosomes present in both, a mismatch is warned about and the LONGER length is used."""
+    import logging
+    log = logging.getLogger(__name__)
+    out = {}
+    for ref, bam_size in bam_sizes.items():
+        ext = external_sizes.get(ref)
+        if ext is None:
+            log.debug("External size for '%s' not found", ref)
+            out[ref] = bam_size
+            continue
+        if ext != bam_size:
+            log.warning("'%s' reference length mismatch: SAM/BAM -> %s, External -> %s", ref, format(bam_size, ","),
+                        format(ext, ","))
+            if bam_size < ext:
+                log.warning("Use longer length '%d' for '%s' anyway", ext, ref)
+        out[ref] = max(bam_size, ext)
+    return out
+
+
 def run_sharded(bam_path, max_shift: int, read_len: int, mapq_criteria: int, bigwig_path=None,
                 references: Sequence[str] = None, skip_ncc: bool = False, device: int = None, context=None,
                 chrom2mappable_len=None, group=None):
     """BAM (+ BigWig) -> genome-wide result on every rank; chromosomes LPT-sharded over the ranks by length.
 
+    Launch: one process per GPU under ``torch.distributed`` (torchrun, or pymasc_amd.launch.spawn_ranks), the process
+    group initialised BEFORE this call; ``device`` = this rank's GPU (default LOCAL_RANK).
     Every rank reads its own chromosomes through the .bai index when there is one (the reference requires it for
     its multi-process mode, reader/bam.py:246-262), otherwise it streams the whole BAM through the native reader
-    (~30 M records/s on 16 host threads) and keeps its share; the kernels see only the rank's chromosomes; one object all-gather at the end, then the reference's aggregation
-    (result.py:301-464 -> pymasc_amd.result.aggregate_results)."""
+    (~30 M records/s on 16 host threads) and keeps its share; the kernels see only the rank's chromosomes; one object
+    all-gather at the end, then the reference's aggregation (result.py:301-464 -> pymasc_amd.result.aggregate_results).
+    A rank that fails reports through that same all-gather, so every rank raises instead of hanging."""
     from .bam import BamReader, feed_bam
     from .bigwig import BigWigReader
     from .calculator import CCHipCalculator
@@ -116,25 +165,42 @@ def run_sharded(bam_path, max_shift: int, read_len: int, mapq_criteria: int, big
     on = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if on else 0
     world = dist.get_world_size(group) if on else 1
-    with BamReader(bam_path) as bam:
-        names = [n for n in bam.references if references is None or n in set(references)]
-        lengths = dict(zip(bam.references, bam.lengths))
-        mine = [names[i] for i in sorted(lpt_assign([lengths[n] for n in names], world)[rank])]
-        bw = BigWigReader(bigwig_path) if bigwig_path is not None else None
-        kw = {}
-        if context is not None:
-            kw["context"] = context
-        elif device is not None:
-            kw["device"] = device
-        local: Dict[str, object] = {}
-        if mine:
-            calc = CCHipCalculator(max_shift, read_len, mine, [lengths[n] for n in mine], bwfeeder=bw,
-                                   skip_ncc=skip_ncc, chrom2mappable_len=chrom2mappable_len, **kw)
-            feed_bam(calc, bam, mapq_criteria, references=mine)
-            local = {c: calc.get_result(c) for c in mine}
-            if context is None:
-                calc.close()
-        if bw is not None:
-            bw.close()
-    merged = gather_chromosome_results(local, names, group)
+    if device is None and context is None and on:
+        import os
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    _collective_device_setup(device, group)
+    local: Dict[str, object] = {}
+    names: List[str] = []
+    error = None
+    try:
+        with BamReader(bam_path) as bam:
+            names = [n for n in bam.references if references is None or n in set(references)]
+            lengths = dict(zip(bam.references, bam.lengths))
+            bw = BigWigReader(bigwig_path) if bigwig_path is not None else None
+            try:
+                if bw is not None:      # the track's chromosome sizes win where they are longer (handler/calc.py:100-115)
+                    lengths.update(reconcile_chromosome_sizes({n: lengths[n] for n in names}, bw.chromsizes))
+                mine = [names[i] for i in sorted(lpt_assign([lengths[n] for n in names], world)[rank])]
+                kw = {}
+                if context is not None:
+                    kw["context"] = context
+                elif device is not None:
+                    kw["device"] = device
+                if mine:
+                    calc = CCHipCalculator(max_shift, read_len, mine, [lengths[n] for n in mine], bwfeeder=bw,
+                                           skip_ncc=skip_ncc, chrom2mappable_len=chrom2mappable_len, **kw)
+                    try:
+                        feed_bam(calc, bam, mapq_criteria, references=mine)
+                        local = {c: calc.get_result(c) for c in mine}
+                    finally:
+                        if context is None:
+                            calc.close()
+            finally:
+                if bw is not None:
+                    bw.close()
+    except BaseException as e:          # surfaced on every rank by the gather below
+        if not on or world == 1:
+            raise
+        error = e
+    merged = gather_chromosome_results(local, names, group, error=error)
     return aggregate_results(merged)

@@ -177,3 +177,131 @@ def test_run_from_files_gpu_matches_host_restatement(tmp_path):
         host = sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, skip_ncc=skip_ncc, context=FakeContext())
         gpu = sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, skip_ncc=skip_ncc, device=0)
         assert _table_bytes(gpu, tmp, "gpu2") == _table_bytes(host, tmp, "host2")
+
+
+# ---- chromosome sizes: the track wins where it is longer (handler/calc.py:100-115, reader/bam.py:217-255) ----------
+def test_reconcile_chromosome_sizes_rule():
+    out = sharding.reconcile_chromosome_sizes({"a": 100, "b": 200, "c": 300}, {"a": 150, "b": 180, "z": 5})
+    assert out == {"a": 150, "b": 200, "c": 300}
+
+
+def test_track_chromosome_longer_than_the_bam_header(tmp_path):
+    """A BigWig whose chromosome is longer than the BAM's, with mappable intervals beyond the BAM length: the reference
+    uses the longer length for genomelen and the vectors; before the fix the intervals overran the bit-vector
+    (PMX_ERR_INVALID) and genomelen differed."""
+    from tests import io_writers as W
+    from tests.fake_context import FakeContext
+    from pymasc_amd.bam import BamReader, feed_bam
+    from pymasc_amd.bigwig import BigWigReader
+    from pymasc_amd.calculator import CCHipCalculator
+    tmp = str(tmp_path)
+    rng = np.random.default_rng(5)
+    refs = [("c1", 30000), ("c2", 20000)]
+    recs, meta = W.synth_bam_records(rng, refs, 600)
+    bam = os.path.join(tmp, "s.bam")
+    W.write_bam_indexed(bam, refs, recs, [int(x) for x in meta[:, 0]], block=3000)
+    sizes = {"c1": 33000, "c2": 19000}                    # c1 longer in the track, c2 shorter
+    tracks = {"c1": [(100, 9000, 1.0), (12000, 29990, 1.0), (30500, 32990, 1.0)], "c2": [(0, 18000, 1.0)]}
+    bw = os.path.join(tmp, "m.bw")
+    W.write_bigwig(bw, sizes, tracks, items_per_block=40)
+    res = sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, context=FakeContext())
+    assert res.genomelen == 33000 + 20000
+    assert res.chroms["c1"].genomelen == 33000 and res.mappable_chroms["c2"].genomelen == 20000
+    # the same through a calculator built with the reconciled lengths by hand
+    with BamReader(bam) as b, BigWigReader(bw) as w:
+        calc = CCHipCalculator(120, 36, ["c1", "c2"], [33000, 20000], bwfeeder=w, context=FakeContext())
+        feed_bam(calc, b, 10)
+    for c in ("c1", "c2"):
+        assert list(res.mappable_chroms[c].ccbins) == list(calc.get_result(c).mappable_chrom.ccbins)
+        assert list(res.mappable_chroms[c].mappable_len) == list(calc.get_result(c).mappable_chrom.mappable_len)
+        assert list(res.chroms[c].ccbins) == list(calc.get_result(c).chrom.ccbins)
+    assert res.mappable_chroms["c1"].mappable_len[0] == (9000 - 100) + (29990 - 12000) + (32990 - 30500)
+
+
+# ---- pipeline.run under several ranks: the lag cache is computed once, written atomically, broadcast ---------------
+def _pipeline_worker(rank, world, port, q, bam, bw, tmp, tag):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pymasc_amd import pipeline, mappability
+        from tests.fake_context import FakeContext
+        calls = []
+        orig = mappability.MappabilityStats.calc_mappability
+        mappability.MappabilityStats.calc_mappability = lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1]
+        res, written = pipeline.run(bam, os.path.join(tmp, "out_%s_%d" % (tag, rank)), 120, 36, 10, mappability_path=bw,
+                                    context=FakeContext())
+        tabs = [open(p, "rb").read() for p in written]
+        q.put((rank, tabs, len(calls), [os.path.basename(str(p)) for p in written]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_pipeline_computes_the_lag_cache_once(tmp_path):
+    from pymasc_amd import pipeline
+    from tests.fake_context import FakeContext
+    tmp = str(tmp_path)
+    bam, bw = _write_inputs(tmp)
+    cache = os.path.join(tmp, "m_mappability.json")
+    single, written = pipeline.run(bam, os.path.join(tmp, "single"), 120, 36, 10, mappability_path=bw,
+                                   context=FakeContext(), save_mappability_stats=False)
+    assert not os.path.exists(cache)
+    expect = [open(p, "rb").read() for p in written]
+    for tag in ("cold", "warm"):                           # cold: rank 0 computes + saves; warm: the file is loaded
+        world = 2
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q, bam, bw, tmp, tag)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=600) for _ in range(world))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        assert got[0][1] == expect and got[0][3] == ["s_cc.tab", "s_mscc.tab", "s_nreads.tab"]
+        assert got[1][1] == [] and got[1][3] == []         # rank 0 writes the tables
+        assert [g[2] for g in got] == ([1, 0] if tag == "cold" else [0, 0])   # computed once, on rank 0 only / loaded
+        assert os.path.exists(cache) and not [f for f in os.listdir(tmp) if ".tmp." in f]
+        json_ok = __import__("json").load(open(cache))
+        assert set(json_ok) == {"max_shift", "__whole__", "references"}
+
+
+# ---- a failing rank surfaces on every rank instead of leaving the others in the collective ---------------------------
+def _failing_worker(rank, world, port, q, bam, bw):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pymasc_amd import ffi
+        from tests.fake_context import FakeContext
+
+        class Broken(FakeContext):
+            def cc_dev(self, *a, **k):
+                raise ffi.PmxError(-2, "injected kernel failure")
+        try:
+            sharding.run_sharded(bam, 120, 36, 10, bigwig_path=bw, context=Broken() if rank == 1 else FakeContext())
+            q.put((rank, "no error"))
+        except Exception as e:
+            q.put((rank, "{}: {}".format(type(e).__name__, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_failure_on_one_rank_raises_on_all(tmp_path):
+    bam, bw = _write_inputs(str(tmp_path))
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, bam, bw)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=400) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[1].startswith("PmxError") and "injected kernel failure" in got[1]
+    assert got[0].startswith("RuntimeError") and "rank(s): 1" in got[0] and "injected kernel failure" in got[0]
