@@ -179,10 +179,16 @@ __device__ __forceinline__ void fa(u32 a, u32 b, u32 cin, u32 &s, u32 &cout)
 // The counter is cleared.  Inlined at exactly ONE place per kernel (the loops below are built around that): its
 // temporaries (n[16], a[24]) are live where few other registers are, so it does not raise the kernel's allocation,
 // whereas a non-inlined callee's registers ADD to the caller's on this target.
-__device__ __forceinline__ void counter_to_lds(Planes &c, u32 quadcnt, u32 lgG, u32 tid, u32 *stage, u32 *acc)
+__device__ __forceinline__ void counter_to_lds(Planes &c, u32 quadcnt, u32 lgG, u32 tid, u32 *stage, u32 *acc,
+                                               bool active = true)
 {
+    // active == false (wave-uniform; role-split builds): this wave does not carry the counter being folded: it stages
+    // zeros and keeps `c`, which belongs to another accumulator
     u32 n[SP_NS];
-    {
+    if (!active) {
+#pragma unroll
+        for (int k = 0; k < SP_NS; k++) n[k] = 0;
+    } else {
         n[0] = c.P[0];
         n[1] = c.P[1];
         const u32 q2v = (quadcnt & 1u) ? c.Q2 : 0u;
@@ -197,8 +203,8 @@ __device__ __forceinline__ void counter_to_lds(Planes &c, u32 quadcnt, u32 lgG, 
         }
 #pragma unroll
         for (int k = SP_NP; k < SP_NS; k++) n[k] = 0;
+        planes_zero(c);
     }
-    planes_zero(c);
     for (u32 step = 1u << lgG; step < 64; step <<= 1) {   // lanes ^ G, ^ 2G, ...: the same shifts of other slots
         u32 carry = 0;
 #pragma unroll
@@ -449,15 +455,16 @@ __device__ __forceinline__ void emit_positions(const uint4 w, const uint4 flag_b
 // unmappable forward reads, get the address of the zero region instead of a mask.
 //   forward: {shift word of the R window, R window address (lane adds 4l), M window address (lane subtracts 4l), M shift}
 template <bool HAS_M>
-__device__ __forceinline__ void build_forward_records(u32 *lds, uint4 *recs, u32 first, u32 lane_in_slot, u32 G, u32 nq,
-                                                      u32 n, int32_t c)
+__device__ __forceinline__ void build_forward_records(u32 *lds, uint4 *recs, u32 qbase, u32 qstride, u32 lane_in_slot,
+                                                      u32 G, u32 nq, u32 n, int32_t c)
 {
     typedef SpLds<HAS_M> L;
     const u32 *pl = lds + L::PLF;
     for (u32 j = lane_in_slot; j < 4 * nq; j += G) {
         uint4 rec = make_uint4(0u, L::ZERO * 4u, (L::ZERO + 32u) * 4u, 0u);
-        if (first + j < n) {
-            const u32 e = pl[first + j];
+        const u32 idx = 4u * (qbase + (j >> 2) * qstride) + (j & 3u);   // the slot's k-th quad is quad qbase + k qstride
+        if (idx < n) {
+            const u32 e = pl[idx];
             const u32 pos = e & 0x7fffu;
             rec.x = pos;
             rec.y = (L::R + (pos >> 5)) * 4u;
@@ -473,15 +480,16 @@ __device__ __forceinline__ void build_forward_records(u32 *lds, uint4 *recs, u32
 
 //   reverse: {shift word of M[p-d], its address (lane subtracts 4l), address of the decimated copy holding M[p+c-2d]
 //             (lane subtracts 4l), its shift word}
-__device__ __forceinline__ void build_reverse_records(u32 *lds, uint4 *recs, u32 first, u32 lane_in_slot, u32 G, u32 nq, u32 n,
-                                                      int32_t c)
+__device__ __forceinline__ void build_reverse_records(u32 *lds, uint4 *recs, u32 qbase, u32 qstride, u32 lane_in_slot, u32 G,
+                                                      u32 nq, u32 n, int32_t c)
 {
     typedef SpLds<true> L;
     const u32 *pl = lds + L::PLR;
     for (u32 j = lane_in_slot; j < 4 * nq; j += G) {
         uint4 rec = make_uint4(0u, (L::ZERO + 32u) * 4u, (L::ZERO + 32u) * 4u, 0u);
-        if (first + j < n) {
-            const u32 p = pl[first + j] & 0x7fffu;
+        const u32 idx = 4u * (qbase + (j >> 2) * qstride) + (j & 3u);
+        if (idx < n) {
+            const u32 p = pl[idx] & 0x7fffu;
             const u32 a1 = p + SP_HALO_M - 31u;
             const u32 bb = p + SP_HALO_M + (u32)c;
             const u32 a2 = (bb >> 1) - 31u;
@@ -529,6 +537,9 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 #define SP_WAVES_NCC 6             // waves per SIMD of the NCC-only instantiation (1 counter; measured 4: 0.334, 5: 0.309,
                                    // 6: 0.300, 7: 0.311, 8: 0.473 ms on the benchmark genome)
 #endif
+#ifndef SP_ROLES
+#define SP_ROLES 0                 // 1: waves 0-1 carry (ncc, mscc.ccbins), waves 2-3 (mscc.fsum, mscc.rsum) -- A/B build
+#endif
 template <bool HAS_M, bool DO_NCC, bool CH>
 __global__ void __launch_bounds__(256, CH ? (HAS_M ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
 k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
@@ -550,12 +561,19 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     for (u32 i = tid; i < 40; i += 256) lds[L::ZERO + i] = 0;
     for (u32 i = tid; i < L::NCOUNTERS * SP_NL * 32; i += 256) acc[i] = 0;
 
+    constexpr bool ROLES = SP_ROLES && HAS_M && DO_NCC && !CH;
+    constexpr u32 RCAP = ROLES ? SP_CAP / 2 : SP_CAP;   // records of one list a round can take (a role has half the slots)
     Planes cN, cF, cC, cR;
     planes_zero(cN);
     planes_zero(cF);
     planes_zero(cC);
     planes_zero(cR);
-    u32 qF = 0, qR = 0;           // quads in the register counters (workgroup-uniform)
+    Planes c0, c1;   // ROLES: role A (waves 0-1): c0 = ncc, c1 = mscc.ccbins; role B (waves 2-3): c0 = mscc.fsum, c1 = mscc.rsum
+    planes_zero(c0);
+    planes_zero(c1);
+    u32 qF = 0, qR = 0;           // upper bound of the quads in the register counters (workgroup-uniform: fold decisions)
+    u32 qFw = 0, qRw = 0;         // quads in THIS wave's register counters (wave-uniform: carry parity)
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u32 q2 = 0;                   // upper bound of the counts folded into the LDS accumulators since conversion
     u32 totF = 0, totR = 0;       // set bits of the current job seen by this workgroup (uniform)
     u32 cntR_thread = 0;          // NCC-only mode: popcount of R accumulated per thread
@@ -594,13 +612,21 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         if (have_tile && round_lo == 0) {
             // phase A: consume the prefetched registers -- tile to LDS, set bits to records (needs no LDS input:
             // the mappability flag of a forward read is a bit of this thread's own M quad)
+#ifdef SP_RESERVE_LATE
             tile_store<HAS_M, CH>(tr, tx, lds, tid);
             SP_STAMP(2)
+#endif
+            // the two cursor atomics go first: their LDS round trips (~400 cycles each under load) run under the
+            // tile stores and the decimation instead of in front of the position loops
             if (!HAS_M) pendR = __popc(tr.r.x) + __popc(tr.r.y) + __popc(tr.r.z) + __popc(tr.r.w);
             iF = emit_reserve(tr.f, &cursor[2 * par]);
             SP_STAMP(8)
             if (HAS_M) iR = emit_reserve(tr.r, &cursor[2 * par + 1]);
             SP_STAMP(9)
+#ifndef SP_RESERVE_LATE
+            tile_store<HAS_M, CH>(tr, tx, lds, tid);
+            SP_STAMP(2)
+#endif
 #ifndef SP_ABL_NOEMIT
             emit_positions(tr.f, HAS_M ? tr.m : tr.f, iF, 0, lds + L::PLF, tid);
             SP_STAMP(10)
@@ -640,26 +666,49 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         }
         u32 nFr = 0, nRr = 0;
         if (have_tile) {
-            nFr = nF > round_lo ? (nF - round_lo < SP_CAP ? nF - round_lo : SP_CAP) : 0u;
-            nRr = nR > round_lo ? (nR - round_lo < SP_CAP ? nR - round_lo : SP_CAP) : 0u;
+            nFr = nF > round_lo ? (nF - round_lo < RCAP ? nF - round_lo : RCAP) : 0u;
+            nRr = nR > round_lo ? (nR - round_lo < RCAP ? nR - round_lo : RCAP) : 0u;
         }
-        const u32 nqF = (nFr + sg.quad_span - 1) >> sg.lg_span;   // quads per slot
-        const u32 nqR = (nRr + sg.quad_span - 1) >> sg.lg_span;
+        // Quads (4 records) are dealt to the waves one wave-iteration (one quad per slot of the wave) at a time: wave w
+        // takes iterations w, w + 4, ...  The waves of a workgroup differ by at most one iteration, and no wave pads
+        // its share up to the workgroup's maximum (164 records in 8 slots: 6 + 5 + 5 + 5 iterations instead of 4 x 6).
+        const u32 lg_spw = 6 - lgG;   // slots per wave = 2^lg_spw
+        const u32 wiF = (((nFr + 3) >> 2) + (1u << lg_spw) - 1) >> lg_spw, wiR = (((nRr + 3) >> 2) + (1u << lg_spw) - 1) >> lg_spw;
+        // ROLES: each role (2 waves) takes ALL forward quads; role B takes all reverse quads as well
+        const bool roleA = wave < 2;
+        const u32 wr = ROLES ? (wave & 1u) : wave;                          // wave index among the waves that share a list
+        const u32 nqF = ROLES ? (wiF + 1) >> 1 : (wiF + 3) >> 2;            // the most any wave has: workgroup-uniform bounds
+        const u32 nqR = ROLES ? (wiR + 1) >> 1 : (wiR + 3) >> 2;
+#ifdef SP_UNBALANCED   // A/B: every wave pads up to the workgroup's maximum, as before
+        const u32 nqFw = nqF, nqRw = nqR;
+#else
+        const u32 nqFw = wr < wiF ? (ROLES ? (wiF - wr + 1) >> 1 : (wiF - wr + 3) >> 2) : 0u;   // this wave's quads per slot
+        const u32 nqRw = (ROLES && roleA) ? 0u : (wr < wiR ? (ROLES ? (wiR - wr + 1) >> 1 : (wiR - wr + 3) >> 2) : 0u);
+#endif
 
         // ---- the one fold / convert site ----
         // registers -> LDS accumulators: when leaving a job, at a tile boundary once enough quads are pending,
         // or (dense tiles only) before a round that would overflow a register counter
         if (leaving || (round_lo == 0 && (qF >= SP_QSOFT || qR >= SP_QSOFT)) || qF + nqF > SP_QLIMIT ||
             qR + nqR > SP_QLIMIT) {
-            if (DO_NCC) counter_to_lds(cN, qF, lgG, tid, stage, acc);
-            if (HAS_M) {
-                counter_to_lds(cF, qF, lgG, tid, stage, acc + 1 * SP_NL * 32);
-                counter_to_lds(cC, qF, lgG, tid, stage, acc + 2 * SP_NL * 32);
-                counter_to_lds(cR, qR, lgG, tid, stage, acc + 3 * SP_NL * 32);
+            if (ROLES) {
+                counter_to_lds(c0, qFw, lgG, tid, stage, acc, roleA);
+                counter_to_lds(c0, qFw, lgG, tid, stage, acc + 1 * SP_NL * 32, !roleA);
+                counter_to_lds(c1, qFw, lgG, tid, stage, acc + 2 * SP_NL * 32, roleA);
+                counter_to_lds(c1, qRw, lgG, tid, stage, acc + 3 * SP_NL * 32, !roleA);
+            } else {
+                if (DO_NCC) counter_to_lds(cN, qFw, lgG, tid, stage, acc);
+                if (HAS_M) {
+                    counter_to_lds(cF, qFw, lgG, tid, stage, acc + 1 * SP_NL * 32);
+                    counter_to_lds(cC, qFw, lgG, tid, stage, acc + 2 * SP_NL * 32);
+                    counter_to_lds(cR, qRw, lgG, tid, stage, acc + 3 * SP_NL * 32);
+                }
             }
             q2 += (qF > qR ? qF : qR) * 4u * sg.total_slots;
             qF = 0;
             qR = 0;
+            qFw = 0;
+            qRw = 0;
         }
         // LDS accumulators -> integers in this workgroup's slab segment of the job (when leaving it, or before the
         // 24-plane accumulators could overflow)
@@ -700,10 +749,56 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         // this slot's record staging region (fixed size, shared by the forward and the reverse pass)
         uint4 *const recs = reinterpret_cast<uint4 *>(lds + L::REC) + (sg.slot << sg.lg_region);
 
+        if (ROLES) {
+            // ---- role-split build: every wave carries two counters ----
+            const u32 rslot = (wr << lg_spw) + (sg.slot & ((1u << lg_spw) - 1)), rstride = 2u << lg_spw;
+            build_forward_records<HAS_M>(lds, recs, rslot, rstride, lane_in_slot, G, nqFw, nFr, c);
+            if (roleA) {
+                for (u32 q = 0; q < nqFw; q++) {
+                    u32 wN[4], wC[4];
+#pragma unroll
+                    for (u32 k = 0; k < 4; k++) {
+                        const uint4 rec = recs[q * 4 + k];
+                        const u32 rw = lds_window(lds, rec.y + sg.l4, rec.x);
+                        wN[k] = rw;
+                        wC[k] = __builtin_bitreverse32(lds_window(lds, rec.z - sg.l4, rec.w)) & rw;
+                    }
+                    const u32 qc = __builtin_amdgcn_readfirstlane(qFw + q);
+                    add_quad(c0, wN[0], wN[1], wN[2], wN[3], qc);
+                    add_quad(c1, wC[0], wC[1], wC[2], wC[3], qc);
+                }
+            } else {
+                for (u32 q = 0; q < nqFw; q++) {
+                    u32 wF[4];
+#pragma unroll
+                    for (u32 k = 0; k < 4; k++) {
+                        const uint4 rec = recs[q * 4 + k];
+                        wF[k] = __builtin_bitreverse32(lds_window(lds, rec.z - sg.l4, rec.w));
+                    }
+                    const u32 qc = __builtin_amdgcn_readfirstlane(qFw + q);
+                    add_quad(c0, wF[0], wF[1], wF[2], wF[3], qc);
+                }
+                build_reverse_records(lds, recs, rslot, rstride, lane_in_slot, G, nqRw, nRr, c);
+                for (u32 q = 0; q < nqRw; q++) {
+                    u32 wR[4];
+#pragma unroll
+                    for (u32 k = 0; k < 4; k++) {
+                        const uint4 rec = recs[q * 4 + k];
+                        wR[k] = lds_window(lds, rec.y - sg.l4, rec.x) & lds_window(lds, rec.z - sg.l4, rec.w);
+                    }
+                    const u32 qc = __builtin_amdgcn_readfirstlane(qRw + q);
+                    add_quad(c1, wR[0], wR[1], wR[2], wR[3], qc);
+                }
+            }
+            qF += nqF;
+            qFw += nqFw;
+            qR += nqR;
+            qRw += nqRw;
+        } else {
         // ---- forward reads drive: ncc, mscc.fsum, mscc.ccbins ----
         {
-            build_forward_records<HAS_M>(lds, recs, sg.slot * 4 * nqF, lane_in_slot, G, nqF, nFr, c);
-            for (u32 q = 0; q < nqF; q++) {
+            build_forward_records<HAS_M>(lds, recs, sg.slot, sg.total_slots, lane_in_slot, G, nqFw, nFr, c);
+            for (u32 q = 0; q < nqFw; q++) {
                 u32 wN[4], wF[4], wC[4];
 #pragma unroll
                 for (u32 k = 0; k < 4; k++) {
@@ -716,7 +811,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                         wC[k] = mw & rw;
                     }
                 }
-                const u32 qc = __builtin_amdgcn_readfirstlane(qF + q);
+                const u32 qc = __builtin_amdgcn_readfirstlane(qFw + q);
                 if (DO_NCC) add_quad(cN, wN[0], wN[1], wN[2], wN[3], qc);
                 if (HAS_M) {
                     add_quad(cF, wF[0], wF[1], wF[2], wF[3], qc);
@@ -724,11 +819,12 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 }
             }
             qF += nqF;
+            qFw += nqFw;
         }
         // ---- reverse reads drive: mscc.rsum ----
         if (HAS_M) {
-            build_reverse_records(lds, recs, sg.slot * 4 * nqR, lane_in_slot, G, nqR, nRr, c);
-            for (u32 q = 0; q < nqR; q++) {
+            build_reverse_records(lds, recs, sg.slot, sg.total_slots, lane_in_slot, G, nqRw, nRr, c);
+            for (u32 q = 0; q < nqRw; q++) {
                 u32 wR[4];
 #pragma unroll
                 for (u32 k = 0; k < 4; k++) {
@@ -737,15 +833,17 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     const u32 w2 = lds_window(lds, rec.z - sg.l4, rec.w);
                     wR[k] = w1 & w2;   // bit i <-> shift 32 l + 31 - i: this counter is kept bit-reversed (see convert)
                 }
-                const u32 qc = __builtin_amdgcn_readfirstlane(qR + q);
+                const u32 qc = __builtin_amdgcn_readfirstlane(qRw + q);
                 add_quad(cR, wR[0], wR[1], wR[2], wR[3], qc);
             }
             qR += nqR;
+            qRw += nqRw;
+        }
         }
         SP_STAMP(6)
 
         // next round of this tile, or next tile (and remember to convert when the job ends here)
-        round_lo += SP_CAP;
+        round_lo += RCAP;
         if (round_lo >= nmax) {
             round_lo = 0;
             if (jn != ji || g + 1 == g1) {
