@@ -113,7 +113,7 @@ def pipe_utilisation(kernel, default_workload):
         return None
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_summary.json")))
-        k = prof["kernels"][kernel]
+        k = prof["kernels"][kernel.split("+")[0]]
         return {"valu_issue": k["valu_issue_util"], "lds_pipe": k["lds_pipe_util"], "waves_per_simd": k.get("waves_per_simd"),
                 "source": "profiles/r2_pmc_summary.json (" + prof.get("how", "rocprofv3 --pmc") + ")"}
     except Exception:
@@ -271,7 +271,7 @@ def main():
     try:
         if default_workload:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
-            key = {ffi.PMX_KERNEL_CC_SPARSE: "k_cc_sparse", ffi.PMX_KERNEL_AUTOCORR: "k_autocorr_edges"}.get(dom)
+            key = {ffi.PMX_KERNEL_CC_SPARSE: "k_cc_sparse", ffi.PMX_KERNEL_AUTOCORR: "k_autocorr_pairs"}.get(dom)
             if key:
                 traffic = prof["mode_both"][key]["hbm_bytes"]
                 traffic_src = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
@@ -358,6 +358,9 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
         },
         "pipe_utilisation": pipe_utilisation(ctx.kernel_name(dom), default_workload),
+        # HIP-event durations on the stream each kernel runs on; the mappable-length pass runs on the context's auxiliary
+        # stream BESIDE k_cc_sparse, so its figure includes the time it waits for CUs and the figures do not add up to
+        # ms_per_step
         "kernel_ms_per_step": kernel_ms_per_step,
         "value_end_to_end": end_to_end["value"] if end_to_end else None,
         "end_to_end": end_to_end,

@@ -871,6 +871,7 @@ struct ReduceSpec {
     u32 out_stride;
     u32 use_out2;       // autocorrelation: rows go to out2 (per-job scratch) instead of the result block
     u32 accumulate;     // ... and are ADDED to what the pair pass left there
+    u32 keep_scalar2;   // scalar [2] (popcount(M)) belongs to the autocorrelation pass, which may run concurrently
     u32 nzero;          // rows of the result block this batch does not produce: written as zeros (chunk 0 only)
     u32 zero_row[5];
 };
@@ -915,8 +916,10 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
         }
     } else if (scalar) {
         u64 *dst = jb.out + (size_t)rs.dst_row[r] * rs.out_stride;
-        for (u32 k = i; k < rs.out_stride; k += gridDim.x * 32)   // [0],[1] sums, [3] path, everything else zero
+        for (u32 k = i; k < rs.out_stride; k += gridDim.x * 32) {   // [0],[1] sums, [3] path, everything else zero
+            if (k == 2 && rs.keep_scalar2) continue;
             dst[k] = k < 2 ? t : (k == 3 ? (u64)PMX_PATH_SPARSE : 0ull);
+        }
     } else if (i < n) {
         jb.out[(size_t)rs.dst_row[r] * rs.out_stride + jb.d_off + i] = t;
     }
@@ -1398,12 +1401,12 @@ k_autocorr_pairs(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
         const u32 n = __builtin_amdgcn_readfirstlane(nd + th);             // + partners above it
         const bool dense = n > AP_CAP;
         u32 *const list = lists + par * AP_CAP;
+        if (!dense) {
 #ifdef AP_ABL_NOEMIT
-        if (max_lag == 0xffffffffu)
+            if (max_lag == 0xffffffffu) {
 #else
-        if (!dense)
+            {
 #endif
-        {
             const u32 e01 = b01 + s01 - (c[0] | (c[1] << 16));   // exclusive, per row
             ap_emit(E[0], ar.m[0], e01 & 0xffffu, 0 * SP_TB + 128u * tid, list);
             ap_emit(E[1], ar.m[1], T0 + (e01 >> 16), 1 * SP_TB + 128u * tid, list);
@@ -1413,6 +1416,7 @@ k_autocorr_pairs(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
                 ap_emit(E[AP_NQ > 2 ? 3 : 0], ar.m[AP_NQ > 2 ? 3 : 0], T0 + T1 + T2 + (e23 >> 16), 3 * SP_TB + 128u * tid, list);
             }
             ap_emit(Eh, ar.h, nd + bh + sh - ch, AP_TB + 128u * tid, list);
+            }
             cntM += pendM;
             cntU += pendU;
         } else if (tid == 0) {
@@ -1702,6 +1706,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     rs.nzero = nz;
     rs.out_stride = out_stride;
     rs.use_out2 = 0;
+    rs.keep_scalar2 = (has_m && !zero_mlen) ? 1 : 0;
 
     for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS) {
         const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS ? vjobs.size() - lo : SP_MAXJOBS);
@@ -1835,21 +1840,21 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         memset(&tab, 0, sizeof tab);
         uint32_t total, tpw, nwg;
         plan_launch(ctx, &vjobs[lo], n, true, chunked ? AC_WAVES_CH : AC_WAVES, &tab, &total, &tpw, &nwg);
-        int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
+        int rc = pmx_ensure_slab_ac(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
         if (rc) return rc;
         pmx_timed_launch tl;
         rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
         if (rc) return rc;
         if (chunked)
             hipLaunchKernelGGL(k_autocorr_edges<true>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,
-                               ctx->d_slab, (const unsigned char *)d_flags, (const u32 *)d_nflagged);
+                               ctx->d_slab_ac, (const unsigned char *)d_flags, (const u32 *)d_nflagged);
         else
             hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,
-                               ctx->d_slab, (const unsigned char *)d_flags, (const u32 *)d_nflagged);
+                               ctx->d_slab_ac, (const unsigned char *)d_flags, (const u32 *)d_nflagged);
         PMX_CHECK_LAUNCH("k_autocorr_edges");
         rc = pmx_prof_end(ctx, &tl);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_reduce_segments, dim3(32, 3, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab,
+        hipLaunchKernelGGL(k_reduce_segments, dim3(32, 3, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab_ac, tab,
                            (u32)AC_SEG_ROWS, rs, (const u32 *)d_nflagged);
         PMX_CHECK_LAUNCH("k_reduce_segments");
     }

@@ -73,6 +73,11 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->slab2_words = 0;
     ctx->d_flags = nullptr;
     ctx->flags_bytes = 0;
+    ctx->d_slab_ac = nullptr;
+    ctx->slab_ac_words = 0;
+    ctx->aux_stream = nullptr;
+    ctx->ev_fork = nullptr;
+    ctx->ev_join = nullptr;
     ctx->d_out_stage = nullptr;
     ctx->out_stage_words = 0;
     ctx->d_pad_stage = nullptr;
@@ -97,6 +102,13 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
         }
         ctx->own_stream = true;
     }
+    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        pmx_set_error("pmx_ctx_create: cannot create the auxiliary stream / events");
+        (void)pmx_ctx_destroy(ctx);
+        return PMX_ERR_HIP;
+    }
     *out = ctx;
     return PMX_OK;
 }
@@ -114,6 +126,7 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (!ctx) return PMX_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     for (auto &tl : ctx->timed) {
         (void)hipEventDestroy(tl.start);
         (void)hipEventDestroy(tl.stop);
@@ -123,6 +136,10 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (ctx->d_slab) (void)hipFree(ctx->d_slab);
     if (ctx->d_slab2) (void)hipFree(ctx->d_slab2);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->d_slab_ac) (void)hipFree(ctx->d_slab_ac);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->d_out_stage) (void)hipFree(ctx->d_out_stage);
     if (ctx->d_pad_stage) (void)hipFree(ctx->d_pad_stage);
     for (int i = 0; i < 3; i++)
@@ -178,6 +195,20 @@ int pmx_ensure_slab2(pmx_ctx *ctx, size_t u32_words)
     }
     PMX_HIP(hipMalloc((void **)&ctx->d_slab2, u32_words * sizeof(u32)));
     ctx->slab2_words = u32_words;
+    return PMX_OK;
+}
+
+int pmx_ensure_slab_ac(pmx_ctx *ctx, size_t u32_words)
+{
+    if (ctx->slab_ac_words >= u32_words) return PMX_OK;
+    if (ctx->d_slab_ac) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(ctx->d_slab_ac));
+        ctx->d_slab_ac = nullptr;
+        ctx->slab_ac_words = 0;
+    }
+    PMX_HIP(hipMalloc((void **)&ctx->d_slab_ac, u32_words * sizeof(u32)));
+    ctx->slab_ac_words = u32_words;
     return PMX_OK;
 }
 
@@ -312,7 +343,7 @@ const char *pmx_kernel_name(int kernel_id)
     switch (kernel_id) {
     case PMX_KERNEL_CC_DENSE: return "k_cc_dense";
     case PMX_KERNEL_CC_SPARSE: return "k_cc_sparse";
-    case PMX_KERNEL_AUTOCORR: return "k_autocorr_edges";
+    case PMX_KERNEL_AUTOCORR: return "k_autocorr_pairs+edges";
     default: return "?";
     }
 }
@@ -613,12 +644,26 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             jobs[i].d_out = d_out[lo + i];
             jobs[i].d_out2 = has_m ? (uint64_t *)(ctx->d_scratch + (size_t)i * ac_words) : nullptr;
         }
-        int rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, !do_mlen);
-        if (rc) return rc;
+        // fork: the mappable-length pass on the auxiliary stream, beside the set-bit kernel (they share no output word:
+        // row MLEN and scalar [2] belong to the autocorrelation, everything else to the cross-correlation)
+        int rc;
         if (do_mlen) {
+            PMX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            PMX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+            hipStream_t main_stream = ctx->stream;
+            ctx->stream = ctx->aux_stream;       // the launchers enqueue on ctx->stream (a context is single-threaded)
             rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
+            hipError_t er = rc ? hipSuccess : hipEventRecord(ctx->ev_join, ctx->aux_stream);
+            ctx->stream = main_stream;
             if (rc) return rc;
+            if (er != hipSuccess) {
+                pmx_set_error("hipEventRecord(ev_join) failed: %s", hipGetErrorString(er));
+                return PMX_ERR_HIP;
+            }
         }
+        rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, !do_mlen);
+        if (rc) return rc;
+        if (do_mlen) PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join
     }
     return PMX_OK;
 }

@@ -39,8 +39,12 @@ struct pmx_timed_launch {
 
 struct pmx_ctx {
     int device;
-    hipStream_t stream;
+    hipStream_t stream;          // the stream launches are enqueued on (the caller's, or our own)
     bool own_stream;
+    // The mappable-length pass only reads M and writes its own row: it runs on a second stream beside the set-bit kernel
+    // (fork / join events on `stream`), so its chain of small launches hides under k_cc_sparse.
+    hipStream_t aux_stream;
+    hipEvent_t ev_fork, ev_join;
     int num_cus;
     bool profiling;
     std::vector<pmx_timed_launch> timed;       // launches not yet folded into the totals
@@ -58,6 +62,8 @@ struct pmx_ctx {
     size_t slab2_words;
     unsigned char *d_flags;
     size_t flags_bytes;
+    u32 *d_slab_ac;              // slab of the window autocorrelation kernel (separate: it may run beside k_cc_sparse)
+    size_t slab_ac_words;
     // staging for the host-pointer entry points
     uint64_t *d_stage[3];
     size_t stage_words[3];
@@ -99,12 +105,14 @@ uint32_t pmx_sparse_max_jobs(void);
 // (rows the batch does not produce are written as zeros, MLEN included when there is no mappability).
 int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
                                uint32_t read_len, bool do_ncc, uint32_t out_stride, bool zero_mlen);
+// zero_mlen == false: the autocorrelation pass (possibly running concurrently) owns row MLEN and scalar [2]: both are left alone
 // Run-edge autocorrelation of every job's d_M.  mode 0: d_out[k] = A(k), k <= max_lag.
 // mode 1: d_out is a result block: row MLEN[d] = A(|read_len - 1 - d|), d <= max_shift; scalar [2] = popcount(M).
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag,
                                     uint32_t mode, uint32_t read_len, uint32_t max_shift, uint32_t out_stride);
 int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_slab2(pmx_ctx *ctx, size_t u32_words);
+int pmx_ensure_slab_ac(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_flags(pmx_ctx *ctx, size_t bytes);
 size_t pmx_autocorr_scratch_words(uint32_t max_lag);
 // out[k] = sum_j M[j] & M[j+k], k = 0..max_lag
