@@ -164,6 +164,36 @@ __device__ __forceinline__ void add_quad(Planes &c, u32 w0, u32 w1, u32 w2, u32 
     }
 }
 
+// Two quads at once (8 windows): the two weight-4 carries pair with EACH OTHER (no parity at that level: a parked Q2
+// stays parked), so only the weight-8 carry goes through the parked-carry branch -- one wave-uniform branch per 8
+// windows and counter instead of three.  quadcnt as in add_quad; the caller advances it by 2.
+__device__ __forceinline__ u32 quad_carry(Planes &c, u32 w0, u32 w1, u32 w2, u32 w3)
+{
+    u32 c1a, c1b, c2;
+    csa(c.P[0], w0, w1, c1a);
+    csa(c.P[0], w2, w3, c1b);
+    csa(c.P[1], c1a, c1b, c2);
+    return c2;
+}
+
+__device__ __forceinline__ void add_carry_pair(Planes &c, u32 c2a, u32 c2b, u32 quadcnt)
+{
+    u32 c3;
+    csa(c.P[2], c2a, c2b, c3);
+    if ((quadcnt & 2u) == 0u) {
+        c.Q3 = c3;
+    } else {
+        u32 cy;
+        csa(c.P[3], c.Q3, c3, cy);
+#pragma unroll
+        for (int l = 4; l < SP_NP; l++) {   // half adders
+            const u32 t = c.P[l] & cy;
+            c.P[l] ^= cy;
+            cy = t;
+        }
+    }
+}
+
 // full adder on bit planes
 __device__ __forceinline__ void fa(u32 a, u32 b, u32 cin, u32 &s, u32 &cout)
 {
@@ -431,10 +461,14 @@ __device__ __forceinline__ u32 emit_reserve(const uint4 w, u32 *cursor)
 
 // Stage 1 of the compaction (phase A, divergent loops, so the body is kept minimal): position of every set bit,
 // with one flag bit (forward read mappable / falling edge), into an LDS list.
+// CHECKED = false: the caller knows that all of this thread's entries fit the list (id + popcount <= SP_CAP): the
+// capacity test leaves the loop body
+template <bool WIDE = false, bool CHECKED = true>
 __device__ __forceinline__ void emit_positions(const uint4 w, const uint4 flag_bits, u32 idx0, u32 round_lo, u32 *list, u32 tid,
                                                u32 base = 0)
 {
     u32 id = idx0 - round_lo;   // unsigned: entries before the round wrap to huge values
+    if (!WIDE) {   // one loop per dword
     const u32 ws[4] = {w.x, w.y, w.z, w.w};
     const u32 fs[4] = {flag_bits.x, flag_bits.y, flag_bits.z, flag_bits.w};
 #pragma unroll
@@ -443,10 +477,44 @@ __device__ __forceinline__ void emit_positions(const uint4 w, const uint4 flag_b
         while (ww) {
             const u32 b = __builtin_ctz(ww);
             ww &= ww - 1;
-            if (id < SP_CAP) list[id] = (base + 128u * tid + 32u * k + b) | (((fs[k] >> b) & 1u) << 16);
+            if (!CHECKED || id < SP_CAP) list[id] = (base + 128u * tid + 32u * k + b) | (((fs[k] >> b) & 1u) << 16);
             id++;
         }
     }
+    } else {
+    // the quad is walked as two 64-bit words: every loop costs its ~25 instructions of control flow per trip whether or
+    // not one of the 64 lanes has a bit, and at read densities a 64-bit word rarely needs more trips than a dword.
+    // Measured on config 4: NCC+MSCC -5.3 % (0.936 -> 0.886 ms); the NCC-only instantiation (80 VGPRs, 6 waves) +7 %,
+    // so it keeps the dword loops.
+    const u64 ws[2] = {(u64)w.x | ((u64)w.y << 32), (u64)w.z | ((u64)w.w << 32)};
+    const u64 fs[2] = {(u64)flag_bits.x | ((u64)flag_bits.y << 32), (u64)flag_bits.z | ((u64)flag_bits.w << 32)};
+#pragma unroll
+    for (u32 k = 0; k < 2; k++) {
+        u64 ww = ws[k];
+        while (ww) {
+            const u32 b = (u32)__builtin_ctzll(ww);
+            ww &= ww - 1;
+            if (!CHECKED || id < SP_CAP) list[id] = (base + 128u * tid + 64u * k + b) | ((u32)((fs[k] >> b) & 1ull) << 16);
+            id++;
+        }
+    }
+    }
+}
+
+// round 0 of a tile: threads whose entries all fit (every thread, unless a vector has more than SP_CAP set bits in the
+// tile) take the loop without the capacity test
+template <bool WIDE>
+__device__ __forceinline__ void emit_positions_round0(const uint4 w, const uint4 flag_bits, u32 idx0, u32 *list, u32 tid)
+{
+#ifdef SP_EMIT_CHECKED
+    emit_positions<WIDE, true>(w, flag_bits, idx0, 0, list, tid);
+#else
+    const u32 n = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+    if (idx0 + n <= SP_CAP)
+        emit_positions<WIDE, false>(w, flag_bits, idx0, 0, list, tid);
+    else
+        emit_positions<WIDE, true>(w, flag_bits, idx0, 0, list, tid);
+#endif
 }
 
 // Stage 2 (after B1, no divergence): every slot turns ITS share of the positions into 16-byte records in its own
@@ -562,6 +630,11 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     for (u32 i = tid; i < L::NCOUNTERS * SP_NL * 32; i += 256) acc[i] = 0;
 
     constexpr bool ROLES = SP_ROLES && HAS_M && DO_NCC && !CH;
+#ifdef SP_NOPAIRS
+    constexpr bool QUAD_PAIRS = false;
+#else
+    constexpr bool QUAD_PAIRS = !HAS_M;
+#endif
     constexpr u32 RCAP = ROLES ? SP_CAP / 2 : SP_CAP;   // records of one list a round can take (a role has half the slots)
     Planes cN, cF, cC, cR;
     planes_zero(cN);
@@ -628,9 +701,9 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             SP_STAMP(2)
 #endif
 #ifndef SP_ABL_NOEMIT
-            emit_positions(tr.f, HAS_M ? tr.m : tr.f, iF, 0, lds + L::PLF, tid);
+            emit_positions_round0<HAS_M>(tr.f, HAS_M ? tr.m : tr.f, iF, lds + L::PLF, tid);
             SP_STAMP(10)
-            if (HAS_M) emit_positions(tr.r, tr.r, iR, 0, lds + L::PLR, tid);
+            if (HAS_M) emit_positions_round0<HAS_M>(tr.r, tr.r, iR, lds + L::PLR, tid);
 #endif
             if (tid < 2) cursor[2 * (par ^ 1) + tid] = 0;   // next tile's cursors (last read before B0)
             SP_STAMP(3)
@@ -680,11 +753,19 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         const u32 nqF = ROLES ? (wiF + 1) >> 1 : (wiF + 3) >> 2;            // the most any wave has: workgroup-uniform bounds
         const u32 nqR = ROLES ? (wiR + 1) >> 1 : (wiR + 3) >> 2;
 #ifdef SP_UNBALANCED   // A/B: every wave pads up to the workgroup's maximum, as before
-        const u32 nqFw = nqF, nqRw = nqR;
+        const u32 nqFw = nqF, nqRw = nqR, wrR = wr;
 #else
         const u32 nqFw = wr < wiF ? (ROLES ? (wiF - wr + 1) >> 1 : (wiF - wr + 3) >> 2) : 0u;   // this wave's quads per slot
-        const u32 nqRw = (ROLES && roleA) ? 0u : (wr < wiR ? (ROLES ? (wiR - wr + 1) >> 1 : (wiR - wr + 3) >> 2) : 0u);
+        // the reverse quads are dealt in the opposite wave order (wave 3 first), so the odd iteration of each list
+        // lands on a different wave: the tile's critical wave carries 6 + 5 iterations instead of 6 + 6
+#ifdef SP_RDEAL_SAME
+        const u32 wrR = wr;
+#else
+        const u32 wrR = ROLES ? wr : 3u - wave;
 #endif
+        const u32 nqRw = (ROLES && roleA) ? 0u : (wrR < wiR ? (ROLES ? (wiR - wrR + 1) >> 1 : (wiR - wrR + 3) >> 2) : 0u);
+#endif
+        const u32 rslotR = (wrR << lg_spw) + (sg.slot & ((1u << lg_spw) - 1));   // this slot's place in the reverse dealing
 
         // ---- the one fold / convert site ----
         // registers -> LDS accumulators: when leaving a job, at a tile boundary once enough quads are pending,
@@ -798,7 +879,40 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         // ---- forward reads drive: ncc, mscc.fsum, mscc.ccbins ----
         {
             build_forward_records<HAS_M>(lds, recs, sg.slot, sg.total_slots, lane_in_slot, G, nqFw, nFr, c);
-            for (u32 q = 0; q < nqFw; q++) {
+            u32 q = 0;
+            // two quads per trip: one parked-carry branch per counter (add_carry_pair).  NCC-only: -3 % (0.296 -> 0.286 ms);
+            // with mappability the three extra live carries push the allocation into scratch and nothing is gained, so
+            // that instantiation keeps one quad per trip
+            for (; QUAD_PAIRS && q + 1 < nqFw; q += 2) {
+                u32 c2N[2], c2F[2], c2C[2];
+#pragma unroll
+                for (u32 h = 0; h < 2; h++) {
+                    u32 wN[4], wF[4], wC[4];
+#pragma unroll
+                    for (u32 k = 0; k < 4; k++) {
+                        const uint4 rec = recs[(q + h) * 4 + k];
+                        const u32 rw = lds_window(lds, rec.y + sg.l4, rec.x);
+                        wN[k] = rw;
+                        if (HAS_M) {
+                            const u32 mw = __builtin_bitreverse32(lds_window(lds, rec.z - sg.l4, rec.w));
+                            wF[k] = mw;
+                            wC[k] = mw & rw;
+                        }
+                    }
+                    if (DO_NCC) c2N[h] = quad_carry(cN, wN[0], wN[1], wN[2], wN[3]);
+                    if (HAS_M) {
+                        c2F[h] = quad_carry(cF, wF[0], wF[1], wF[2], wF[3]);
+                        c2C[h] = quad_carry(cC, wC[0], wC[1], wC[2], wC[3]);
+                    }
+                }
+                const u32 qc = __builtin_amdgcn_readfirstlane(qFw + q);
+                if (DO_NCC) add_carry_pair(cN, c2N[0], c2N[1], qc);
+                if (HAS_M) {
+                    add_carry_pair(cF, c2F[0], c2F[1], qc);
+                    add_carry_pair(cC, c2C[0], c2C[1], qc);
+                }
+            }
+            for (; q < nqFw; q++) {
                 u32 wN[4], wF[4], wC[4];
 #pragma unroll
                 for (u32 k = 0; k < 4; k++) {
@@ -823,8 +937,23 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         }
         // ---- reverse reads drive: mscc.rsum ----
         if (HAS_M) {
-            build_reverse_records(lds, recs, sg.slot, sg.total_slots, lane_in_slot, G, nqRw, nRr, c);
-            for (u32 q = 0; q < nqRw; q++) {
+            build_reverse_records(lds, recs, rslotR, sg.total_slots, lane_in_slot, G, nqRw, nRr, c);
+            u32 q = 0;
+            for (; QUAD_PAIRS && q + 1 < nqRw; q += 2) {
+                u32 c2R[2];
+#pragma unroll
+                for (u32 h = 0; h < 2; h++) {
+                    u32 wR[4];
+#pragma unroll
+                    for (u32 k = 0; k < 4; k++) {
+                        const uint4 rec = recs[(q + h) * 4 + k];
+                        wR[k] = lds_window(lds, rec.y - sg.l4, rec.x) & lds_window(lds, rec.z - sg.l4, rec.w);
+                    }
+                    c2R[h] = quad_carry(cR, wR[0], wR[1], wR[2], wR[3]);
+                }
+                add_carry_pair(cR, c2R[0], c2R[1], __builtin_amdgcn_readfirstlane(qRw + q));
+            }
+            for (; q < nqRw; q++) {
                 u32 wR[4];
 #pragma unroll
                 for (u32 k = 0; k < 4; k++) {
