@@ -114,7 +114,8 @@ def pipe_utilisation(kernel, default_workload):
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_summary.json")))
         k = prof["kernels"][kernel.split("+")[0]]
-        return {"valu_issue": k["valu_issue_util"], "lds_pipe": k["lds_pipe_util"], "waves_per_simd": k.get("waves_per_simd"),
+        return {"valu_issue": k["valu_issue_util"], "lds_pipe": k["lds_pipe_util"],
+                "wave_cycles_issuing": k.get("wave_cycles_issuing"), "wave_cycles_waiting": k.get("wave_cycles_waiting"),
                 "source": "profiles/r2_pmc_summary.json (" + prof.get("how", "rocprofv3 --pmc") + ")"}
     except Exception:
         return None
