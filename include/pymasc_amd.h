@@ -85,7 +85,9 @@ int pmx_bits_clear(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits);
 int pmx_bits_upload(pmx_ctx *ctx, uint64_t *d_words, const uint64_t *h_words, uint64_t nbits);
 int pmx_bits_download(pmx_ctx *ctx, const uint64_t *d_words, uint64_t *h_words, uint64_t nbits);
 /* bitarray[pos] = 1 for every pos (feed_forward_read mscc.pyx:393, feed_reverse_read :416-417);
- * positions are bit indices, duplicates allowed; any pos >= nbits or < 0 -> PMX_ERR_INVALID. */
+ * positions are bit indices, duplicates allowed; any pos >= nbits or < 0 -> PMX_ERR_INVALID (host variant: the range
+ * check runs on the device, so the bits of the in-range positions have been set when the error is reported; dev
+ * variant: out-of-range positions are dropped). */
 int pmx_bits_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits,
                            const int64_t *h_pos, uint64_t n);
 int pmx_bits_set_positions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits,

@@ -3,14 +3,20 @@
 #include "pmx_common.h"
 
 // bitarray[pos] = 1 (mscc.pyx:393, :416-417). One lane per read; 64-bit atomic OR because many
-// reads share a word.  Out-of-range positions are dropped (the host entry point validates first).
+// reads share a word.  Out-of-range positions are dropped; with `bad` != null the smallest offending index is
+// recorded there (the host entry point reads it back instead of scanning the positions on the CPU first: for the
+// 31 M reads of the benchmark genome that scan was half of the end-to-end time).
 __global__ void __launch_bounds__(256) k_set_positions(u64 *__restrict__ words, uint64_t nbits,
-                                                       const int64_t *__restrict__ pos, uint64_t n)
+                                                       const int64_t *__restrict__ pos, uint64_t n,
+                                                       u64 *__restrict__ bad)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (uint64_t)gridDim.x * blockDim.x) {
         const int64_t p = pos[i];
-        if (p >= 0 && (uint64_t)p < nbits) atomicOr(&words[p >> 6], 1ull << (p & 63));
+        if (p >= 0 && (uint64_t)p < nbits)
+            atomicOr(&words[p >> 6], 1ull << (p & 63));
+        else if (bad)
+            atomicMin(bad, (u64)i);
     }
 }
 
@@ -65,11 +71,12 @@ static int grid_for(pmx_ctx *ctx, uint64_t items, int per_block)
     return (int)blocks;
 }
 
-int pmx_launch_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_pos, uint64_t n)
+int pmx_launch_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_pos, uint64_t n,
+                             u64 *d_bad)
 {
     if (n == 0) return PMX_OK;
     hipLaunchKernelGGL(k_set_positions, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream,
-                       (u64 *)d_words, nbits, d_pos, n);
+                       (u64 *)d_words, nbits, d_pos, n, d_bad);
     PMX_CHECK_LAUNCH("k_set_positions");
     return PMX_OK;
 }

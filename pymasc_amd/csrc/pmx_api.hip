@@ -427,18 +427,26 @@ int pmx_bits_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, cons
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && (h_pos || n == 0), "pmx_bits_set_positions: NULL argument");
     if (n == 0) return PMX_OK;
-    for (uint64_t i = 0; i < n; i++)
-        if (h_pos[i] < 0 || (uint64_t)h_pos[i] >= nbits) {
-            pmx_set_error("pmx_bits_set_positions: position %lld at index %llu outside [0, %llu)",
-                          (long long)h_pos[i], (unsigned long long)i, (unsigned long long)nbits);
-            return PMX_ERR_INVALID;
-        }
+    // positions are range-checked by the kernel itself (the smallest bad index comes back with the synchronisation this
+    // entry point does anyway); on PMX_ERR_INVALID the bits of the valid positions have been set
     int rc = ensure_stage(ctx, 0, n);
     if (rc) return rc;
-    PMX_HIP(hipMemcpyAsync(ctx->d_stage[0], h_pos, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    rc = pmx_launch_set_positions(ctx, d_words, nbits, (const int64_t *)ctx->d_stage[0], n);
+    rc = pmx_ensure_scratch(ctx, 4096);
     if (rc) return rc;
+    u64 *d_bad = ctx->d_scratch + 8;
+    const u64 none = ~0ull;
+    PMX_HIP(hipMemcpyAsync(d_bad, &none, sizeof none, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(ctx->d_stage[0], h_pos, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = pmx_launch_set_positions(ctx, d_words, nbits, (const int64_t *)ctx->d_stage[0], n, d_bad);
+    if (rc) return rc;
+    u64 bad = none;
+    PMX_HIP(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));   // h_pos and the staging buffer may be reused by the caller
+    if (bad != none) {
+        pmx_set_error("pmx_bits_set_positions: position %lld at index %llu outside [0, %llu)", (long long)h_pos[bad],
+                      (unsigned long long)bad, (unsigned long long)nbits);
+        return PMX_ERR_INVALID;
+    }
     return PMX_OK;
 }
 

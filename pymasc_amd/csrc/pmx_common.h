@@ -81,7 +81,8 @@ int pmx_ensure_scratch(pmx_ctx *ctx, size_t words);
 
 // ---- launchers implemented next to their kernels --------------------------------------------
 // bits (kernels_bits.hip)
-int pmx_launch_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_pos, uint64_t n);
+int pmx_launch_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_pos, uint64_t n,
+                             u64 *d_bad = nullptr);   // d_bad: device u64, receives the smallest out-of-range index
 int pmx_launch_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_from,
                            const int64_t *d_to, uint64_t n);
 int pmx_launch_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, u64 *d_count /* += */);
