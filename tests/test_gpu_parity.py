@@ -148,6 +148,19 @@ def test_mappable_len_sparse_and_dense_edge_regions_in_one_track(ctx):
     check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
 
 
+@pytest.mark.parametrize("mean_on,mean_off", [(800, 224), (400, 112), (1500, 548)])
+@pytest.mark.parametrize("max_shift", [1000, 4000])
+def test_mappable_len_around_the_dense_tile_threshold(ctx, mean_on, mean_off, max_shift):
+    """Run periods of ~1024 / 512 / 2048 bits put the 128-Kbit tiles of the pair pass right at, above and below its
+    256-edge threshold (geometric run lengths: neighbouring tiles fall on different sides); every lag must add up
+    whichever pass took a tile.  max_shift 4000: histograms of 4 K lags per workgroup, window kernel in lag chunks."""
+    G = 1_500_000
+    nbits = G + 36 + max_shift + 100
+    M = synth.run_bits(np.random.default_rng(1000 + mean_on + max_shift), nbits, mean_on, mean_off, 1, nbits)
+    ref = oracle.mappable_len_readless(M, nbits, max_shift)
+    np.testing.assert_array_equal(ctx.mappable_len(M, nbits, max_shift, 0).astype(np.int64), ref)
+
+
 def test_skip_ncc(ctx):
     nbits, F, R, M = synth.make_case(11, 30000, 200, 36)
     ref = oracle.calc_correlation(F, R, M, nbits, 200, 36, skip_ncc=True)
