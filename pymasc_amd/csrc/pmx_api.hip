@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -654,8 +655,16 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         }
         // fork: the mappable-length pass on the auxiliary stream, beside the set-bit kernel (they share no output word:
         // row MLEN and scalar [2] belong to the autocorrelation, everything else to the cross-correlation)
+        // PMX_AUTOCORR_FORK=0 in the environment keeps everything on the caller's stream (per-kernel profiling)
+        static const bool fork_enabled = [] {
+            const char *e = getenv("PMX_AUTOCORR_FORK");
+            return !(e && e[0] == '0');
+        }();
         int rc;
-        if (do_mlen) {
+        if (do_mlen && !fork_enabled) {
+            rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
+            if (rc) return rc;
+        } else if (do_mlen) {
             PMX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
             PMX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
             hipStream_t main_stream = ctx->stream;
@@ -671,7 +680,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         }
         rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, !do_mlen);
         if (rc) return rc;
-        if (do_mlen) PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join
+        if (do_mlen && fork_enabled) PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join
     }
     return PMX_OK;
 }

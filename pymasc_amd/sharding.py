@@ -198,7 +198,7 @@ def run_sharded(bam_path, max_shift: int, read_len: int, mapq_criteria: int, big
             finally:
                 if bw is not None:
                     bw.close()
-    except BaseException as e:          # surfaced on every rank by the gather below
+    except Exception as e:              # surfaced on every rank by the gather below
         if not on or world == 1:
             raise
         error = e
