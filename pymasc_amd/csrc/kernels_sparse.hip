@@ -605,6 +605,18 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 #define SP_WAVES_NCC 6             // waves per SIMD of the NCC-only instantiation (1 counter; measured 4: 0.334, 5: 0.309,
                                    // 6: 0.300, 7: 0.311, 8: 0.473 ms on the benchmark genome)
 #endif
+// s_setprio per phase.  Any phase of the tile loop raised above the bookkeeping / barrier code (priority 0) is worth
+// 5-6 % on config 4 (k_cc_sparse alone, same box: 0.851 -> 0.799 ms with staging 3 / record loops 2; 0.80-0.81 for every
+// other assignment tried, including staging only or record loops only): with equal priorities the SIMD arbitrates by
+// age, the waves of the oldest workgroup win every cycle they can issue, and the co-resident workgroups move in lockstep
+// through the same phases; with phase priorities a wave that is ready to do tile work is never behind one that is
+// spinning towards a barrier.
+#ifndef SP_PRIO_STAGE
+#define SP_PRIO_STAGE 3
+#endif
+#ifndef SP_PRIO_PROCESS
+#define SP_PRIO_PROCESS 2
+#endif
 #ifndef SP_ROLES
 #define SP_ROLES 0                 // 1: waves 0-1 carry (ncc, mscc.ccbins), waves 2-3 (mscc.fsum, mscc.rsum) -- A/B build
 #endif
@@ -683,6 +695,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         __syncthreads();   // B0: everyone is done with the previous tile's (round's) LDS
         SP_STAMP(0)
         if (have_tile && round_lo == 0) {
+            if (SP_PRIO_STAGE) __builtin_amdgcn_s_setprio(SP_PRIO_STAGE);
             // phase A: consume the prefetched registers -- tile to LDS, set bits to records (needs no LDS input:
             // the mappability flag of a forward read is a bit of this thread's own M quad)
 #ifdef SP_RESERVE_LATE
@@ -716,6 +729,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 tile_fetch_job<HAS_M, CH>(tr, tx, pj, g + 1 - pj.tile0, tid);
             }
             SP_STAMP(4)
+            if (SP_PRIO_STAGE) __builtin_amdgcn_s_setprio(0);
             __syncthreads();   // B1: tile and records visible
             SP_STAMP(5)
 #ifdef SP_ABL_NOPROC
@@ -829,6 +843,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         }
         // this slot's record staging region (fixed size, shared by the forward and the reverse pass)
         uint4 *const recs = reinterpret_cast<uint4 *>(lds + L::REC) + (sg.slot << sg.lg_region);
+        if (SP_PRIO_PROCESS) __builtin_amdgcn_s_setprio(SP_PRIO_PROCESS);
 
         if (ROLES) {
             // ---- role-split build: every wave carries two counters ----
@@ -969,6 +984,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             qRw += nqRw;
         }
         }
+        if (SP_PRIO_PROCESS) __builtin_amdgcn_s_setprio(0);
         SP_STAMP(6)
 
         // next round of this tile, or next tile (and remember to convert when the job ends here)
