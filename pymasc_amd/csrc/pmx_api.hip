@@ -660,8 +660,11 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             const char *e = getenv("PMX_AUTOCORR_FORK");
             return !(e && e[0] == '0');
         }();
+        // beside the shift-chunked instantiation (max_shift > 1023) the fork does not pay (config 5 on one GPU: 17.4 ms
+        // forked, 16.5 ms in sequence): the pair pass then holds 40 KB of histograms per workgroup
+        const bool fork = fork_enabled && max_shift <= 1023;
         int rc;
-        if (do_mlen && !fork_enabled) {
+        if (do_mlen && !fork) {
             rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
             if (rc) return rc;
         } else if (do_mlen) {
@@ -680,7 +683,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         }
         rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, !do_mlen);
         if (rc) return rc;
-        if (do_mlen && fork_enabled) PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join
+        if (do_mlen && fork) PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join
     }
     return PMX_OK;
 }
