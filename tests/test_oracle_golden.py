@@ -115,3 +115,17 @@ def test_bruteforce_definition_small():
         assert out["mscc_forward_sum"][d] == sum(int(f[j]) & D[j] for j in range(nbits))
         assert out["mscc_reverse_sum"][d] == sum(R(j + d) & D[j] for j in range(nbits))
         assert out["mscc_ccbins"][d] == sum(int(f[j]) & R(j + d) & D[j] for j in range(nbits))
+
+
+def test_fixture_read_counts_match_the_reference_summary():
+    """The reference's own summary of its test BAM (tests/integration/expected_results/encode_data_summary.json:
+    total_reads 2501, all on chr1, chr1_valid_reads 1292) against the fixture the
+    parity tests are fed from: 1292 = 622 forward + 670 reverse reads after the -q 10 filter."""
+    import csv
+    import os
+    with open(os.path.join(fx.GOLDEN, "ENCFF000RMB-test.reads.tsv")) as fh:
+        rows = list(csv.reader(fh, delimiter="\t"))[1:]
+    assert len(rows) == 2501 and {r[1] for r in rows} == {"chr1"}
+    reads = fx.load_reads(mapq=10)
+    assert len(reads) == 1292
+    assert (sum(1 for r in reads if not r[0]), sum(1 for r in reads if r[0])) == (622, 670)
