@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["hg38", "stress"], default="hg38",
                     help="hg38: BASELINE config 4 (default, the metric's configuration); stress: config 5, one "
                          "synthetic 10 Gbp / 200-chromosome genome sharded over the ranks, max_shift 5000")
