@@ -1,0 +1,516 @@
+// Event-driven cross-correlation for sparse tiles (gfx950).  Included by kernels_sparse.hip (job table, loaders, scans).
+//
+// Same sums as k_cc_sparse (mscc.pyx:288-317), enumerated as EVENTS between sorted position lists instead of as
+// windows: on read-occupancy vectors (0.5 % density) and a mappability track (one run edge per ~1200 bits) a 64-Kbit
+// tile holds ~330 forward reads, ~330 reverse reads and ~55 run edges, and every output is a short sum over pairs:
+//
+//   ncc[d]       = #{(x in F, y in R) : y - x = d}                                            one event per pair
+//   mscc.cc[d]   = #{(x in F&M, y in R) : y - x = d, M[x + c - d]}     (c = read_len - 1)     + one bit of M per pair
+//   mscc.fsum[d] = sum_{x in F&M} M[x + c - d]: as a function of d this is a step function that changes only where
+//                  x + c - d crosses a run edge.  With E[j] = M[j] - M[j-1]:
+//                  M[x+c-d] = M[x+c] - sum_{j = x+c-d+1 .. x+c} E[j], so
+//                  fsum[d] = Bf - sum_{t=1..d} GF[t],  Bf = sum_x M[x+c],  GF[t] = sum_x E[x+c-t+1]   (x in F&M)
+//                  -> one signed event per (forward read, edge within max_shift below x + c)
+//   mscc.rsum[d] = sum_{p in R} a_p(d) b_p(d),  a_p(d) = M[p-d],  b_p(d) = M[p+c-2d]:
+//                  a(d)b(d) - a(d-1)b(d-1) = [a(d)-a(d-1)] b(d) + a(d-1) [b(d)-b(d-1)]
+//                  a(d)-a(d-1) = -E[p-d+1]                    -> edge j = p-d+1:        GR[d] -= E[j] M[p+c-2d]   (type A)
+//                  b(d)-b(d-1) = -E[p+c-2d+1] - E[p+c-2d+2]   -> d = (p+c-j+2) >> 1:    GR[d] -= E[j] M[p-d+1]    (type B)
+//                  rsum[d] = R0 + sum_{t=1..d} GR[t],  R0 = sum_p M[p] M[p+c]
+// All integer arithmetic; the histograms GF / GR are signed and k_events_finish takes their prefix sums.
+//
+// The lists are SORTED (position order comes out of block-wide scans of the per-thread popcounts), and the first
+// partner of every driver is known without searching: the rank of a position among the R bits of the tile is a
+// popcount of the emitting thread's own registers; among the edges it is a per-dword prefix count (u16 in LDS) plus a
+// masked popcount of one edge word.  Cost follows the number of events (~2700 per tile), not tile size x shift range.
+//
+// Tiles whose lists would overflow (dense vectors: tests, pathological tracks) are flagged and left to k_cc_sparse,
+// which then processes the flagged tiles only; its sums are added to what this pass wrote.
+#pragma once
+
+#define EV_NQ 2u                          // driver quads per thread and vector: a tile is EV_NQ x 32 Kbit
+#define EV_TBW (EV_NQ * SP_TBW)           // 2048 dwords
+#define EV_TB (EV_NQ * SP_TB)             // 65536 bits
+#define EV_LO 64u                         // dwords of M staged below the tile (2 x max_shift bits)
+#define EV_HI 36u                         // ... and above it (read_len - 1 bits, + the partners' M bits)
+#define EV_MW (EV_LO + EV_TBW + EV_HI)    // 2148 dwords
+#define EV_BIAS (EV_LO * 32u)             // list positions are relative to the first staged bit of M
+#define EV_CAPF 512u                      // list capacities = the dense-tile thresholds
+#define EV_CAPR 640u                      // reverse reads of the tile + of the max_shift bits above it
+#define EV_CAPE 384u                      // run edges of everything staged
+#define EV_POS 0x1ffffu                   // 17 bits of biased position
+#ifndef EV_WAVES
+#define EV_WAVES 4
+#endif
+#ifndef EV_WAVES_NCC
+#define EV_WAVES_NCC 6
+#endif
+
+#ifdef EV_STAMPS   // diagnostic build: where does a tile's time go (never defined in the shipped library)
+#define EV_NSTAMP 12
+#define EV_STAMP(i)                                                                                    \
+    {                                                                                                  \
+        unsigned long long t_;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        stamp_acc[i] += t_ - stamp_last;                                                               \
+        stamp_last = t_;                                                                               \
+    }
+#else
+#define EV_STAMP(i)
+#endif
+
+template <bool HAS_M>
+struct EvLds {
+    static constexpr u32 HIST = 0;                                  // rows of 1024 i32: ncc, GF, cc, GR (NCC-only: ncc)
+    static constexpr u32 MT0 = HIST + (HAS_M ? 4096u : 1024u);      // [3] = the dword below the staged range, [4..] = M
+    static constexpr u32 PREF = MT0 + (HAS_M ? 4u + EV_MW : 0u);    // u16 per staged dword: edges before it
+    static constexpr u32 LF = PREF + (HAS_M ? (EV_MW + 3) / 4 * 2 : 0u);
+    static constexpr u32 LR = LF + EV_CAPF;
+    static constexpr u32 LE = LR + EV_CAPR + 2;                     // (+2: the event loops read two entries per trip)
+    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE + 2 : 0u);          // [5][4 waves] scan totals
+    static constexpr u32 MISC = WT + 32;
+    static constexpr u32 TOTAL = MISC + 16;
+};
+
+struct EvRegs {
+    uint4 f[EV_NQ], r[EV_NQ], m[EV_NQ], h;   // quad q covers dwords q*1024 + 4 tid ..; h: one halo quad (see ev_fetch)
+    u32 mb[EV_NQ], hb;                       // the dword of M below m[q] / below h
+};
+
+// halo quads, one role per wave so that no wave carries all the extra emission: threads [64,80) M below the tile,
+// [128,137) M above it, [192, 192+nhr) R above it
+template <bool HAS_M, bool GUARD>
+__device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, const u32 *__restrict__ R,
+                                         const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid, u32 nhr)
+{
+#pragma unroll
+    for (u32 q = 0; q < EV_NQ; q++) {
+        const int64_t j = d0 + (int64_t)q * SP_TBW + 4 * (int64_t)tid;
+        er.f[q] = ld_quad<GUARD>(F, j, nbits);
+        er.r[q] = ld_quad<GUARD>(R, j, nbits);
+        if (HAS_M) {
+            er.m[q] = ld_quad<GUARD>(M, j, nbits);
+            er.mb[q] = GUARD ? ld_dword_guarded(M, j - 1, nbits) : M[j - 1];
+        } else {
+            er.m[q] = make_uint4(0, 0, 0, 0);
+            er.mb[q] = 0;
+        }
+    }
+    er.h = make_uint4(0, 0, 0, 0);
+    er.hb = 0;
+    const u32 ht = tid & 63u, hw = tid >> 6;
+    if (HAS_M && ((hw == 1 && ht < 16) || (hw == 2 && ht < 9))) {
+        const int64_t jh = hw == 1 ? d0 - (int64_t)EV_LO + 4 * (int64_t)ht : d0 + EV_TBW + 4 * (int64_t)ht;
+        er.h = ld_quad<GUARD>(M, jh, nbits);
+        er.hb = GUARD ? ld_dword_guarded(M, jh - 1, nbits) : M[jh - 1];
+    } else if (hw == 3 && ht < nhr) {
+        er.h = ld_quad<GUARD>(R, d0 + EV_TBW + 4 * (int64_t)ht, nbits);
+    }
+}
+
+template <bool HAS_M>
+__device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u32 local_tile, u32 tid, u32 nhr)
+{
+    const int64_t d0 = (int64_t)local_tile * EV_TBW;
+    const int64_t lo = d0 - (int64_t)EV_LO - 1;
+    const uint64_t hi = (uint64_t)d0 + EV_TBW + EV_HI;
+    const bool interior = jb.aligned16 && lo >= 0 && hi + 2 <= jb.nbits / 32;
+    if (interior)
+        ev_fetch<HAS_M, false>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr);
+    else
+        ev_fetch<HAS_M, true>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr);
+}
+
+// forward list entry: bits 0..16 biased position, 17..26 index of the first reverse read at or above it, 31 = M[x]
+__device__ __forceinline__ void ev_emit_f(const uint4 f, const uint4 r, const uint4 m, u32 idx, u32 rank0, u32 base_bit,
+                                          u32 *list)
+{
+    const u64 fs[2] = {(u64)f.x | ((u64)f.y << 32), (u64)f.z | ((u64)f.w << 32)};
+    const u64 rs[2] = {(u64)r.x | ((u64)r.y << 32), (u64)r.z | ((u64)r.w << 32)};
+    const u64 ms[2] = {(u64)m.x | ((u64)m.y << 32), (u64)m.z | ((u64)m.w << 32)};
+    u32 rk = rank0;
+#pragma unroll
+    for (u32 k = 0; k < 2; k++) {
+        u64 ww = fs[k];
+        while (ww) {
+            const u32 b = (u32)__builtin_ctzll(ww);
+            ww &= ww - 1;
+            const u64 below = (rs[k] << (63u - b)) << 1;   // the reverse reads of this word strictly below bit b
+            list[idx] = (base_bit + 64u * k + b) | ((rk + (u32)__popcll(below)) << 17) | ((u32)((ms[k] >> b) & 1ull) << 31);
+            idx++;
+        }
+        rk += (u32)__popcll(rs[k]);
+    }
+}
+
+__device__ __forceinline__ void ev_emit_pos(const uint4 v, u32 idx, u32 base_bit, u32 *list)
+{
+    const u64 vs[2] = {(u64)v.x | ((u64)v.y << 32), (u64)v.z | ((u64)v.w << 32)};
+#pragma unroll
+    for (u32 k = 0; k < 2; k++) {
+        u64 ww = vs[k];
+        while (ww) {
+            const u32 b = (u32)__builtin_ctzll(ww);
+            ww &= ww - 1;
+            list[idx] = base_bit + 64u * k + b;
+            idx++;
+        }
+    }
+}
+
+// exclusive edge counts of the four dwords of a quad, as u16 x 4
+__device__ __forceinline__ void ev_store_pref(const uint4 e, u32 base, unsigned short *pref16, u32 dword)
+{
+    const u32 p0 = base, p1 = p0 + __popc(e.x), p2 = p1 + __popc(e.y), p3 = p2 + __popc(e.z);
+    *reinterpret_cast<uint2 *>(pref16 + dword) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+}
+
+__device__ __forceinline__ u32 ev_mbit(const u32 *MT, u32 q) { return (MT[q >> 5] >> (q & 31u)) & 1u; }
+
+// number of run edges at biased positions < q
+__device__ __forceinline__ u32 ev_rank_e(const u32 *MT, const unsigned short *pref16, u32 q)
+{
+    const u32 w = q >> 5;
+    const u32 mw = MT[w], mlo = MT[(int)w - 1];
+    const u32 ew = mw ^ __builtin_amdgcn_alignbit(mw, mlo, 31);
+    return (u32)pref16[w] + __popc(ew & ((1u << (q & 31u)) - 1u));
+}
+
+// Edges e, e + 1, ... of the (sorted, two entries padded) list while their position is <= hi; two per trip.
+template <class Fn>
+__device__ __forceinline__ void ev_edge_loop(const u32 *LE, u32 nE, u32 e, u32 hi, bool lv, Fn fn)
+{
+    for (;;) {
+        const u32 e0 = LE[e], e1 = LE[e + 1];
+        const bool h0 = lv && e < nE && (e0 & EV_POS) <= hi;
+        const bool h1 = h0 && e + 1 < nE && (e1 & EV_POS) <= hi;
+        if (!__builtin_amdgcn_readfirstlane(__ballot(h0) != 0)) break;
+        if (h0) fn(e0);
+        if (h1) fn(e1);
+        lv = h1;
+        e += 2;
+    }
+}
+
+// slab segment of a (workgroup, job) pair: SP_SEG_ROWS rows of 1024 u32: ncc, GF, cc, GR, scalars (|F|, |R|, Bf, R0)
+template <bool HAS_M, bool DO_NCC>
+__global__ void __launch_bounds__(256, HAS_M ? EV_WAVES : EV_WAVES_NCC)
+k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr,
+            u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags, u32 *__restrict__ n_flagged)
+{
+    typedef EvLds<HAS_M> L;
+    __shared__ __align__(16) u32 lds[L::TOTAL];
+    u32 *const hN = lds + L::HIST;
+    u32 *const hGF = lds + L::HIST + (HAS_M ? 1024u : 0u);
+    u32 *const hC = lds + L::HIST + (HAS_M ? 2048u : 0u);
+    u32 *const hGR = lds + L::HIST + (HAS_M ? 3072u : 0u);
+    u32 *const MT = lds + L::MT0 + 4;
+    unsigned short *const pref16 = reinterpret_cast<unsigned short *>(lds + L::PREF);
+    u32 *const LF = lds + L::LF;
+    u32 *const LR = lds + L::LR;
+    u32 *const LE = lds + L::LE;
+    u32 *const wt = lds + L::WT;
+    u32 *const misc = lds + L::MISC;
+
+    const u32 tid_ = threadIdx.x;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const u32 g0 = blockIdx.x * tiles_per_wg;
+    const u32 g1 = g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles;
+    if (g0 >= g1) return;
+    {
+        const u32 tid = tid_;
+#pragma nounroll
+        for (u32 i = tid; i < (HAS_M ? 4096u : 1024u); i += 256) lds[L::HIST + i] = 0;
+    }
+
+    u32 ji = 0;
+    while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
+    u32 jn = ji;
+    EvRegs er;
+    SpJobRegs pj;   // job of the tile being prefetched (index jn), held in scalar registers
+    load_job(pj, jobs.j[ji]);
+    ev_fetch_job<HAS_M>(er, pj, g0 - pj.tile0, tid_, nhr);
+    u32 cur_tile0 = pj.tile0, cur_flag0 = pj.flag0;   // of the job whose tile is being processed (index ji)
+    u32 cntF = 0, cntR = 0, cntB = 0, cnt0 = 0;   // per-thread: |F|, |R|, Bf, R0 of the tiles taken here
+#ifdef EV_STAMPS
+    unsigned long long stamp_acc[EV_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
+
+    for (u32 g = g0; g < g1; g++) {
+        EV_STAMP(9)
+        __syncthreads();   // B0: every wave is done with the previous tile's lists and M words
+        EV_STAMP(0)
+        // ---- phase A: from the prefetched registers ----
+        // (thread-index derived addresses are recomputed per tile from an opaque copy: hoisted out of the tile loop they
+        // cost ~30 registers for its whole lifetime and push the allocation into scratch)
+        u32 tid = tid_;
+        asm volatile("" : "+v"(tid));
+        const u32 lane = tid & 63;
+        u32 cF[EV_NQ], cR[EV_NQ], cE[EV_NQ] = {0, 0}, cEh = 0, cRh = 0;
+#pragma unroll
+        for (u32 q = 0; q < EV_NQ; q++) {
+            cF[q] = popc4(er.f[q]);
+            cR[q] = popc4(er.r[q]);
+            if (HAS_M) {
+                cE[q] = popc4(edge_words(er.m[q], er.mb[q]));   // (the edge words are recomputed when they are emitted)
+                *reinterpret_cast<uint4 *>(MT + EV_LO + q * SP_TBW + 4 * tid) = er.m[q];
+            }
+        }
+        const bool h_below = HAS_M && wave == 1 && lane < 16, h_above = HAS_M && wave == 2 && lane < 9;
+        const bool h_r = wave == 3 && lane < nhr;
+        if (h_below || h_above) {
+            cEh = popc4(edge_words(er.h, er.hb));
+            *reinterpret_cast<uint4 *>(MT + (h_below ? 4 * lane : EV_LO + EV_TBW + 4 * lane)) = er.h;
+            if (h_below && lane == 0) MT[-1] = er.hb;
+        }
+        if (h_r) cRh = popc4(er.h);
+        // position order = (row q, thread, word, bit): exclusive offsets from packed block scans (a row holds <= 32768
+        // bits and the halos <= 2048, so the 16-bit fields never carry)
+        const u32 pF = cF[0] | (cF[1] << 16), pR = cR[0] | (cR[1] << 16), pE = cE[0] | (cE[1] << 16);
+        const u32 pH = h_below ? cEh : cEh << 16;   // below | above
+        const u32 sF = wave_inclusive_scan(pF), sR = wave_inclusive_scan(pR), sH = wave_inclusive_scan(cRh);
+        u32 sE = 0, sX = 0;
+        if (HAS_M) {
+            sE = wave_inclusive_scan(pE);
+            sX = wave_inclusive_scan(pH);
+        }
+        if (lane == 63) {
+            wt[0 + wave] = sF;
+            wt[4 + wave] = sR;
+            wt[8 + wave] = sH;
+            if (HAS_M) {
+                wt[12 + wave] = sE;
+                wt[16 + wave] = sX;
+            }
+        }
+        EV_STAMP(1)
+        __syncthreads();   // Bs
+        EV_STAMP(2)
+        u32 bF = 0, bR = 0, bH = 0, bE = 0, bX = 0, tF = 0, tR = 0, tH = 0, tE = 0, tX = 0;
+#pragma unroll
+        for (u32 w = 0; w < 4; w++) {
+            const u32 xF = wt[w], xR = wt[4 + w], xH = wt[8 + w], xE = HAS_M ? wt[12 + w] : 0u, xX = HAS_M ? wt[16 + w] : 0u;
+            if (w < wave) {
+                bF += xF;
+                bR += xR;
+                bH += xH;
+                bE += xE;
+                bX += xX;
+            }
+            tF += xF;
+            tR += xR;
+            tH += xH;
+            tE += xE;
+            tX += xX;
+        }
+        const u32 TF0 = tF & 0xffffu, TR0 = tR & 0xffffu, TE0 = tE & 0xffffu, TE1 = tE >> 16, TXb = tX & 0xffffu;
+        const u32 nF = __builtin_amdgcn_readfirstlane(TF0 + (tF >> 16));
+        const u32 nRt = __builtin_amdgcn_readfirstlane(TR0 + (tR >> 16));   // reverse reads inside the tile: the rsum drivers
+        const u32 nR = __builtin_amdgcn_readfirstlane(nRt + tH);            // + the partners above it
+        const u32 nE = __builtin_amdgcn_readfirstlane(TXb + TE0 + TE1 + (tX >> 16));
+        const bool dense = nF > EV_CAPF || nR > EV_CAPR || nE > EV_CAPE;
+#ifdef EV_ABL_NOEMIT
+        if (S == 0xffffffffu) {
+#else
+        if (!dense) {
+#endif
+            const u32 eF = bF + sF - pF, eR = bR + sR - pR;   // exclusive, per row
+            const u32 oR0 = eR & 0xffffu, oR1 = TR0 + (eR >> 16);
+            ev_emit_f(er.f[0], er.r[0], er.m[0], eF & 0xffffu, oR0, EV_BIAS + 0 * SP_TB + 128u * tid, LF);
+            ev_emit_f(er.f[1], er.r[1], er.m[1], TF0 + (eF >> 16), oR1, EV_BIAS + 1 * SP_TB + 128u * tid, LF);
+            ev_emit_pos(er.r[0], oR0, EV_BIAS + 0 * SP_TB + 128u * tid, LR);
+            ev_emit_pos(er.r[1], oR1, EV_BIAS + 1 * SP_TB + 128u * tid, LR);
+            if (h_r) ev_emit_pos(er.h, nRt + bH + sH - cRh, EV_BIAS + EV_TB + 128u * lane, LR);
+            if (HAS_M) {
+                const u32 eE = bE + sE - pE, eX = bX + sX - pH;
+                const u32 oE0 = TXb + (eE & 0xffffu), oE1 = TXb + TE0 + (eE >> 16);
+#pragma unroll
+                for (u32 q = 0; q < EV_NQ; q++) {
+                    const uint4 Eq = edge_words(er.m[q], er.mb[q]);
+                    const u32 o = q ? oE1 : oE0;
+                    ap_emit(Eq, er.m[q], o, EV_BIAS + q * SP_TB + 128u * tid, LE);
+                    ev_store_pref(Eq, o, pref16, EV_LO + q * SP_TBW + 4 * tid);
+                }
+                const uint4 Eh = edge_words(er.h, er.hb);
+                if (h_below) {
+                    ap_emit(Eh, er.h, eX & 0xffffu, 128u * lane, LE);
+                    ev_store_pref(Eh, eX & 0xffffu, pref16, 4 * lane);
+                } else if (h_above) {
+                    const u32 oa = TXb + TE0 + TE1 + (eX >> 16);
+                    ap_emit(Eh, er.h, oa, EV_BIAS + EV_TB + 128u * lane, LE);
+                    ev_store_pref(Eh, oa, pref16, EV_LO + EV_TBW + 4 * lane);
+                }
+            }
+            cntF += cF[0] + cF[1];
+            cntR += cR[0] + cR[1];
+        } else if (tid == 0) {
+            // dense tile: left to k_cc_sparse (both of its 32-Kbit tiles; the flag array is padded per job)
+            const u32 f = cur_flag0 + EV_NQ * (g - cur_tile0);
+            for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
+            atomicAdd(n_flagged, 1u);
+        }
+        EV_STAMP(3)
+        // ---- prefetch the next tile into the (now free) registers ----
+        if (g + 1 < g1) {
+            if (g + 1 >= pj.tile_end) {   // rare: the next tile belongs to the next job
+                jn = ji + 1;
+                load_job(pj, jobs.j[jn]);
+            }
+            ev_fetch_job<HAS_M>(er, pj, g + 1 - pj.tile0, tid, nhr);
+        }
+        EV_STAMP(4)
+        __syncthreads();   // B1: lists, M words and edge ranks visible
+        EV_STAMP(5)
+        if (!dense) {
+            // Work items are blocks of 64 drivers of three kinds; kind k deals its blocks to the waves starting at a
+            // different wave, so that the odd blocks of the kinds land on different waves.
+            const u32 nbF = (nF + 63) >> 6, nbR = (nRt + 63) >> 6;
+#ifndef EV_ABL_NOFR
+            // ---- forward reads x reverse reads in [x, x + S]: ncc, mscc.cc.  Two partners per trip. ----
+            for (u32 b = wave; b < nbF; b += 4) {
+                const u32 i = 64 * b + lane;
+                const u32 ent = i < nF ? LF[i] : 0u;
+                const u32 x = ent & EV_POS;
+                const bool fl = (ent >> 31) != 0;
+                u32 r = (ent >> 17) & 0x3ffu;
+                bool live = i < nF;
+                for (;;) {
+                    const u32 y0 = LR[r], y1 = LR[r + 1];   // (the list is padded by two entries)
+                    const u32 d0 = y0 - x, d1 = y1 - x;
+                    const bool h0 = live && r < nR && d0 <= S;
+                    const bool h1 = h0 && r + 1 < nR && d1 <= S;   // sorted: a miss ends the driver
+                    if (!__builtin_amdgcn_readfirstlane(__ballot(h0) != 0)) break;
+                    if (h0) {
+                        if (DO_NCC) atomicAdd(&hN[d0], 1u);
+                        if (HAS_M && fl && ev_mbit(MT, x + c - d0)) atomicAdd(&hC[d0], 1u);
+                    }
+                    if (h1) {
+                        if (DO_NCC) atomicAdd(&hN[d1], 1u);
+                        if (HAS_M && fl && ev_mbit(MT, x + c - d1)) atomicAdd(&hC[d1], 1u);
+                    }
+                    live = h1;
+                    r += 2;
+                }
+            }
+#endif
+            EV_STAMP(6)
+#ifndef EV_ABL_NOFE
+            // ---- mappable forward reads x edges in (x + c - S, x + c]: mscc.fsum ----
+            if (HAS_M)
+                for (u32 b = (wave + 3) & 3; b < nbF; b += 4) {
+                    const u32 i = 64 * b + lane;
+                    const u32 ent = i < nF ? LF[i] : 0u;
+                    const bool lv = i < nF && (ent >> 31) != 0;
+                    const u32 hi = (ent & EV_POS) + c;
+                    if (lv) cntB += ev_mbit(MT, hi);
+                    ev_edge_loop(LE, nE, lv ? ev_rank_e(MT, pref16, hi - S + 1) : 0u, hi, lv, [&](u32 ee) {
+                        atomicAdd(&hGF[hi - (ee & EV_POS) + 1], (ee >> 31) ? 0xffffffffu : 1u);   // E[j]: -1 falling, +1 rising
+                    });
+                }
+#endif
+            EV_STAMP(8)
+#ifndef EV_ABL_NOREV
+            // ---- reverse reads x edges: mscc.rsum ----
+            if (HAS_M)
+                for (u32 b = (wave + 2) & 3; b < nbR; b += 4) {
+                    const u32 i = 64 * b + lane;
+                    const bool in = i < nRt;
+                    const u32 p = in ? LR[i] : EV_BIAS;
+                    if (in) cnt0 += ev_mbit(MT, p) & ev_mbit(MT, p + c);
+                    // type A: edges j in [p - S + 1, p], d = p - j + 1, weight M[p + c - 2d]
+                    ev_edge_loop(LE, nE, ev_rank_e(MT, pref16, p - S + 1), p, in, [&](u32 ee) {
+                        const u32 d = p - (ee & EV_POS) + 1;
+                        if (ev_mbit(MT, p + c - 2 * d)) atomicAdd(&hGR[d], (ee >> 31) ? 1u : 0xffffffffu);   // -E[j]
+                    });
+                    // type B: edges j in [p + c - 2S + 1, p + c], d = (p + c - j + 2) >> 1, weight M[p - d + 1]
+                    const u32 hi = p + c;
+                    ev_edge_loop(LE, nE, ev_rank_e(MT, pref16, hi - 2 * S + 1), hi, in, [&](u32 ee) {
+                        const u32 d = (hi - (ee & EV_POS) + 2) >> 1;
+                        if (ev_mbit(MT, p - d + 1)) atomicAdd(&hGR[d], (ee >> 31) ? 1u : 0xffffffffu);
+                    });
+                }
+#endif
+        }
+        EV_STAMP(7)
+        const bool leaving = jn != ji || g + 1 == g1;
+        if (leaving) {
+            // histograms + scalars of this (workgroup, job) -> its slab segment; cleared for the next job
+            __syncthreads();
+            u32 *seg = slab + (size_t)(blockIdx.x + ji) * SP_SEG_ROWS * 1024;
+#pragma nounroll   // (unrolled, its sixteen index registers are hoisted out of the tile loop and spill)
+            for (u32 i = tid; i < (HAS_M ? 4096u : 1024u); i += 256) {
+                seg[i] = lds[L::HIST + i];
+                lds[L::HIST + i] = 0;
+            }
+            u32 v0 = cntF, v1 = cntR, v2 = cntB, v3 = cnt0;
+            for (int off = 32; off > 0; off >>= 1) {
+                v0 += __shfl_down(v0, off, 64);
+                v1 += __shfl_down(v1, off, 64);
+                v2 += __shfl_down(v2, off, 64);
+                v3 += __shfl_down(v3, off, 64);
+            }
+            if (lane == 0) {
+                misc[wave] = v0;
+                misc[4 + wave] = v1;
+                misc[8 + wave] = v2;
+                misc[12 + wave] = v3;
+            }
+            __syncthreads();
+            if (tid < 4) seg[4 * 1024 + tid] = misc[4 * tid] + misc[4 * tid + 1] + misc[4 * tid + 2] + misc[4 * tid + 3];
+            cntF = 0;
+            cntR = 0;
+            cntB = 0;
+            cnt0 = 0;
+        }
+        ji = jn;
+        cur_tile0 = pj.tile0;
+        cur_flag0 = pj.flag0;
+    }
+#ifdef EV_STAMPS
+    if ((tid_ & 63) == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(slab + (size_t)(gridDim.x + njobs) * SP_SEG_ROWS * 1024);
+        for (int i = 0; i < EV_NSTAMP; i++) dbg[((size_t)blockIdx.x * 4 + wave) * EV_NSTAMP + i] = stamp_acc[i];
+    }
+#endif
+}
+
+// fsum[d] = Bf - sum_{t<=d} GF[t], rsum[d] = R0 + sum_{t<=d} GR[t]: k_reduce_segments left the (signed) sums of GF / GR
+// over the workgroups in rows MSCC_FSUM / MSCC_RSUM of the result block; Bf and R0 are summed from the slab here.
+// One block per job.
+__global__ void __launch_bounds__(256)
+k_events_finish(const u32 *__restrict__ slab, const SpJobTable jobs, u32 S, u32 out_stride)
+{
+    __shared__ long long part[256];
+    const u32 job = blockIdx.x, tid = threadIdx.x;
+    const SpJobDev &jb = jobs.j[job];
+    long long bf = 0, r0 = 0;
+    for (u32 w = jb.wg_first + tid; w <= jb.wg_last; w += 256) {
+        const u32 *sc = slab + (size_t)(w + job) * SP_SEG_ROWS * 1024 + 4 * 1024;
+        bf += sc[2];
+        r0 += sc[3];
+    }
+    __shared__ long long tot[2];
+    const long long eb = block_exclusive_offset(bf, part, tid);   // (ends with a barrier)
+    if (tid == 255) tot[0] = eb + bf;
+    const long long e0 = block_exclusive_offset(r0, part, tid);
+    if (tid == 255) tot[1] = e0 + r0;
+    __syncthreads();
+    const long long Bf = tot[0], R0 = tot[1];
+    const u32 seg = (S + 1 + 255) / 256;
+    const u32 k0 = tid * seg, k1 = (k0 + seg < S + 1) ? k0 + seg : S + 1;
+#pragma unroll
+    for (u32 row = 0; row < 2; row++) {
+        long long *v = reinterpret_cast<long long *>(jb.out + (size_t)(row ? PMX_ROW_MSCC_RSUM : PMX_ROW_MSCC_FSUM) * out_stride);
+        long long sum = 0;
+        for (u32 k = k0; k < k1; k++) sum += v[k];
+        long long run = block_exclusive_offset(sum, part, tid);
+        for (u32 k = k0; k < k1; k++) {
+            run += v[k];
+            v[k] = row ? R0 + run : Bf - run;
+        }
+        __syncthreads();
+    }
+}

@@ -75,7 +75,7 @@ struct SpJobTable {
 struct SpJobRegs {
     const u32 *F, *R, *M;
     u64 nbits;
-    u32 tile0, tile_end, aligned16, d_off;
+    u32 tile0, tile_end, aligned16, d_off, flag0;
 };
 
 __device__ __forceinline__ void load_job(SpJobRegs &r, const SpJobDev &j)
@@ -88,6 +88,7 @@ __device__ __forceinline__ void load_job(SpJobRegs &r, const SpJobDev &j)
     r.tile_end = j.tile0 + j.ntiles;
     r.aligned16 = j.aligned16;
     r.d_off = j.d_off;
+    r.flag0 = j.flag0;
 }
 
 // ---- LDS layouts (dwords) ----------------------------------------------------------------------------------
@@ -371,8 +372,17 @@ __device__ __forceinline__ void tile_fetch(TileRegs &tr, TileRegsX &tx, const u3
 }
 
 template <bool HAS_M, bool CH>
-__device__ __forceinline__ void tile_fetch_job(TileRegs &tr, TileRegsX &tx, const SpJobRegs &jb, u32 local_tile, u32 tid)
+__device__ __forceinline__ void tile_fetch_job(TileRegs &tr, TileRegsX &tx, const SpJobRegs &jb, u32 local_tile, u32 tid,
+                                               const unsigned char *__restrict__ flags = nullptr)
 {
+    // behind the event kernel only the tiles it flagged as dense are processed: the others read as empty
+    if (!CH && flags && !flags[jb.flag0 + local_tile]) {
+        tr.f = make_uint4(0, 0, 0, 0);
+        tr.r = tr.f;
+        tr.m = tr.f;
+        tr.h = tr.f;
+        return;
+    }
     // edge tiles (or unaligned vectors) take the guarded loader
     const int64_t d0 = (int64_t)local_tile * SP_TBW;
     const int64_t off = CH ? (int64_t)(jb.d_off / 32) : 0;
@@ -623,8 +633,9 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 template <bool HAS_M, bool DO_NCC, bool CH>
 __global__ void __launch_bounds__(256, CH ? (HAS_M ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
 k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
-            u32 *__restrict__ slab)
+            u32 *__restrict__ slab, const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged)
 {
+    if (n_flagged && *n_flagged == 0) return;   // the event kernel took every tile (uniform over the whole grid)
     typedef SpLds<HAS_M> L;
     __shared__ __align__(16) u32 lds[L::TOTAL];
     u32 *const cursor = lds + L::MISC;   // [0] = F records, [1] = R records of the current tile
@@ -677,7 +688,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     TileRegsX tx;
     SpJobRegs pj;   // job of the tile being prefetched (index jn)
     load_job(pj, jobs.j[ji]);
-    tile_fetch_job<HAS_M, CH>(tr, tx, pj, g0 - pj.tile0, tid);
+    tile_fetch_job<HAS_M, CH>(tr, tx, pj, g0 - pj.tile0, tid, tile_flags);
     if (tid < 4) cursor[tid] = 0;   // [2 par + 0] = F records, [2 par + 1] = R records; parity alternates per tile
     u32 par = 0;
     const u32 G = 1u << lgG;
@@ -726,7 +737,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     jn = ji + 1;
                     load_job(pj, jobs.j[jn]);
                 }
-                tile_fetch_job<HAS_M, CH>(tr, tx, pj, g + 1 - pj.tile0, tid);
+                tile_fetch_job<HAS_M, CH>(tr, tx, pj, g + 1 - pj.tile0, tid, tile_flags);
             }
             SP_STAMP(4)
             if (SP_PRIO_STAGE) __builtin_amdgcn_s_setprio(0);
@@ -1015,7 +1026,8 @@ struct ReduceSpec {
     u32 is_scalar[5];   // the scalar row: 2 sums, the rest of the row zero-filled, [3] = path marker; chunk 0 only
     u32 out_stride;
     u32 use_out2;       // autocorrelation: rows go to out2 (per-job scratch) instead of the result block
-    u32 accumulate;     // ... and are ADDED to what the pair pass left there
+    u32 accumulate;     // sums are ADDED to what an earlier pass (pair / event kernel) left in the destination
+    u32 is_signed[5];   // the slab row holds i32 (event histograms of edge signs)
     u32 keep_scalar2;   // scalar [2] (popcount(M)) belongs to the autocorrelation pass, which may run concurrently
     u32 nzero;          // rows of the result block this batch does not produce: written as zeros (chunk 0 only)
     u32 zero_row[5];
@@ -1026,6 +1038,7 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
                   const u32 *__restrict__ gate)
 {
     const bool live = !gate || *gate != 0;   // gate == 0: the producing kernel did not run, every sum is zero
+    if (!live && rs.accumulate) return;      // ... and there is nothing to add
     // 32 consecutive elements x 8 workgroup phases per block: every load is a full 128-B line
     __shared__ u64 part[8][32];
     const u32 r = blockIdx.y, job = blockIdx.z;
@@ -1033,7 +1046,7 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
     const u32 e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const u32 i = blockIdx.x * 32 + e;
     if (r >= rs.nrows) {   // a row this batch leaves empty
-        if ((jb.flags & 1u) && g == 0) {
+        if ((jb.flags & 1u) && g == 0 && !rs.accumulate) {
             u64 *dst = jb.out + (size_t)rs.zero_row[r - rs.nrows] * rs.out_stride;
             for (u32 k = i; k < rs.out_stride; k += gridDim.x * 32) dst[k] = 0;
         }
@@ -1046,7 +1059,10 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
     if (i < n && live) {
         const size_t stride = (size_t)seg_rows * 1024;
         const u32 *p = slab + (size_t)rs.src_row[r] * 1024 + i;
-        for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 8) sum += p[(size_t)(w + job) * stride];
+        if (rs.is_signed[r])
+            for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 8) sum += (u64)(long long)(int32_t)p[(size_t)(w + job) * stride];
+        else
+            for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 8) sum += p[(size_t)(w + job) * stride];
     }
     part[g][e] = sum;
     __syncthreads();
@@ -1063,10 +1079,15 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
         u64 *dst = jb.out + (size_t)rs.dst_row[r] * rs.out_stride;
         for (u32 k = i; k < rs.out_stride; k += gridDim.x * 32) {   // [0],[1] sums, [3] path, everything else zero
             if (k == 2 && rs.keep_scalar2) continue;
+            if (rs.accumulate) {
+                if (k < 2) dst[k] += t;
+                continue;
+            }
             dst[k] = k < 2 ? t : (k == 3 ? (u64)PMX_PATH_SPARSE : 0ull);
         }
     } else if (i < n) {
-        jb.out[(size_t)rs.dst_row[r] * rs.out_stride + jb.d_off + i] = t;
+        u64 *dst = jb.out + (size_t)rs.dst_row[r] * rs.out_stride + jb.d_off + i;
+        *dst = rs.accumulate ? *dst + t : t;
     }
 }
 
@@ -1734,6 +1755,8 @@ k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 lagcap, u32 mode, int3
     }
 }
 
+#include "kernels_events.h"
+
 // ---- host side ----------------------------------------------------------------------------------------------
 
 static uint32_t lg_slot_lanes(uint32_t nshifts)   // nshifts = shifts handled per slot
@@ -1762,14 +1785,14 @@ struct VJob {
 
 // Cuts the global tile sequence of a launch into per-workgroup ranges and fills the device job table.
 static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr, uint32_t wg_per_cu, SpJobTable *tab,
-                        uint32_t *total_tiles, uint32_t *tiles_per_wg, uint32_t *nwg, uint64_t autocorr_tile_bits = 0)
+                        uint32_t *total_tiles, uint32_t *tiles_per_wg, uint32_t *nwg, uint64_t tile_bits_override = 0)
 {
     uint32_t t = 0;
     for (uint32_t i = 0; i < n; i++) {
         SpJobDev &d = tab->j[i];
         const pmx_job &jb = *vj[i].job;
         const uint64_t bits = jb.nbits + (autocorr ? 1 : 0);   // edges live on [0, nbits]
-        const uint64_t tile_bits = autocorr ? (autocorr_tile_bits ? autocorr_tile_bits : AC_TB) : SP_TB;
+        const uint64_t tile_bits = tile_bits_override ? tile_bits_override : (autocorr ? AC_TB : SP_TB);
         uint64_t nt = (bits + tile_bits - 1) / tile_bits;
         if (nt < 1) nt = 1;
         d.F = (const u32 *)jb.d_F;
@@ -1853,20 +1876,77 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     rs.use_out2 = 0;
     rs.keep_scalar2 = (has_m && !zero_mlen) ? 1 : 0;
 
+    // Pass 1 (sparse tiles): the event kernel over every chromosome; tiles whose lists would overflow are flagged.
+    // PMX_CC_EVENTS=0 in the environment keeps everything on the window kernel (A/B measurements, tests).
+    static const bool events_enabled = [] {
+        const char *e = getenv("PMX_CC_EVENTS");
+        return !(e && e[0] == '0');
+    }();
+    const bool use_events = events_enabled && !chunked;
+    unsigned char *d_flags = nullptr;
+    u32 *d_nflagged = nullptr;
+    if (use_events) {
+        uint64_t total_flags = 0;
+        for (size_t i = 0; i < vjobs.size(); i++) {
+            vjobs[i].flag0 = (uint32_t)total_flags;
+            total_flags += (vjobs[i].job->nbits + SP_TB - 1) / SP_TB + EV_NQ;   // padding: an event tile flags EV_NQ window tiles
+        }
+        const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
+        int rc = pmx_ensure_flags_cc(ctx, flag_bytes + 16);
+        if (rc) return rc;
+        d_flags = ctx->d_flags_cc;
+        d_nflagged = (u32 *)(ctx->d_flags_cc + flag_bytes);
+        PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, flag_bytes + 16, ctx->stream));
+    }
+    ReduceSpec rs_ev = rs;
+    for (u32 i = 0; i < nr; i++)
+        if (rs.dst_row[i] == PMX_ROW_MSCC_FSUM || rs.dst_row[i] == PMX_ROW_MSCC_RSUM) rs_ev.is_signed[i] = 1;
+    if (use_events) rs.accumulate = 1;
+
     for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS) {
         const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS ? vjobs.size() - lo : SP_MAXJOBS);
         SpJobTable tab;
-        memset(&tab, 0, sizeof tab);
         uint32_t total, tpw, nwg;
-        plan_launch(ctx, &vjobs[lo], n, false, chunked ? (has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (has_m ? SP_WAVES : SP_WAVES_NCC), &tab, &total, &tpw, &nwg);
-        int rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
-        if (rc) return rc;
+        int rc;
         pmx_timed_launch tl;
+        if (use_events) {
+            memset(&tab, 0, sizeof tab);
+            plan_launch(ctx, &vjobs[lo], n, false, has_m ? EV_WAVES : EV_WAVES_NCC, &tab, &total, &tpw, &nwg, EV_TB);
+            rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
+            if (rc) return rc;
+            rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl);
+            if (rc) return rc;
+            const u32 nhr = (max_shift + 1 + 127) / 128;   // quads of R above a tile that hold partners of its forward reads
+#define EV_LAUNCH(HM, NC)                                                                                             \
+    hipLaunchKernelGGL((k_cc_events<HM, NC>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, (u32)c, max_shift, \
+                       nhr, ctx->d_slab, d_flags, d_nflagged)
+            if (has_m && do_ncc) EV_LAUNCH(true, true);
+            else if (has_m) EV_LAUNCH(true, false);
+            else EV_LAUNCH(false, true);
+#undef EV_LAUNCH
+            PMX_CHECK_LAUNCH("k_cc_events");
+            rc = pmx_prof_end(ctx, &tl);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab,
+                               (u32)SP_SEG_ROWS, rs_ev, (const u32 *)nullptr);
+            PMX_CHECK_LAUNCH("k_reduce_segments");
+            if (has_m) {
+                hipLaunchKernelGGL(k_events_finish, dim3(n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, max_shift,
+                                   out_stride);
+                PMX_CHECK_LAUNCH("k_events_finish");
+            }
+        }
+        // Pass 2 (window kernel): every tile, or -- behind the event pass -- only the tiles it flagged (the whole grid returns
+        // at once when there are none); its sums are then ADDED to the result blocks.
+        memset(&tab, 0, sizeof tab);
+        plan_launch(ctx, &vjobs[lo], n, false, chunked ? (has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (has_m ? SP_WAVES : SP_WAVES_NCC), &tab, &total, &tpw, &nwg);
+        rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
+        if (rc) return rc;
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl);
         if (rc) return rc;
 #define SP_LAUNCH(HM, NC, CK)                                                                                      \
     hipLaunchKernelGGL((k_cc_sparse<HM, NC, CK>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, c, lgG, \
-                       ctx->d_slab)
+                       ctx->d_slab, (const unsigned char *)d_flags, (const u32 *)d_nflagged)
         if (chunked) {
             if (has_m && do_ncc) SP_LAUNCH(true, true, true);
             else if (has_m) SP_LAUNCH(true, false, true);
@@ -1882,7 +1962,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         if (rc) return rc;
         // sum the per-workgroup slab segments into the result blocks
         hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab,
-                           (u32)SP_SEG_ROWS, rs, (const u32 *)nullptr);
+                           (u32)SP_SEG_ROWS, rs, (const u32 *)d_nflagged);
         PMX_CHECK_LAUNCH("k_reduce_segments");
     }
     return PMX_OK;

@@ -74,6 +74,8 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->slab2_words = 0;
     ctx->d_flags = nullptr;
     ctx->flags_bytes = 0;
+    ctx->d_flags_cc = nullptr;
+    ctx->flags_cc_bytes = 0;
     ctx->d_slab_ac = nullptr;
     ctx->slab_ac_words = 0;
     ctx->aux_stream = nullptr;
@@ -137,6 +139,7 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (ctx->d_slab) (void)hipFree(ctx->d_slab);
     if (ctx->d_slab2) (void)hipFree(ctx->d_slab2);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->d_flags_cc) (void)hipFree(ctx->d_flags_cc);
     if (ctx->d_slab_ac) (void)hipFree(ctx->d_slab_ac);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -225,6 +228,21 @@ int pmx_ensure_flags(pmx_ctx *ctx, size_t bytes)
     const size_t want = bytes < 65536 ? 65536 : bytes * 2;
     PMX_HIP(hipMalloc((void **)&ctx->d_flags, want));
     ctx->flags_bytes = want;
+    return PMX_OK;
+}
+
+int pmx_ensure_flags_cc(pmx_ctx *ctx, size_t bytes)
+{
+    if (ctx->flags_cc_bytes >= bytes) return PMX_OK;
+    if (ctx->d_flags_cc) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(ctx->d_flags_cc));
+        ctx->d_flags_cc = nullptr;
+        ctx->flags_cc_bytes = 0;
+    }
+    const size_t want = bytes < 65536 ? 65536 : bytes * 2;
+    PMX_HIP(hipMalloc((void **)&ctx->d_flags_cc, want));
+    ctx->flags_cc_bytes = want;
     return PMX_OK;
 }
 

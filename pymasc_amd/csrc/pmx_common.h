@@ -62,6 +62,8 @@ struct pmx_ctx {
     size_t slab2_words;
     unsigned char *d_flags;
     size_t flags_bytes;
+    unsigned char *d_flags_cc;   // dense-tile flags (+ counter) the event kernel hands to the window kernel
+    size_t flags_cc_bytes;
     u32 *d_slab_ac;              // slab of the window autocorrelation kernel (separate: it may run beside k_cc_sparse)
     size_t slab_ac_words;
     // staging for the host-pointer entry points
@@ -115,6 +117,7 @@ int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_slab2(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_slab_ac(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_flags(pmx_ctx *ctx, size_t bytes);
+int pmx_ensure_flags_cc(pmx_ctx *ctx, size_t bytes);
 size_t pmx_autocorr_scratch_words(uint32_t max_lag);
 // out[k] = sum_j M[j] & M[j+k], k = 0..max_lag
 int pmx_launch_autocorr_dense(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint32_t max_lag, u64 *d_out);

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""GPU box diagnostic: builds the library with -DEV_STAMPS and prints where a tile's cycles go in k_cc_events."""
+import ctypes, os, subprocess, sys, glob
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+lib = "/tmp/libevstamps.so"
+extra = [a for a in sys.argv[2:]]
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP", "-fPIC", "-shared", "-DEV_STAMPS",
+                       "-o", lib] + extra + sorted(glob.glob(os.path.join(ROOT, "pymasc_amd/csrc/*.hip"))))
+os.environ["PYMASC_AMD_LIB"] = lib
+os.environ["PMX_AUTOCORR_FORK"] = "0"
+import torch
+from pymasc_amd import ffi, synth
+mode = sys.argv[1] if len(sys.argv) > 1 else "both"
+with_m = mode == "both"
+ctx = ffi.Context(0)
+dev = torch.device("cuda", 0)
+S, L = 1000, 36
+vecs = [synth.make_chromosome(ctx, dev, n, ln, S, L, 0xC0FFEE + i, with_m=with_m) for i, (n, ln) in enumerate(synth.HG38)]
+out = torch.zeros((len(vecs), ffi.PMX_NROWS, S + 1), dtype=torch.int64, device=dev)
+args = ([v.F.data_ptr() for v in vecs], [v.R.data_ptr() for v in vecs], [v.M.data_ptr() for v in vecs] if with_m else None,
+        [v.nbits for v in vecs], S, L, 0, [out[i].data_ptr() for i in range(len(vecs))])
+for _ in range(3):
+    ctx.cc_batch_dev(*args)
+ctx.sync()
+ntiles = sum((v.nbits + 65535) // 65536 for v in vecs)
+per_cu = int(os.environ.get("EV_PER_CU", 4 if with_m else 8))
+nwg = min(256 * per_cu, ntiles)
+tpw = -(-ntiles // nwg); nwg = -(-ntiles // tpw)
+off = (nwg + len(vecs)) * 5 * 1024 * 4
+NS = 12
+buf = np.zeros(nwg * 4 * NS, dtype=np.uint64)
+Lb = ffi.load_library()
+Lb.pmx_debug_read_slab.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+rc = Lb.pmx_debug_read_slab(ctx._h, off, buf.ctypes.data, buf.nbytes)
+assert rc == 0
+a = buf.reshape(nwg, 4, NS).astype(np.float64)
+tot = a.sum(axis=2).mean()
+print(f"mode={mode} nwg={nwg} tiles/wg={tpw} cycles per wave lifetime={tot:.0f}  per tile={tot / tpw:.0f}")
+lab = {0: "B0 barrier wait", 1: "counts + M store + scans", 2: "Bs barrier wait", 3: "totals + emit lists", 4: "prefetch issue",
+       5: "B1 barrier wait", 6: "forward events (F x R, F x E)", 7: "reverse events (R x E)", 8: "-", 9: "flush / loop tail", 10: "-", 11: "-"}
+for i in range(NS):
+    print(f"  {lab[i]:32s} {a[:, :, i].mean() / tpw:9.0f} cyc/tile  {100 * a[:, :, i].sum() / a.sum():5.1f} %")
+for w in range(4):
+    print("  wave", w, " ".join(f"{a[:, w, i].mean() / tpw:7.0f}" for i in range(NS)))
