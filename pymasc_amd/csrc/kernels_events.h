@@ -38,6 +38,8 @@
 #define EV_CAPR 640u                      // reverse reads of the tile + of the max_shift bits above it
 #define EV_CAPE 384u                      // run edges of everything staged
 #define EV_POS 0x1ffffu                   // 17 bits of biased position
+#define EV_HROW 1088u                      // histogram row: 1024 shifts + [1024 + lane] = where lane's missing events are added
+                                          // (one slot per lane: LDS atomics of a wave to ONE address are serialised)
 #ifndef EV_WAVES
 #define EV_WAVES 4
 #endif
@@ -62,13 +64,13 @@
 
 template <bool HAS_M>
 struct EvLds {
-    static constexpr u32 HIST = 0;                                  // rows of 1024 i32: ncc, GF, cc, GR (NCC-only: ncc)
-    static constexpr u32 MT0 = HIST + (HAS_M ? 4096u : 1024u);      // [3] = the dword below the staged range, [4..] = M
+    static constexpr u32 HIST = 0;                                  // rows of EV_HROW i32: ncc, GF, cc, GR (NCC-only: ncc)
+    static constexpr u32 MT0 = HIST + (HAS_M ? 4 * EV_HROW : EV_HROW);      // [3] = the dword below the staged range, [4..] = M
     static constexpr u32 PREF = MT0 + (HAS_M ? 4u + EV_MW : 0u);    // u16 per staged dword: edges before it
     static constexpr u32 LF = PREF + (HAS_M ? (EV_MW + 3) / 4 * 2 : 0u);
     static constexpr u32 LR = LF + EV_CAPF;
-    static constexpr u32 LE = LR + EV_CAPR + 2;                     // (+2: the event loops read two entries per trip)
-    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE + 2 : 0u);          // [5][4 waves] scan totals
+    static constexpr u32 LE = LR + EV_CAPR + 4;                     // (+4: the event loops read two entries per trip, two ahead)
+    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE + 4 : 0u);          // [5][4 waves] scan totals
     static constexpr u32 MISC = WT + 32;
     static constexpr u32 TOTAL = MISC + 16;
 };
@@ -177,22 +179,6 @@ __device__ __forceinline__ u32 ev_rank_e(const u32 *MT, const unsigned short *pr
     return (u32)pref16[w] + __popc(ew & ((1u << (q & 31u)) - 1u));
 }
 
-// Edges e, e + 1, ... of the (sorted, two entries padded) list while their position is <= hi; two per trip.
-template <class Fn>
-__device__ __forceinline__ void ev_edge_loop(const u32 *LE, u32 nE, u32 e, u32 hi, bool lv, Fn fn)
-{
-    for (;;) {
-        const u32 e0 = LE[e], e1 = LE[e + 1];
-        const bool h0 = lv && e < nE && (e0 & EV_POS) <= hi;
-        const bool h1 = h0 && e + 1 < nE && (e1 & EV_POS) <= hi;
-        if (!__builtin_amdgcn_readfirstlane(__ballot(h0) != 0)) break;
-        if (h0) fn(e0);
-        if (h1) fn(e1);
-        lv = h1;
-        e += 2;
-    }
-}
-
 // slab segment of a (workgroup, job) pair: SP_SEG_ROWS rows of 1024 u32: ncc, GF, cc, GR, scalars (|F|, |R|, Bf, R0)
 template <bool HAS_M, bool DO_NCC>
 __global__ void __launch_bounds__(256, HAS_M ? EV_WAVES : EV_WAVES_NCC)
@@ -202,9 +188,9 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     typedef EvLds<HAS_M> L;
     __shared__ __align__(16) u32 lds[L::TOTAL];
     u32 *const hN = lds + L::HIST;
-    u32 *const hGF = lds + L::HIST + (HAS_M ? 1024u : 0u);
-    u32 *const hC = lds + L::HIST + (HAS_M ? 2048u : 0u);
-    u32 *const hGR = lds + L::HIST + (HAS_M ? 3072u : 0u);
+    u32 *const hGF = lds + L::HIST + (HAS_M ? 1 * EV_HROW : 0u);
+    u32 *const hC = lds + L::HIST + (HAS_M ? 2 * EV_HROW : 0u);
+    u32 *const hGR = lds + L::HIST + (HAS_M ? 3 * EV_HROW : 0u);
     u32 *const MT = lds + L::MT0 + 4;
     unsigned short *const pref16 = reinterpret_cast<unsigned short *>(lds + L::PREF);
     u32 *const LF = lds + L::LF;
@@ -221,7 +207,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     {
         const u32 tid = tid_;
 #pragma nounroll
-        for (u32 i = tid; i < (HAS_M ? 4096u : 1024u); i += 256) lds[L::HIST + i] = 0;
+        for (u32 i = tid; i < (HAS_M ? 4 * EV_HROW : EV_HROW); i += 256) lds[L::HIST + i] = 0;
     }
 
     u32 ji = 0;
@@ -344,6 +330,9 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     ev_store_pref(Eh, oa, pref16, EV_LO + EV_TBW + 4 * lane);
                 }
             }
+            // sentinels behind the lists: the event loops need no index bounds (and read two entries ahead)
+            if (tid < 4) LR[nR + tid] = 0x7fffffffu;
+            else if (HAS_M && tid < 8) LE[nE + tid - 4] = EV_POS;
             cntF += cF[0] + cF[1];
             cntR += cR[0] + cR[1];
         } else if (tid == 0) {
@@ -366,33 +355,43 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         EV_STAMP(5)
         if (!dense) {
             // Work items are blocks of 64 drivers of three kinds; kind k deals its blocks to the waves starting at a
-            // different wave, so that the odd blocks of the kinds land on different waves.
+            // different wave, so that the odd blocks of the kinds land on different waves.  The loops are bound by LDS
+            // round trips, not by instruction issue: every trip takes two list entries, the next two are already in flight,
+            // and the M bits of both are looked up together.
             const u32 nbF = (nF + 63) >> 6, nbR = (nRt + 63) >> 6;
+            const u32 dump = 1024u + lane;
 #ifndef EV_ABL_NOFR
-            // ---- forward reads x reverse reads in [x, x + S]: ncc, mscc.cc.  Two partners per trip. ----
+            // ---- forward reads x reverse reads in [x, x + S]: ncc, mscc.cc ----
+            // No predication: an event that misses is added to the lane's dump slot of the row; idle lanes carry x = 0
+            // (every distance from it exceeds S: list positions start at EV_BIAS), finished lanes park on the sentinel.
             for (u32 b = wave; b < nbF; b += 4) {
                 const u32 i = 64 * b + lane;
                 const u32 ent = i < nF ? LF[i] : 0u;
-                const u32 x = ent & EV_POS;
-                const bool fl = (ent >> 31) != 0;
+                const u32 x = ent & EV_POS, xc = x + c;
+                const u32 flm = (u32)((int32_t)ent >> 31);   // all ones: mappable
                 u32 r = (ent >> 17) & 0x3ffu;
-                bool live = i < nF;
+                u32 y0 = LR[r], y1 = LR[r + 1];
                 for (;;) {
-                    const u32 y0 = LR[r], y1 = LR[r + 1];   // (the list is padded by two entries)
                     const u32 d0 = y0 - x, d1 = y1 - x;
-                    const bool h0 = live && r < nR && d0 <= S;
-                    const bool h1 = h0 && r + 1 < nR && d1 <= S;   // sorted: a miss ends the driver
-                    if (!__builtin_amdgcn_readfirstlane(__ballot(h0) != 0)) break;
-                    if (h0) {
-                        if (DO_NCC) atomicAdd(&hN[d0], 1u);
-                        if (HAS_M && fl && ev_mbit(MT, x + c - d0)) atomicAdd(&hC[d0], 1u);
+                    const bool h0 = d0 <= S, h1 = d1 <= S;   // sorted: h1 implies h0
+                    if (!__ballot(h0)) break;
+                    r = h1 ? r + 2 : nR;
+                    y0 = LR[r];
+                    y1 = LR[r + 1];
+                    const u32 a0 = h0 ? d0 : dump, a1 = h1 ? d1 : dump;
+                    if (HAS_M) {
+                        const u32 q0 = xc - (h0 ? d0 : 0u), q1 = xc - (h1 ? d1 : 0u);
+                        const u32 m0 = MT[q0 >> 5], m1 = MT[q1 >> 5];
+                        if (DO_NCC) {
+                            atomicAdd(&hN[a0], 1u);
+                            atomicAdd(&hN[a1], 1u);
+                        }
+                        atomicAdd(&hC[a0], (m0 >> (q0 & 31u)) & flm & 1u);
+                        atomicAdd(&hC[a1], (m1 >> (q1 & 31u)) & flm & 1u);
+                    } else {
+                        atomicAdd(&hN[a0], 1u);
+                        atomicAdd(&hN[a1], 1u);
                     }
-                    if (h1) {
-                        if (DO_NCC) atomicAdd(&hN[d1], 1u);
-                        if (HAS_M && fl && ev_mbit(MT, x + c - d1)) atomicAdd(&hC[d1], 1u);
-                    }
-                    live = h1;
-                    r += 2;
                 }
             }
 #endif
@@ -403,34 +402,61 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 for (u32 b = (wave + 3) & 3; b < nbF; b += 4) {
                     const u32 i = 64 * b + lane;
                     const u32 ent = i < nF ? LF[i] : 0u;
-                    const bool lv = i < nF && (ent >> 31) != 0;
+                    const bool lv = (ent >> 31) != 0;
                     const u32 hi = (ent & EV_POS) + c;
                     if (lv) cntB += ev_mbit(MT, hi);
-                    ev_edge_loop(LE, nE, lv ? ev_rank_e(MT, pref16, hi - S + 1) : 0u, hi, lv, [&](u32 ee) {
-                        atomicAdd(&hGF[hi - (ee & EV_POS) + 1], (ee >> 31) ? 0xffffffffu : 1u);   // E[j]: -1 falling, +1 rising
-                    });
+                    u32 e = lv ? ev_rank_e(MT, pref16, hi - S + 1) : nE;   // idle lanes sit on the sentinel
+                    u32 e0 = LE[e], e1 = LE[e + 1];
+                    for (;;) {
+                        const u32 p0 = e0 & EV_POS, p1 = e1 & EV_POS;
+                        const bool h0 = p0 <= hi, h1 = p1 <= hi;
+                        if (!__ballot(h0)) break;
+                        atomicAdd(&hGF[h0 ? hi - p0 + 1 : dump], (u32)(((int32_t)e0 >> 31) | 1));   // E[j]: -1 falling, +1 rising
+                        atomicAdd(&hGF[h1 ? hi - p1 + 1 : dump], (u32)(((int32_t)e1 >> 31) | 1));
+                        e = h1 ? e + 2 : nE;
+                        e0 = LE[e];
+                        e1 = LE[e + 1];
+                    }
                 }
 #endif
             EV_STAMP(8)
 #ifndef EV_ABL_NOREV
-            // ---- reverse reads x edges: mscc.rsum ----
+            // ---- reverse reads x edges: mscc.rsum.  Both edge ranges of a read are walked in the same loop:
+            // type A: edges j in [p - S + 1, p],          d = p - j + 1,            weight M[p + c - 2d]
+            // type B: edges j in [p + c - 2S + 1, p + c], d = (p + c - j + 2) >> 1, weight M[p - d + 1]
             if (HAS_M)
                 for (u32 b = (wave + 2) & 3; b < nbR; b += 4) {
                     const u32 i = 64 * b + lane;
                     const bool in = i < nRt;
-                    const u32 p = in ? LR[i] : EV_BIAS;
-                    if (in) cnt0 += ev_mbit(MT, p) & ev_mbit(MT, p + c);
-                    // type A: edges j in [p - S + 1, p], d = p - j + 1, weight M[p + c - 2d]
-                    ev_edge_loop(LE, nE, ev_rank_e(MT, pref16, p - S + 1), p, in, [&](u32 ee) {
-                        const u32 d = p - (ee & EV_POS) + 1;
-                        if (ev_mbit(MT, p + c - 2 * d)) atomicAdd(&hGR[d], (ee >> 31) ? 1u : 0xffffffffu);   // -E[j]
-                    });
-                    // type B: edges j in [p + c - 2S + 1, p + c], d = (p + c - j + 2) >> 1, weight M[p - d + 1]
-                    const u32 hi = p + c;
-                    ev_edge_loop(LE, nE, ev_rank_e(MT, pref16, hi - 2 * S + 1), hi, in, [&](u32 ee) {
-                        const u32 d = (hi - (ee & EV_POS) + 2) >> 1;
-                        if (ev_mbit(MT, p - d + 1)) atomicAdd(&hGR[d], (ee >> 31) ? 1u : 0xffffffffu);
-                    });
+                    const u32 p = in ? LR[i] : EV_BIAS, hi = p + c;
+                    if (in) cnt0 += ev_mbit(MT, p) & ev_mbit(MT, hi);
+                    u32 eA = in ? ev_rank_e(MT, pref16, p - S + 1) : nE, eB = in ? ev_rank_e(MT, pref16, hi - 2 * S + 1) : nE;
+                    u32 a0 = LE[eA], a1 = LE[eA + 1], b0 = LE[eB], b1 = LE[eB + 1];
+                    for (;;) {
+                        const u32 pa0 = a0 & EV_POS, pa1 = a1 & EV_POS, pb0 = b0 & EV_POS, pb1 = b1 & EV_POS;
+                        const bool hA0 = pa0 <= p, hA1 = pa1 <= p, hB0 = pb0 <= hi, hB1 = pb1 <= hi;
+                        if (!__ballot(hA0 || hB0)) break;
+                        // shifts (or the lane's dump slot) and the positions of the weights (a miss looks up a staged bit near p)
+                        const u32 dA0 = hA0 ? p - pa0 + 1 : 0u, dA1 = hA1 ? p - pa1 + 1 : 0u;
+                        const u32 dB0 = hB0 ? (hi - pb0 + 2) >> 1 : 0u, dB1 = hB1 ? (hi - pb1 + 2) >> 1 : 0u;
+                        const u32 tA0 = hA0 ? dA0 : dump, tA1 = hA1 ? dA1 : dump, tB0 = hB0 ? dB0 : dump, tB1 = hB1 ? dB1 : dump;
+                        const u32 qA0 = hi - 2 * dA0, qA1 = hi - 2 * dA1;
+                        const u32 qB0 = p + 1 - dB0, qB1 = p + 1 - dB1;
+                        const u32 mA0 = MT[qA0 >> 5], mA1 = MT[qA1 >> 5], mB0 = MT[qB0 >> 5], mB1 = MT[qB1 >> 5];
+                        // -E[j]: +1 falling, -1 rising
+                        const int32_t nA0 = ((int32_t)~a0 >> 31) | 1, nA1 = ((int32_t)~a1 >> 31) | 1;
+                        const int32_t nB0 = ((int32_t)~b0 >> 31) | 1, nB1 = ((int32_t)~b1 >> 31) | 1;
+                        eA = hA1 ? eA + 2 : nE;
+                        eB = hB1 ? eB + 2 : nE;
+                        a0 = LE[eA];
+                        a1 = LE[eA + 1];
+                        b0 = LE[eB];
+                        b1 = LE[eB + 1];
+                        atomicAdd(&hGR[tA0], (u32)(nA0 * (int32_t)((mA0 >> (qA0 & 31u)) & 1u)));
+                        atomicAdd(&hGR[tA1], (u32)(nA1 * (int32_t)((mA1 >> (qA1 & 31u)) & 1u)));
+                        atomicAdd(&hGR[tB0], (u32)(nB0 * (int32_t)((mB0 >> (qB0 & 31u)) & 1u)));
+                        atomicAdd(&hGR[tB1], (u32)(nB1 * (int32_t)((mB1 >> (qB1 & 31u)) & 1u)));
+                    }
                 }
 #endif
         }
@@ -442,8 +468,9 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             u32 *seg = slab + (size_t)(blockIdx.x + ji) * SP_SEG_ROWS * 1024;
 #pragma nounroll   // (unrolled, its sixteen index registers are hoisted out of the tile loop and spill)
             for (u32 i = tid; i < (HAS_M ? 4096u : 1024u); i += 256) {
-                seg[i] = lds[L::HIST + i];
-                lds[L::HIST + i] = 0;
+                u32 *h = lds + L::HIST + (i >> 10) * EV_HROW + (i & 1023u);
+                seg[i] = *h;
+                *h = 0;
             }
             u32 v0 = cntF, v1 = cntR, v2 = cntB, v3 = cnt0;
             for (int off = 32; off > 0; off >>= 1) {
