@@ -257,6 +257,7 @@ def main():
         ffi.PMX_KERNEL_CC_DENSE: (3 if with_m else 2) * vec_bytes + (4 if with_m else 1) * out_bytes * len(vecs),
         ffi.PMX_KERNEL_CC_SPARSE: (3 if with_m else 2) * vec_bytes + (4 if with_m else 1) * out_bytes * len(vecs),
         ffi.PMX_KERNEL_AUTOCORR: vec_bytes + out_bytes * len(vecs),
+        ffi.PMX_KERNEL_CC_EVENTS: (3 if with_m else 2) * vec_bytes + (4 if with_m else 1) * out_bytes * len(vecs),
     }[dom]
     alg_bytes_per_launch = per_pass * args.steps / max(dom_n, 1)
     avg_ms = dom_ms / max(dom_n, 1)
@@ -272,7 +273,8 @@ def main():
     try:
         if default_workload:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
-            key = {ffi.PMX_KERNEL_CC_SPARSE: "k_cc_sparse", ffi.PMX_KERNEL_AUTOCORR: "k_autocorr_pairs"}.get(dom)
+            key = {ffi.PMX_KERNEL_CC_SPARSE: "k_cc_sparse", ffi.PMX_KERNEL_AUTOCORR: "k_autocorr_pairs",
+                   ffi.PMX_KERNEL_CC_EVENTS: "k_cc_events"}.get(dom)
             if key:
                 traffic = prof["mode_both"][key]["hbm_bytes"]
                 traffic_src = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"

@@ -136,7 +136,8 @@ int pmx_mappable_len(pmx_ctx *ctx, const uint64_t *h_M, uint64_t nbits, uint32_t
 #define PMX_KERNEL_CC_DENSE     0
 #define PMX_KERNEL_CC_SPARSE    1
 #define PMX_KERNEL_AUTOCORR     2
-#define PMX_KERNEL_COUNT_       3
+#define PMX_KERNEL_CC_EVENTS    3   /* the event kernel of the set-bit path (sparse tiles; CC_SPARSE then counts its window pass) */
+#define PMX_KERNEL_COUNT_       4
 int pmx_ctx_set_profiling(pmx_ctx *ctx, int on);
 int pmx_ctx_reset_kernel_times(pmx_ctx *ctx);
 int pmx_ctx_kernel_time(pmx_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);

@@ -77,7 +77,10 @@ struct EvLds {
 
 struct EvRegs {
     uint4 f[EV_NQ], r[EV_NQ], m[EV_NQ], h;   // quad q covers dwords q*1024 + 4 tid ..; h: one halo quad (see ev_fetch)
-    u32 mb[EV_NQ], hb;                       // the dword of M below m[q] / below h
+    u32 wb[EV_NQ], hbw;                      // WAVE-UNIFORM: the dword of M below lane 0's m[q] / below lane 0's h; the other
+                                             // lanes take their neighbour's last dword (ev_below).  A per-thread load of
+                                             // M[j - 1] is merged with the quad load into one misaligned 16-byte load + a
+                                             // register shuffle that waits for the prefetch right where it is issued.
 };
 
 // halo quads, one role per wave so that no wave carries all the extra emission: threads [64,80) M below the tile,
@@ -93,21 +96,26 @@ __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, 
         er.r[q] = ld_quad<GUARD>(R, j, nbits);
         if (HAS_M) {
             er.m[q] = ld_quad<GUARD>(M, j, nbits);
-            er.mb[q] = GUARD ? ld_dword_guarded(M, j - 1, nbits) : M[j - 1];
+            const int64_t j0 = d0 + (int64_t)q * SP_TBW + 4 * (int64_t)(tid & ~63u) - 1;   // uniform over the wave
+            er.wb[q] = GUARD ? ld_dword_guarded(M, j0, nbits) : M[j0];
         } else {
             er.m[q] = make_uint4(0, 0, 0, 0);
-            er.mb[q] = 0;
+            er.wb[q] = 0;
         }
     }
-    er.h = make_uint4(0, 0, 0, 0);
-    er.hb = 0;
+    // ONE halo load for every lane (lanes without a role re-read their own quad and ignore it): loads of the roles in
+    // separate branches target the same registers, and the compiler then waits for everything in flight between them
     const u32 ht = tid & 63u, hw = tid >> 6;
-    if (HAS_M && ((hw == 1 && ht < 16) || (hw == 2 && ht < 9))) {
-        const int64_t jh = hw == 1 ? d0 - (int64_t)EV_LO + 4 * (int64_t)ht : d0 + EV_TBW + 4 * (int64_t)ht;
-        er.h = ld_quad<GUARD>(M, jh, nbits);
-        er.hb = GUARD ? ld_dword_guarded(M, jh - 1, nbits) : M[jh - 1];
-    } else if (hw == 3 && ht < nhr) {
-        er.h = ld_quad<GUARD>(R, d0 + EV_TBW + 4 * (int64_t)ht, nbits);
+    const bool m_lo = HAS_M && hw == 1 && ht < 16, m_hi = HAS_M && hw == 2 && ht < 9, r_hi = hw == 3 && ht < nhr;
+    const u32 *hp = (m_lo || m_hi) ? M : R;
+    int64_t jh = d0 + 4 * (int64_t)tid;
+    if (m_lo) jh = d0 - (int64_t)EV_LO + 4 * (int64_t)ht;
+    if (m_hi || r_hi) jh = d0 + EV_TBW + 4 * (int64_t)ht;
+    er.h = ld_quad<GUARD>(hp, jh, nbits);
+    er.hbw = 0;
+    if (HAS_M) {
+        const int64_t jh0 = (hw == 1 ? d0 - (int64_t)EV_LO : d0 + EV_TBW) - 1;   // uniform over the wave
+        er.hbw = GUARD ? ld_dword_guarded(M, jh0, nbits) : M[jh0];
     }
 }
 
@@ -166,6 +174,12 @@ __device__ __forceinline__ void ev_store_pref(const uint4 e, u32 base, unsigned 
 {
     const u32 p0 = base, p1 = p0 + __popc(e.x), p2 = p1 + __popc(e.y), p3 = p2 + __popc(e.z);
     *reinterpret_cast<uint2 *>(pref16 + dword) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+}
+
+// the dword below this lane's quad: the last dword of the lane below it (lane 0: `first`, uniform over the wave)
+__device__ __forceinline__ u32 ev_below(u32 last_dword, u32 first)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)first, (int)last_dword, 0x138, 0xf, 0xf, false);   // wave_shr:1
 }
 
 __device__ __forceinline__ u32 ev_mbit(const u32 *MT, u32 q) { return (MT[q >> 5] >> (q & 31u)) & 1u; }
@@ -241,16 +255,17 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             cF[q] = popc4(er.f[q]);
             cR[q] = popc4(er.r[q]);
             if (HAS_M) {
-                cE[q] = popc4(edge_words(er.m[q], er.mb[q]));   // (the edge words are recomputed when they are emitted)
+                cE[q] = popc4(edge_words(er.m[q], ev_below(er.m[q].w, er.wb[q])));   // (recomputed when they are emitted)
                 *reinterpret_cast<uint4 *>(MT + EV_LO + q * SP_TBW + 4 * tid) = er.m[q];
             }
         }
         const bool h_below = HAS_M && wave == 1 && lane < 16, h_above = HAS_M && wave == 2 && lane < 9;
         const bool h_r = wave == 3 && lane < nhr;
+        const u32 hbel = HAS_M ? ev_below(er.h.w, er.hbw) : 0u;   // (all lanes: DPP reads the lane below)
         if (h_below || h_above) {
-            cEh = popc4(edge_words(er.h, er.hb));
+            cEh = popc4(edge_words(er.h, hbel));
             *reinterpret_cast<uint4 *>(MT + (h_below ? 4 * lane : EV_LO + EV_TBW + 4 * lane)) = er.h;
-            if (h_below && lane == 0) MT[-1] = er.hb;
+            if (h_below && lane == 0) MT[-1] = er.hbw;
         }
         if (h_r) cRh = popc4(er.h);
         // position order = (row q, thread, word, bit): exclusive offsets from packed block scans (a row holds <= 32768
@@ -315,12 +330,12 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 const u32 oE0 = TXb + (eE & 0xffffu), oE1 = TXb + TE0 + (eE >> 16);
 #pragma unroll
                 for (u32 q = 0; q < EV_NQ; q++) {
-                    const uint4 Eq = edge_words(er.m[q], er.mb[q]);
+                    const uint4 Eq = edge_words(er.m[q], ev_below(er.m[q].w, er.wb[q]));
                     const u32 o = q ? oE1 : oE0;
                     ap_emit(Eq, er.m[q], o, EV_BIAS + q * SP_TB + 128u * tid, LE);
                     ev_store_pref(Eq, o, pref16, EV_LO + q * SP_TBW + 4 * tid);
                 }
-                const uint4 Eh = edge_words(er.h, er.hb);
+                const uint4 Eh = edge_words(er.h, ev_below(er.h.w, er.hbw));
                 if (h_below) {
                     ap_emit(Eh, er.h, eX & 0xffffu, 128u * lane, LE);
                     ev_store_pref(Eh, eX & 0xffffu, pref16, 4 * lane);

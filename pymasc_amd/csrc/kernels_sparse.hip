@@ -1914,7 +1914,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             plan_launch(ctx, &vjobs[lo], n, false, has_m ? EV_WAVES : EV_WAVES_NCC, &tab, &total, &tpw, &nwg, EV_TB);
             rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
             if (rc) return rc;
-            rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl);
+            rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_EVENTS, &tl);
             if (rc) return rc;
             const u32 nhr = (max_shift + 1 + 127) / 128;   // quads of R above a tile that hold partners of its forward reads
 #define EV_LAUNCH(HM, NC)                                                                                             \

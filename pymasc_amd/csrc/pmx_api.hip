@@ -363,6 +363,7 @@ const char *pmx_kernel_name(int kernel_id)
     case PMX_KERNEL_CC_DENSE: return "k_cc_dense";
     case PMX_KERNEL_CC_SPARSE: return "k_cc_sparse";
     case PMX_KERNEL_AUTOCORR: return "k_autocorr_pairs+edges";
+    case PMX_KERNEL_CC_EVENTS: return "k_cc_events";
     default: return "?";
     }
 }

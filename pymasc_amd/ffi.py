@@ -33,7 +33,8 @@ PMX_PATH_SPARSE = 2
 PMX_KERNEL_CC_DENSE = 0
 PMX_KERNEL_CC_SPARSE = 1
 PMX_KERNEL_AUTOCORR = 2
-PMX_KERNEL_COUNT = 3
+PMX_KERNEL_CC_EVENTS = 3
+PMX_KERNEL_COUNT = 4
 
 # every symbol include/pymasc_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
