@@ -208,3 +208,125 @@ def test_bits_builders_match_oracle(ctx):
             ctx.bits_set_positions(d, 100, np.array([5, 100]))
         finally:
             ctx.bits_free(d)
+
+
+# ---- the event kernel (sparse tiles) and its hand-over to the window kernel (dense tiles) ----------------------------
+EVENT_TILE = 65536      # kernels_events.h: EV_TB
+EVENT_CAP_F = 512       # EV_CAPF: forward reads of one tile
+EVENT_CAP_R = 640       # EV_CAPR: reverse reads of the tile + of the max_shift bits above it
+EVENT_CAP_E = 384       # EV_CAPE: run edges of everything staged for the tile
+
+
+def _exact_count_bits(rng, nbits, lo, hi, k):
+    w = np.zeros(synth.nwords(nbits), dtype=np.uint64)
+    pos = rng.choice(hi - lo, size=k, replace=False).astype(np.int64) + lo
+    np.bitwise_or.at(w, pos >> 6, np.uint64(1) << (pos & 63).astype(np.uint64))
+    return w
+
+
+@pytest.mark.parametrize("with_m", [True, False])
+@pytest.mark.parametrize("which,count", [("F", EVENT_CAP_F), ("F", EVENT_CAP_F + 1), ("R", EVENT_CAP_R), ("R", EVENT_CAP_R + 1)])
+def test_event_lists_exactly_full_and_one_over(ctx, which, count, with_m):
+    """Tile 1 of three holds exactly the list capacity (stays on the event kernel) or one entry more (flagged, summed by
+    the window kernel and ADDED to what the event kernel wrote for tiles 0 and 2)."""
+    S, L = 700, 36
+    rng = np.random.default_rng(700 + count + (1 if with_m else 0))
+    nbits = 3 * EVENT_TILE - 1000
+    sparse = lambda: synth.random_bits(rng, nbits, 0.003, 1, nbits - 200)
+    F, R = sparse(), sparse()
+    lo, hi = EVENT_TILE, 2 * EVENT_TILE
+    target = F if which == "F" else R
+    # clear tile 1 (and, for R, the max_shift bits above it, which count towards its list), then place `count` bits in it
+    clear_hi = hi if which == "F" else hi + 1024
+    for wd in range(lo // 64, clear_hi // 64):
+        target[wd] = 0
+    target |= _exact_count_bits(rng, nbits, lo, hi, count)
+    M = synth.run_bits(rng, nbits, 3000, 900, 1, nbits - 300) if with_m else None
+    ref = oracle.calc_correlation(F, R, M, nbits, S, L)
+    out = ctx.calc_correlation(F, R, M, nbits, S, L, ffi.PMX_FLAG_FORCE_SPARSE)
+    check_block(out, ref, S, with_m)
+
+
+@pytest.mark.parametrize("n_edges", [EVENT_CAP_E - 2, EVENT_CAP_E, EVENT_CAP_E + 2])
+def test_event_edge_list_around_its_capacity(ctx, n_edges):
+    """Mappability runs placed so that the edges staged for tile 1 (the tile, 2048 bits below, 1152 above) number
+    n_edges: at most the capacity -> event kernel, more -> window kernel for that tile only."""
+    S, L = 500, 50
+    rng = np.random.default_rng(n_edges)
+    nbits = 3 * EVENT_TILE
+    F = synth.random_bits(rng, nbits, 0.004, 1, nbits - 700)
+    R = synth.random_bits(rng, nbits, 0.004, 1, nbits - 700)
+    bits = np.zeros(nbits, dtype=np.uint8)
+    # n_edges / 2 runs of 40 bits, 100 bits apart, from the start of tile 1 on; elsewhere two long runs
+    for i in range(n_edges // 2):
+        p = EVENT_TILE + 10 + 100 * i
+        bits[p:p + 40] = 1
+    bits[1000:30000] = 1
+    bits[2 * EVENT_TILE + 5000:2 * EVENT_TILE + 40000] = 1
+    M = np.packbits(bits, bitorder="little").view(np.uint64).copy()
+    ref = oracle.calc_correlation(F, R, M, nbits, S, L)
+    out = ctx.calc_correlation(F, R, M, nbits, S, L, ffi.PMX_FLAG_FORCE_SPARSE)
+    check_block(out, ref, S, True)
+
+
+@pytest.mark.parametrize("skip_ncc", [False, True])
+def test_dense_and_sparse_tiles_in_one_chromosome(ctx, skip_ncc):
+    """Read density 0.05 in the middle tiles, 0.004 elsewhere; mappability edges dense in another region: both kernels
+    contribute to every output row of the same result block."""
+    S, L = 1000, 36
+    rng = np.random.default_rng(99)
+    nbits = 6 * EVENT_TILE + 12345
+    F = synth.random_bits(rng, nbits, 0.004, 1, nbits - 1200)
+    R = synth.random_bits(rng, nbits, 0.004, 1, nbits - 1200)
+    F |= synth.random_bits(rng, nbits, 0.05, 2 * EVENT_TILE + 300, 3 * EVENT_TILE + 777)
+    R |= synth.random_bits(rng, nbits, 0.05, 3 * EVENT_TILE - 5000, 4 * EVENT_TILE)
+    M = synth.run_bits(rng, nbits, 2500, 700, 1, 4 * EVENT_TILE)
+    M |= synth.run_bits(rng, nbits, 30, 20, 4 * EVENT_TILE + 100, 5 * EVENT_TILE)
+    flags = ffi.PMX_FLAG_FORCE_SPARSE | (ffi.PMX_FLAG_SKIP_NCC if skip_ncc else 0)
+    ref = oracle.calc_correlation(F, R, M, nbits, S, L)
+    out = ctx.calc_correlation(F, R, M, nbits, S, L, flags)
+    check_block(out, ref, S, True, skip_ncc=skip_ncc)
+
+
+@pytest.mark.parametrize("S,L", [(3, 1), (5, 1024), (1023, 1), (1023, 1024), (64, 700), (700, 64)])
+def test_event_kernel_shift_and_read_length_corners(ctx, S, L):
+    """Smallest / largest shift range and read length of the event kernel (max_shift <= 1023, read_len <= 1024), and
+    read_len - 1 above / below max_shift (the two edge ranges of a reverse read then overlap differently)."""
+    rng = np.random.default_rng(S * 2048 + L)
+    nbits = 2 * EVENT_TILE + 4321
+    F = synth.random_bits(rng, nbits, 0.005, 0, nbits)
+    R = synth.random_bits(rng, nbits, 0.005, 0, nbits)
+    M = synth.run_bits(rng, nbits, 900, 300, 0, nbits)
+    for w in (F, R, M):
+        synth.set_bit(w, 0)
+        synth.set_bit(w, nbits - 1)
+    ref = oracle.calc_correlation(F, R, M, nbits, S, L)
+    out = ctx.calc_correlation(F, R, M, nbits, S, L, ffi.PMX_FLAG_FORCE_SPARSE)
+    check_block(out, ref, S, True)
+
+
+def test_window_kernel_alone_matches_the_event_path(ctx):
+    """PMX_CC_EVENTS=0 (read once per process) keeps every tile on the window kernel: a child process computes the same
+    case that way and both agree with the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import json, sys, numpy as np\n"
+        "from pymasc_amd import ffi\n"
+        "from tests import synth\n"
+        "nbits, F, R, M = synth.make_case(3, 200000, 1000, 36, 0.005, 0.005, True)\n"
+        "c = ffi.Context(0)\n"
+        "out = c.calc_correlation(F, R, M, nbits, 1000, 36, ffi.PMX_FLAG_FORCE_SPARSE)\n"
+        "print(json.dumps(np.asarray(out).astype(np.int64).tolist()))\n"
+    )
+    env = dict(os.environ, PMX_CC_EVENTS="0", PMX_AUTOCORR_PAIRS="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    child = np.asarray(json.loads(res.stdout.strip().splitlines()[-1]), dtype=np.int64)
+    nbits, F, R, M = synth.make_case(3, 200000, 1000, 36, 0.005, 0.005, True)
+    here = np.asarray(ctx.calc_correlation(F, R, M, nbits, 1000, 36, ffi.PMX_FLAG_FORCE_SPARSE)).astype(np.int64)
+    np.testing.assert_array_equal(child, here)
+    check_block(here, oracle.calc_correlation(F, R, M, nbits, 1000, 36), 1000, True)
