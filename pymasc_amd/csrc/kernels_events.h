@@ -38,8 +38,7 @@
 #define EV_CAPR 640u                      // reverse reads of the tile + of the max_shift bits above it
 #define EV_CAPE 384u                      // run edges of everything staged
 #define EV_POS 0x1ffffu                   // 17 bits of biased position
-#define EV_HROW 1088u                      // histogram row: 1024 shifts + [1024 + lane] = where lane's missing events are added
-                                          // (one slot per lane: LDS atomics of a wave to ONE address are serialised)
+#define EV_SEG_ROWS 6u                    // slab segment rows of 1024 u32: ncc, GF, cc, GR, scalars, EE
 #ifndef EV_WAVES
 #define EV_WAVES 4
 #endif
@@ -62,17 +61,27 @@
 #define EV_STAMP(i)
 #endif
 
+// LDS (dwords).  Histogram rows of 1024 i32: ncc, cc, GF, GR, EE (NCC-only: ncc).  An event that misses is not predicated
+// away but added to a DUMP slot, one per lane (LDS atomics of a wave to ONE address are serialised): a row r reaches the 64
+// slots of DUMP_A with the row-relative index (NROWS - r) * 1024 + lane.  The pair loop adds to rows ncc AND cc with ONE
+// index, so the same index must be harmless from row cc too: that is DUMP_B, 1024 dwords after DUMP_A, and the forward and
+// edge lists live in the gap.
 template <bool HAS_M>
 struct EvLds {
-    static constexpr u32 HIST = 0;                                  // rows of EV_HROW i32: ncc, GF, cc, GR (NCC-only: ncc)
-    static constexpr u32 MT0 = HIST + (HAS_M ? 4 * EV_HROW : EV_HROW);      // [3] = the dword below the staged range, [4..] = M
+    static constexpr u32 HIST = 0;
+    static constexpr u32 NROWS = HAS_M ? 5u : 1u;
+    static constexpr u32 DUMP_A = HIST + NROWS * 1024;
+    static constexpr u32 LF = DUMP_A + 64;
+    static constexpr u32 LE = LF + EV_CAPF;
+    static constexpr u32 DUMP_B = HAS_M ? DUMP_A + 1024 : LE;
+    static constexpr u32 LR = HAS_M ? DUMP_B + 64 : LE;
+    static constexpr u32 WT = LR + EV_CAPR + 4;                     // (+4: the event loops read two entries per trip, two ahead)
+    static constexpr u32 MISC = WT + 32;                            // WT: [5][4 waves] scan totals
+    static constexpr u32 MT0 = MISC + 16;                           // [3] = the dword below the staged range, [4..] = M
     static constexpr u32 PREF = MT0 + (HAS_M ? 4u + EV_MW : 0u);    // u16 per staged dword: edges before it
-    static constexpr u32 LF = PREF + (HAS_M ? (EV_MW + 3) / 4 * 2 : 0u);
-    static constexpr u32 LR = LF + EV_CAPF;
-    static constexpr u32 LE = LR + EV_CAPR + 4;                     // (+4: the event loops read two entries per trip, two ahead)
-    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE + 4 : 0u);          // [5][4 waves] scan totals
-    static constexpr u32 MISC = WT + 32;
-    static constexpr u32 TOTAL = MISC + 16;
+    static constexpr u32 TOTAL = PREF + (HAS_M ? (EV_MW + 3) / 4 * 2 + 2 : 0u);
+    static_assert(!HAS_M || LE + EV_CAPE + 4 <= DUMP_B, "the lists must fit between the dump areas");
+    static_assert(MT0 % 4 == 0 && PREF % 2 == 0, "alignment of the 16-byte / 8-byte stores");
 };
 
 struct EvRegs {
@@ -193,18 +202,23 @@ __device__ __forceinline__ u32 ev_rank_e(const u32 *MT, const unsigned short *pr
     return (u32)pref16[w] + __popc(ew & ((1u << (q & 31u)) - 1u));
 }
 
-// slab segment of a (workgroup, job) pair: SP_SEG_ROWS rows of 1024 u32: ncc, GF, cc, GR, scalars (|F|, |R|, Bf, R0)
-template <bool HAS_M, bool DO_NCC>
+// slab segment of a (workgroup, job) pair: EV_SEG_ROWS rows of 1024 u32: ncc, GF, cc, GR, scalars (|F|, |R|, Bf, R0,
+// popcount(M), runs), EE
+// DO_MLEN: also the pairs of run edges (the mappable-length autocorrelation, see k_autocorr_pairs): EE[k] = sum of
+// E[j] E[j + k] over the edges j of the tile, k = 1..max_lag, and popcount(M) / the runs starting in the tile.
+template <bool HAS_M, bool DO_NCC, bool DO_MLEN>
 __global__ void __launch_bounds__(256, HAS_M ? EV_WAVES : EV_WAVES_NCC)
-k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr,
-            u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags, u32 *__restrict__ n_flagged)
+k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr, u32 max_lag,
+            u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags, unsigned char *__restrict__ tile_flags_ac,
+            u32 *__restrict__ n_flagged)
 {
     typedef EvLds<HAS_M> L;
     __shared__ __align__(16) u32 lds[L::TOTAL];
     u32 *const hN = lds + L::HIST;
-    u32 *const hGF = lds + L::HIST + (HAS_M ? 1 * EV_HROW : 0u);
-    u32 *const hC = lds + L::HIST + (HAS_M ? 2 * EV_HROW : 0u);
-    u32 *const hGR = lds + L::HIST + (HAS_M ? 3 * EV_HROW : 0u);
+    u32 *const hC = lds + L::HIST + (HAS_M ? 1 * 1024u : 0u);
+    u32 *const hGF = lds + L::HIST + (HAS_M ? 2 * 1024u : 0u);
+    u32 *const hGR = lds + L::HIST + (HAS_M ? 3 * 1024u : 0u);
+    u32 *const hEE = lds + L::HIST + (HAS_M ? 4 * 1024u : 0u);
     u32 *const MT = lds + L::MT0 + 4;
     unsigned short *const pref16 = reinterpret_cast<unsigned short *>(lds + L::PREF);
     u32 *const LF = lds + L::LF;
@@ -221,7 +235,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     {
         const u32 tid = tid_;
 #pragma nounroll
-        for (u32 i = tid; i < (HAS_M ? 4 * EV_HROW : EV_HROW); i += 256) lds[L::HIST + i] = 0;
+        for (u32 i = tid; i < L::NROWS * 1024; i += 256) lds[L::HIST + i] = 0;
     }
 
     u32 ji = 0;
@@ -233,6 +247,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     ev_fetch_job<HAS_M>(er, pj, g0 - pj.tile0, tid_, nhr);
     u32 cur_tile0 = pj.tile0, cur_flag0 = pj.flag0;   // of the job whose tile is being processed (index ji)
     u32 cntF = 0, cntR = 0, cntB = 0, cnt0 = 0;   // per-thread: |F|, |R|, Bf, R0 of the tiles taken here
+    u32 cntM = 0, cntU = 0;                       // DO_MLEN: popcount(M), runs starting in them
 #ifdef EV_STAMPS
     unsigned long long stamp_acc[EV_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last;
@@ -249,14 +264,20 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         u32 tid = tid_;
         asm volatile("" : "+v"(tid));
         const u32 lane = tid & 63;
-        u32 cF[EV_NQ], cR[EV_NQ], cE[EV_NQ] = {0, 0}, cEh = 0, cRh = 0;
+        u32 cF[EV_NQ], cR[EV_NQ], cE[EV_NQ] = {0, 0}, cEh = 0, cRh = 0, pendM = 0, pendU = 0;
 #pragma unroll
         for (u32 q = 0; q < EV_NQ; q++) {
             cF[q] = popc4(er.f[q]);
             cR[q] = popc4(er.r[q]);
             if (HAS_M) {
-                cE[q] = popc4(edge_words(er.m[q], ev_below(er.m[q].w, er.wb[q])));   // (recomputed when they are emitted)
+                const u32 bel = ev_below(er.m[q].w, er.wb[q]);
+                cE[q] = popc4(edge_words(er.m[q], bel));   // (the edge words are recomputed when they are emitted)
                 *reinterpret_cast<uint4 *>(MT + EV_LO + q * SP_TBW + 4 * tid) = er.m[q];
+                if (DO_MLEN) {
+                    pendM += popc4(er.m[q]);
+                    // run starts = rising edges; rising - falling = M[last bit of the quad] - M[bit before it]
+                    pendU += (cE[q] + (er.m[q].w >> 31) - (bel >> 31)) >> 1;
+                }
             }
         }
         const bool h_below = HAS_M && wave == 1 && lane < 16, h_above = HAS_M && wave == 2 && lane < 9;
@@ -350,10 +371,13 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             else if (HAS_M && tid < 8) LE[nE + tid - 4] = EV_POS;
             cntF += cF[0] + cF[1];
             cntR += cR[0] + cR[1];
+            cntM += pendM;
+            cntU += pendU;
         } else if (tid == 0) {
             // dense tile: left to k_cc_sparse (both of its 32-Kbit tiles; the flag array is padded per job)
             const u32 f = cur_flag0 + EV_NQ * (g - cur_tile0);
             for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
+            if (DO_MLEN) tile_flags_ac[cur_flag0 + (g - cur_tile0)] = 1;   // (its window tile is this tile; same padded indexing)
             atomicAdd(n_flagged, 1u);
         }
         EV_STAMP(3)
@@ -374,7 +398,8 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             // round trips, not by instruction issue: every trip takes two list entries, the next two are already in flight,
             // and the M bits of both are looked up together.
             const u32 nbF = (nF + 63) >> 6, nbR = (nRt + 63) >> 6;
-            const u32 dump = 1024u + lane;
+            // row-relative dump indices (see EvLds)
+            const u32 dumpN = L::NROWS * 1024 + lane, dumpGF = dumpN - 2048, dumpGR = dumpN - 3072, dumpEE = dumpN - 4096;
 #ifndef EV_ABL_NOFR
             // ---- forward reads x reverse reads in [x, x + S]: ncc, mscc.cc ----
             // No predication: an event that misses is added to the lane's dump slot of the row; idle lanes carry x = 0
@@ -393,7 +418,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     r = h1 ? r + 2 : nR;
                     y0 = LR[r];
                     y1 = LR[r + 1];
-                    const u32 a0 = h0 ? d0 : dump, a1 = h1 ? d1 : dump;
+                    const u32 a0 = h0 ? d0 : dumpN, a1 = h1 ? d1 : dumpN;   // (row cc reaches DUMP_B with the same index)
                     if (HAS_M) {
                         const u32 q0 = xc - (h0 ? d0 : 0u), q1 = xc - (h1 ? d1 : 0u);
                         const u32 m0 = MT[q0 >> 5], m1 = MT[q1 >> 5];
@@ -426,8 +451,8 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                         const u32 p0 = e0 & EV_POS, p1 = e1 & EV_POS;
                         const bool h0 = p0 <= hi, h1 = p1 <= hi;
                         if (!__ballot(h0)) break;
-                        atomicAdd(&hGF[h0 ? hi - p0 + 1 : dump], (u32)(((int32_t)e0 >> 31) | 1));   // E[j]: -1 falling, +1 rising
-                        atomicAdd(&hGF[h1 ? hi - p1 + 1 : dump], (u32)(((int32_t)e1 >> 31) | 1));
+                        atomicAdd(&hGF[h0 ? hi - p0 + 1 : dumpGF], (u32)(((int32_t)e0 >> 31) | 1));   // E[j]: -1 falling, +1 rising
+                        atomicAdd(&hGF[h1 ? hi - p1 + 1 : dumpGF], (u32)(((int32_t)e1 >> 31) | 1));
                         e = h1 ? e + 2 : nE;
                         e0 = LE[e];
                         e1 = LE[e + 1];
@@ -454,7 +479,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                         // shifts (or the lane's dump slot) and the positions of the weights (a miss looks up a staged bit near p)
                         const u32 dA0 = hA0 ? p - pa0 + 1 : 0u, dA1 = hA1 ? p - pa1 + 1 : 0u;
                         const u32 dB0 = hB0 ? (hi - pb0 + 2) >> 1 : 0u, dB1 = hB1 ? (hi - pb1 + 2) >> 1 : 0u;
-                        const u32 tA0 = hA0 ? dA0 : dump, tA1 = hA1 ? dA1 : dump, tB0 = hB0 ? dB0 : dump, tB1 = hB1 ? dB1 : dump;
+                        const u32 tA0 = hA0 ? dA0 : dumpGR, tA1 = hA1 ? dA1 : dumpGR, tB0 = hB0 ? dB0 : dumpGR, tB1 = hB1 ? dB1 : dumpGR;
                         const u32 qA0 = hi - 2 * dA0, qA1 = hi - 2 * dA1;
                         const u32 qB0 = p + 1 - dB0, qB1 = p + 1 - dB1;
                         const u32 mA0 = MT[qA0 >> 5], mA1 = MT[qA1 >> 5], mB0 = MT[qB0 >> 5], mB1 = MT[qB1 >> 5];
@@ -474,38 +499,69 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     }
                 }
 #endif
+            // ---- run edges of the tile x the edges within max_lag above them: the mappable-length autocorrelation ----
+            if (DO_MLEN) {
+                const u32 nEt = TE0 + TE1;   // the tile's own edges sit at list indices [TXb, TXb + nEt)
+                for (u32 b = (wave + 1) & 3; 64 * b < nEt; b += 4) {
+                    const u32 i = 64 * b + lane;
+                    const bool in = i < nEt;
+                    const u32 ent = in ? LE[TXb + i] : 0u;
+                    const u32 pos = ent & EV_POS, hi = pos + max_lag;
+                    u32 e = in ? TXb + i + 1 : nE;
+                    u32 e0 = LE[e], e1 = LE[e + 1];
+                    for (;;) {
+                        const u32 p0 = e0 & EV_POS, p1 = e1 & EV_POS;
+                        const bool h0 = p0 <= hi, h1 = p1 <= hi;
+                        if (!__ballot(h0)) break;
+                        atomicAdd(&hEE[h0 ? p0 - pos : dumpEE], (u32)(((int32_t)(e0 ^ ent) >> 31) | 1));   // E[j] E[j + k]
+                        atomicAdd(&hEE[h1 ? p1 - pos : dumpEE], (u32)(((int32_t)(e1 ^ ent) >> 31) | 1));
+                        e = h1 ? e + 2 : nE;
+                        e0 = LE[e];
+                        e1 = LE[e + 1];
+                    }
+                }
+            }
         }
         EV_STAMP(7)
         const bool leaving = jn != ji || g + 1 == g1;
         if (leaving) {
             // histograms + scalars of this (workgroup, job) -> its slab segment; cleared for the next job
             __syncthreads();
-            u32 *seg = slab + (size_t)(blockIdx.x + ji) * SP_SEG_ROWS * 1024;
-#pragma nounroll   // (unrolled, its sixteen index registers are hoisted out of the tile loop and spill)
-            for (u32 i = tid; i < (HAS_M ? 4096u : 1024u); i += 256) {
-                u32 *h = lds + L::HIST + (i >> 10) * EV_HROW + (i & 1023u);
-                seg[i] = *h;
-                *h = 0;
+            u32 *seg = slab + (size_t)(blockIdx.x + ji) * EV_SEG_ROWS * 1024;
+#pragma nounroll   // (unrolled, its index registers are hoisted out of the tile loop and spill)
+            for (u32 i = tid; i < L::NROWS * 1024; i += 256) {
+                // LDS rows ncc, cc, GF, GR, EE -> segment rows 0, 2, 1, 3, 5
+                const u32 r = i >> 10, sr = r == 1 ? 2u : (r == 2 ? 1u : (r == 4 ? 5u : r));
+                if (r < 4 || DO_MLEN) seg[sr * 1024 + (i & 1023u)] = lds[L::HIST + i];
+                lds[L::HIST + i] = 0;
             }
-            u32 v0 = cntF, v1 = cntR, v2 = cntB, v3 = cnt0;
-            for (int off = 32; off > 0; off >>= 1) {
-                v0 += __shfl_down(v0, off, 64);
-                v1 += __shfl_down(v1, off, 64);
-                v2 += __shfl_down(v2, off, 64);
-                v3 += __shfl_down(v3, off, 64);
+            // scalars: |F|, |R|, Bf, R0, popcount(M), runs -> row 4 of the segment (two rounds through misc[16])
+            u32 v[6] = {cntF, cntR, cntB, cnt0, cntM, cntU};
+#pragma unroll
+            for (u32 k = 0; k < 6; k++)
+                for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+#pragma unroll
+            for (u32 round = 0; round < 2; round++) {
+                if (round == 1 && !DO_MLEN) break;
+                if (lane == 0) {
+                    misc[wave] = v[round * 4 + 0];
+                    misc[4 + wave] = v[round * 4 + 1];
+                    if (round == 0) {
+                        misc[8 + wave] = v[2];
+                        misc[12 + wave] = v[3];
+                    }
+                }
+                __syncthreads();
+                if (tid < (round == 0 ? 4u : 2u))
+                    seg[4 * 1024 + round * 4 + tid] = misc[4 * tid] + misc[4 * tid + 1] + misc[4 * tid + 2] + misc[4 * tid + 3];
+                __syncthreads();
             }
-            if (lane == 0) {
-                misc[wave] = v0;
-                misc[4 + wave] = v1;
-                misc[8 + wave] = v2;
-                misc[12 + wave] = v3;
-            }
-            __syncthreads();
-            if (tid < 4) seg[4 * 1024 + tid] = misc[4 * tid] + misc[4 * tid + 1] + misc[4 * tid + 2] + misc[4 * tid + 3];
             cntF = 0;
             cntR = 0;
             cntB = 0;
             cnt0 = 0;
+            cntM = 0;
+            cntU = 0;
         }
         ji = jn;
         cur_tile0 = pj.tile0;
@@ -513,7 +569,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     }
 #ifdef EV_STAMPS
     if ((tid_ & 63) == 0) {
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(slab + (size_t)(gridDim.x + njobs) * SP_SEG_ROWS * 1024);
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(slab + (size_t)(gridDim.x + njobs) * EV_SEG_ROWS * 1024);
         for (int i = 0; i < EV_NSTAMP; i++) dbg[((size_t)blockIdx.x * 4 + wave) * EV_NSTAMP + i] = stamp_acc[i];
     }
 #endif
@@ -530,7 +586,7 @@ k_events_finish(const u32 *__restrict__ slab, const SpJobTable jobs, u32 S, u32 
     const SpJobDev &jb = jobs.j[job];
     long long bf = 0, r0 = 0;
     for (u32 w = jb.wg_first + tid; w <= jb.wg_last; w += 256) {
-        const u32 *sc = slab + (size_t)(w + job) * SP_SEG_ROWS * 1024 + 4 * 1024;
+        const u32 *sc = slab + (size_t)(w + job) * EV_SEG_ROWS * 1024 + 4 * 1024;
         bf += sc[2];
         r0 += sc[3];
     }

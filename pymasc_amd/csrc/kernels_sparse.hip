@@ -1028,37 +1028,39 @@ struct ReduceSpec {
     u32 use_out2;       // autocorrelation: rows go to out2 (per-job scratch) instead of the result block
     u32 accumulate;     // sums are ADDED to what an earlier pass (pair / event kernel) left in the destination
     u32 is_signed[5];   // the slab row holds i32 (event histograms of edge signs)
+    u32 scalar_off;     // first of the two scalars in the slab's scalar row
+    u32 n_override;     // entries per row (0: the job's d_n)
     u32 keep_scalar2;   // scalar [2] (popcount(M)) belongs to the autocorrelation pass, which may run concurrently
     u32 nzero;          // rows of the result block this batch does not produce: written as zeros (chunk 0 only)
     u32 zero_row[5];
 };
 
-__global__ void __launch_bounds__(256)
-k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_rows, ReduceSpec rs,
-                  const u32 *__restrict__ gate)
+__device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab, const SpJobTable &jobs, u32 seg_rows,
+                                                    const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r)
 {
     const bool live = !gate || *gate != 0;   // gate == 0: the producing kernel did not run, every sum is zero
     if (!live && rs.accumulate) return;      // ... and there is nothing to add
     // 32 consecutive elements x 8 workgroup phases per block: every load is a full 128-B line
     __shared__ u64 part[8][32];
-    const u32 r = blockIdx.y, job = blockIdx.z;
+    const u32 job = blockIdx.z;
     const SpJobDev &jb = jobs.j[job];
     const u32 e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const u32 i = blockIdx.x * 32 + e;
     if (r >= rs.nrows) {   // a row this batch leaves empty
         if ((jb.flags & 1u) && g == 0 && !rs.accumulate) {
-            u64 *dst = jb.out + (size_t)rs.zero_row[r - rs.nrows] * rs.out_stride;
-            for (u32 k = i; k < rs.out_stride; k += gridDim.x * 32) dst[k] = 0;
+            u64 *dst = rs.use_out2 ? jb.out2 + rs.zero_row[r - rs.nrows] : jb.out + (size_t)rs.zero_row[r - rs.nrows] * rs.out_stride;
+            const u32 cnt = rs.use_out2 ? (rs.n_override ? rs.n_override : jb.d_n) : rs.out_stride;
+            for (u32 k = i; k < cnt; k += gridDim.x * 32) dst[k] = 0;
         }
         return;
     }
     const bool scalar = rs.is_scalar[r] != 0;
     if (scalar && !(jb.flags & 1u)) return;
-    const u32 n = scalar ? 2u : jb.d_n;
+    const u32 n = scalar ? 2u : (rs.n_override ? rs.n_override : jb.d_n);
     u64 sum = 0;
     if (i < n && live) {
         const size_t stride = (size_t)seg_rows * 1024;
-        const u32 *p = slab + (size_t)rs.src_row[r] * 1024 + i;
+        const u32 *p = slab + (size_t)rs.src_row[r] * 1024 + (scalar ? rs.scalar_off : 0u) + i;
         if (rs.is_signed[r])
             for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 8) sum += (u64)(long long)(int32_t)p[(size_t)(w + job) * stride];
         else
@@ -1089,6 +1091,24 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
         u64 *dst = jb.out + (size_t)rs.dst_row[r] * rs.out_stride + jb.d_off + i;
         *dst = rs.accumulate ? *dst + t : t;
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_rows, ReduceSpec rs,
+                  const u32 *__restrict__ gate)
+{
+    reduce_segments_row(slab, jobs, seg_rows, rs, gate, blockIdx.y);
+}
+
+// two specifications over the same slab in one launch (grid.y = rows of A + rows of B)
+__global__ void __launch_bounds__(256)
+k_reduce_segments2(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_rows, ReduceSpec rsA, ReduceSpec rsB)
+{
+    const u32 rowsA = rsA.nrows + rsA.nzero;   // (uniform over the block)
+    if (blockIdx.y < rowsA)
+        reduce_segments_row(slab, jobs, seg_rows, rsA, nullptr, blockIdx.y);
+    else
+        reduce_segments_row(slab, jobs, seg_rows, rsB, nullptr, blockIdx.y - rowsA);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1696,20 +1716,20 @@ k_reduce_pairs(const u32 *__restrict__ slab, const SpJobTable jobs, u32 nl, u32 
 // and scalar [2] = popcount(M).
 __device__ __forceinline__ long long block_exclusive_offset(long long local_sum, long long *part, u32 tid)
 {
-    part[tid] = local_sum;
-    __syncthreads();
-    if (tid == 0) {
-        long long run = 0;
-        for (u32 i = 0; i < 256; i++) {
-            const long long v = part[i];
-            part[i] = run;
-            run += v;
-        }
+    // inclusive scan over the wave (shuffles), wave totals through LDS; ends with a barrier (part may be reused)
+    long long x = local_sum;
+    const u32 lane = tid & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long y = __shfl_up(x, off, 64);
+        if (lane >= (u32)off) x += y;
     }
+    if (lane == 63) part[tid >> 6] = x;
     __syncthreads();
-    const long long off = part[tid];
+    long long base = 0;
+    for (u32 w = 0; w < (tid >> 6); w++) base += part[w];
     __syncthreads();
-    return off;
+    return base + x - local_sum;
 }
 
 __global__ void __launch_bounds__(256)
@@ -1841,9 +1861,30 @@ static void expand_chunks(const pmx_job *jobs, uint32_t njobs, uint32_t nshifts,
         }
 }
 
-int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
-                               uint32_t read_len, bool do_ncc, uint32_t out_stride, bool zero_mlen)
+static bool events_enabled()
 {
+    // PMX_CC_EVENTS=0 in the environment keeps everything on the window kernel (A/B measurements, tests)
+    static const bool on = [] {
+        const char *e = getenv("PMX_CC_EVENTS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+int pmx_events_can_fuse_mlen(uint32_t max_shift, uint32_t max_lag)
+{
+    static const bool fuse = [] {   // PMX_CC_FUSE_MLEN=0: the mappable-length pass stays a pass of its own
+        const char *e = getenv("PMX_CC_FUSE_MLEN");
+        return !(e && e[0] == '0');
+    }();
+    return events_enabled() && fuse && max_shift <= 1023 && max_lag <= 1023;   // one histogram row of 1024 lags
+}
+
+int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
+                               uint32_t read_len, bool do_ncc, uint32_t out_stride, bool zero_mlen,
+                               uint32_t fused_lag, pmx_fused_mlen *fused)
+{
+    if (fused) fused->done = false;
     if (njobs == 0) return PMX_OK;
     const bool has_m = jobs[0].d_M != nullptr;
     if (!has_m && !do_ncc) return PMX_OK;
@@ -1877,13 +1918,9 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     rs.keep_scalar2 = (has_m && !zero_mlen) ? 1 : 0;
 
     // Pass 1 (sparse tiles): the event kernel over every chromosome; tiles whose lists would overflow are flagged.
-    // PMX_CC_EVENTS=0 in the environment keeps everything on the window kernel (A/B measurements, tests).
-    static const bool events_enabled = [] {
-        const char *e = getenv("PMX_CC_EVENTS");
-        return !(e && e[0] == '0');
-    }();
-    const bool use_events = events_enabled && !chunked;
-    unsigned char *d_flags = nullptr;
+    const bool use_events = events_enabled() && !chunked;
+    const bool fuse_mlen = use_events && has_m && fused && njobs <= SP_MAXJOBS && pmx_events_can_fuse_mlen(max_shift, fused_lag);
+    unsigned char *d_flags = nullptr, *d_flags_ac = nullptr;
     u32 *d_nflagged = nullptr;
     if (use_events) {
         uint64_t total_flags = 0;
@@ -1892,11 +1929,19 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             total_flags += (vjobs[i].job->nbits + SP_TB - 1) / SP_TB + EV_NQ;   // padding: an event tile flags EV_NQ window tiles
         }
         const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
-        int rc = pmx_ensure_flags_cc(ctx, flag_bytes + 16);
+        int rc = pmx_ensure_flags_cc(ctx, 2 * flag_bytes + 16);
         if (rc) return rc;
-        d_flags = ctx->d_flags_cc;
-        d_nflagged = (u32 *)(ctx->d_flags_cc + flag_bytes);
-        PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, flag_bytes + 16, ctx->stream));
+        d_flags = ctx->d_flags_cc;                   // tiles of the cross-correlation window kernel (32 Kbit)
+        d_flags_ac = ctx->d_flags_cc + flag_bytes;   // tiles of the autocorrelation window kernel (64 Kbit), same flag0 per job
+        d_nflagged = (u32 *)(ctx->d_flags_cc + 2 * flag_bytes);
+        PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, 2 * flag_bytes + 16, ctx->stream));
+        if (fuse_mlen) {
+            fused->done = true;
+            fused->d_flags = d_flags_ac;
+            fused->d_nflagged = d_nflagged;
+            fused->flag0.resize(njobs);
+            for (uint32_t i = 0; i < njobs; i++) fused->flag0[i] = vjobs[i].flag0;
+        }
     }
     ReduceSpec rs_ev = rs;
     for (u32 i = 0; i < nr; i++)
@@ -1912,23 +1957,43 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         if (use_events) {
             memset(&tab, 0, sizeof tab);
             plan_launch(ctx, &vjobs[lo], n, false, has_m ? EV_WAVES : EV_WAVES_NCC, &tab, &total, &tpw, &nwg, EV_TB);
-            rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
+            rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * EV_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
             if (rc) return rc;
             rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_EVENTS, &tl);
             if (rc) return rc;
             const u32 nhr = (max_shift + 1 + 127) / 128;   // quads of R above a tile that hold partners of its forward reads
-#define EV_LAUNCH(HM, NC)                                                                                             \
-    hipLaunchKernelGGL((k_cc_events<HM, NC>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, (u32)c, max_shift, \
-                       nhr, ctx->d_slab, d_flags, d_nflagged)
-            if (has_m && do_ncc) EV_LAUNCH(true, true);
-            else if (has_m) EV_LAUNCH(true, false);
-            else EV_LAUNCH(false, true);
+#define EV_LAUNCH(HM, NC, ML)                                                                                          \
+    hipLaunchKernelGGL((k_cc_events<HM, NC, ML>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, (u32)c,     \
+                       max_shift, nhr, fused_lag, ctx->d_slab, d_flags, d_flags_ac, d_nflagged)
+            if (has_m && do_ncc && fuse_mlen) EV_LAUNCH(true, true, true);
+            else if (has_m && do_ncc) EV_LAUNCH(true, true, false);
+            else if (has_m && fuse_mlen) EV_LAUNCH(true, false, true);
+            else if (has_m) EV_LAUNCH(true, false, false);
+            else EV_LAUNCH(false, true, false);
 #undef EV_LAUNCH
             PMX_CHECK_LAUNCH("k_cc_events");
             rc = pmx_prof_end(ctx, &tl);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab,
-                               (u32)SP_SEG_ROWS, rs_ev, (const u32 *)nullptr);
+            if (fuse_mlen) {
+                // the edge-pair sums EE = P - N go to the P row of the per-job scratch as signed numbers, N is cleared,
+                // popcount(M) and the run count to its scalars: what k_autocorr_pairs + k_reduce_pairs leave there
+                const u32 lagcap = (u32)(((size_t)fused_lag + 1 + 1023) / 1024 * 1024);
+                ReduceSpec r2;
+                memset(&r2, 0, sizeof r2);
+                r2.nrows = 2;
+                r2.src_row[0] = 5; r2.dst_row[0] = 0; r2.is_signed[0] = 1;
+                r2.src_row[1] = 4; r2.dst_row[1] = 2 * lagcap; r2.is_scalar[1] = 1; r2.scalar_off = 4;
+                r2.nzero = 1;
+                r2.zero_row[0] = lagcap;
+                r2.use_out2 = 1;
+                r2.n_override = fused_lag + 1;
+                r2.out_stride = out_stride;
+                hipLaunchKernelGGL(k_reduce_segments2, dim3(32, nr + nz + 3, n), dim3(256), 0, ctx->stream,
+                                   (const u32 *)ctx->d_slab, tab, (u32)EV_SEG_ROWS, rs_ev, r2);
+            } else {
+                hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab,
+                                   tab, (u32)EV_SEG_ROWS, rs_ev, (const u32 *)nullptr);
+            }
             PMX_CHECK_LAUNCH("k_reduce_segments");
             if (has_m) {
                 hipLaunchKernelGGL(k_events_finish, dim3(n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, max_shift,
@@ -1978,7 +2043,7 @@ size_t pmx_autocorr_scratch_words(uint32_t max_lag)
 // mode 0: jobs[i].d_out[k] = A(k), k <= max_lag.  mode 1: jobs[i].d_out is a result block: row MLEN[d] = A(|L-1-d|),
 // scalar [2] = popcount(M).
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag, uint32_t mode,
-                                    uint32_t read_len, uint32_t max_shift, uint32_t out_stride)
+                                    uint32_t read_len, uint32_t max_shift, uint32_t out_stride, const pmx_fused_mlen *fused)
 {
     if (njobs == 0) return PMX_OK;
     const bool chunked = max_lag > 1023;
@@ -1991,12 +2056,17 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         const char *e = getenv("PMX_AUTOCORR_PAIRS");
         return !(e && e[0] == '0');
     }();
-    const bool use_pairs = pairs_enabled && max_lag + 1 <= AP_MAX_LAGS;
+    const bool fused_done = fused && fused->done && fused->flag0.size() == njobs;   // the event kernel was pass 1
+    const bool use_pairs = fused_done || (pairs_enabled && max_lag + 1 <= AP_MAX_LAGS);
     std::vector<uint32_t> flag0(njobs, 0);
     unsigned char *d_flags = nullptr;
     u32 *d_nflagged = nullptr;
     const u32 nl = (max_lag + 1 + 63) / 64 * 64;
-    if (use_pairs) {
+    if (fused_done) {
+        flag0 = fused->flag0;
+        d_flags = const_cast<unsigned char *>(fused->d_flags);
+        d_nflagged = const_cast<u32 *>(fused->d_nflagged);
+    } else if (use_pairs) {
         uint64_t total_flags = 0;
         for (uint32_t i = 0; i < njobs; i++) {
             flag0[i] = (uint32_t)total_flags;

@@ -683,6 +683,16 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         // forked, 16.5 ms in sequence): the pair pass then holds 40 KB of histograms per workgroup
         const bool fork = fork_enabled && max_shift <= 1023;
         int rc;
+        if (do_mlen && pmx_events_can_fuse_mlen(max_shift, max_lag)) {
+            // the event kernel stages M and lists its run edges anyway: it takes the edge pairs of the mappable-length pass
+            // too, and only the window kernel for the tiles it flagged + the recurrence remain of that pass
+            pmx_fused_mlen fm;
+            rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, false, max_lag, &fm);
+            if (rc) return rc;
+            rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride, &fm);
+            if (rc) return rc;
+            continue;
+        }
         if (do_mlen && !fork) {
             rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
             if (rc) return rc;

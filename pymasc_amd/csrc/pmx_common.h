@@ -102,17 +102,31 @@ struct pmx_job {
     uint64_t *d_out;                   // result block [PMX_NROWS][out_stride] (or the lag row, autocorr mode 0)
     uint64_t *d_out2;                  // autocorrelation only: pmx_autocorr_scratch_words(max_lag) u64 of per-job scratch
 };
+// What the event kernel already did of the mappable-length pass (pmx_launch_cc_sparse_batch hands this to
+// pmx_launch_autocorr_edges_batch): the edge-pair sums and scalars of every tile it took are in the jobs' d_out2; the tiles
+// it flagged as dense are left to the window kernel.
+struct pmx_fused_mlen {
+    bool done;
+    const unsigned char *d_flags;      // indexed flag0[job] + tile (tiles of 64 Kbit)
+    const u32 *d_nflagged;
+    std::vector<uint32_t> flag0;
+};
 int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len);
+// the event kernel can also take the edge pairs of the mappable-length pass for this geometry (and is not disabled)
+int pmx_events_can_fuse_mlen(uint32_t max_shift, uint32_t max_lag);
 uint32_t pmx_sparse_max_jobs(void);
 // Writes rows NCC_CCBINS / MSCC_FSUM / MSCC_CCBINS / MSCC_RSUM and the scalar row of every job's result block
 // (rows the batch does not produce are written as zeros, MLEN included when there is no mappability).
 int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
-                               uint32_t read_len, bool do_ncc, uint32_t out_stride, bool zero_mlen);
+                               uint32_t read_len, bool do_ncc, uint32_t out_stride, bool zero_mlen,
+                               uint32_t fused_lag = 0xffffffffu, pmx_fused_mlen *fused = nullptr);
+// fused_lag / fused: let the event kernel enumerate the edge pairs up to that lag as well (njobs <= pmx_sparse_max_jobs())
 // zero_mlen == false: the autocorrelation pass (possibly running concurrently) owns row MLEN and scalar [2]: both are left alone
 // Run-edge autocorrelation of every job's d_M.  mode 0: d_out[k] = A(k), k <= max_lag.
 // mode 1: d_out is a result block: row MLEN[d] = A(|read_len - 1 - d|), d <= max_shift; scalar [2] = popcount(M).
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag,
-                                    uint32_t mode, uint32_t read_len, uint32_t max_shift, uint32_t out_stride);
+                                    uint32_t mode, uint32_t read_len, uint32_t max_shift, uint32_t out_stride,
+                                    const pmx_fused_mlen *fused = nullptr);
 int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_slab2(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_slab_ac(pmx_ctx *ctx, size_t u32_words);
