@@ -317,7 +317,7 @@ def main():
         end_to_end = {"value": work_per_step / dt, "unit": "shifts*bp/s", "ms_per_step": dt * 1e3, "steps": n_e2e,
                       "h2d_bytes_this_rank": h2d, "d2h_bytes": int(host_rows.numel() * 8),
                       "what": "positions + intervals in host memory -> pmx_bits_set_positions/_regions (H2D copy + "
-                              "builder kernels) -> k_cc_sparse + k_autocorr -> exchange -> rows in host memory"}
+                              "builder kernels) -> k_cc_events (+ window kernels for dense tiles) -> exchange -> rows in host memory"}
 
     result = {
         "metric": "shifts*genome-bp/sec (whole node), hg38 max_shift=1000; HBM-BW fraction",
@@ -361,9 +361,9 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
         },
         "pipe_utilisation": pipe_utilisation(ctx.kernel_name(dom), default_workload),
-        # HIP-event durations on the stream each kernel runs on; the mappable-length pass runs on the context's auxiliary
-        # stream BESIDE k_cc_sparse, so its figure includes the time it waits for CUs and the figures do not add up to
-        # ms_per_step
+        # HIP-event durations per step.  k_cc_events takes the sparse tiles (and the run-edge pairs of the mappable-length
+        # pass); k_cc_sparse / k_autocorr_pairs+edges are the window kernels, which only see the tiles it flagged as dense
+        # (none on this workload: their figure is an empty launch) -- or everything when max_shift > 1023
         "kernel_ms_per_step": kernel_ms_per_step,
         "value_end_to_end": end_to_end["value"] if end_to_end else None,
         "end_to_end": end_to_end,

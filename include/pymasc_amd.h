@@ -49,12 +49,17 @@ extern "C" {
 /* flags for pmx_cc_dev / pmx_calc_correlation */
 #define PMX_FLAG_SKIP_NCC     1u  /* skip_ncc=True (mscc.pyx:235,313): row 0 left zero (popcounts still reported) */
 #define PMX_FLAG_FORCE_DENSE  2u  /* use the dense word-parallel kernels (one lane per shift)          */
-#define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven window kernels (error if unsupported) */
+#define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven kernels (error if unsupported)        */
 #define PMX_FLAG_SKIP_MLEN    8u  /* the caller holds mappable_len already (the *_mappability.json cache,
                                    * handler/mappability.py:239-259): no autocorrelation pass; row 4 and
                                    * scalars[2] are written as zeros */
-/* default (neither): the set-bit kernels for read_len <= 1024 (shifts beyond 1023 are processed in chunks of
- * 1024), the dense kernels for longer reads.
+/* default (neither): the set-bit kernels for read_len <= 1024 -- for max_shift <= 1023 the event kernel on the
+ * tiles (64 Kbit) whose read / run-edge lists fit its LDS lists and the window kernel on the others, for larger
+ * max_shift the window kernel in chunks of 1024 shifts --, the dense kernels for longer reads.  The integers are
+ * the same whichever kernel produced them.
+ * Environment switches read once per process (A/B measurements, tests): PMX_CC_EVENTS=0 (window kernel on every
+ * tile), PMX_CC_FUSE_MLEN=0 (mappable-length pass not fused into the event kernel), PMX_AUTOCORR_PAIRS=0,
+ * PMX_AUTOCORR_FORK=0.
  * Limits of every entry point below: max_shift <= 65535 (the reference takes any -d, mscc.pyx:288, default 1000;
  * larger values return PMX_ERR_INVALID), read_len <= 65535, nbits < 2^40.
  * max_shift < 3: a row of max_shift + 1 words cannot hold the four scalars, so the scalar row is cut to its first

@@ -28,7 +28,7 @@ ntiles = sum((v.nbits + 65535) // 65536 for v in vecs)
 per_cu = int(os.environ.get("EV_PER_CU", 4 if with_m else 8))
 nwg = min(256 * per_cu, ntiles)
 tpw = -(-ntiles // nwg); nwg = -(-ntiles // tpw)
-off = (nwg + len(vecs)) * 5 * 1024 * 4
+off = (nwg + len(vecs)) * 6 * 1024 * 4   # EV_SEG_ROWS
 NS = 12
 buf = np.zeros(nwg * 4 * NS, dtype=np.uint64)
 Lb = ffi.load_library()
@@ -39,7 +39,8 @@ a = buf.reshape(nwg, 4, NS).astype(np.float64)
 tot = a.sum(axis=2).mean()
 print(f"mode={mode} nwg={nwg} tiles/wg={tpw} cycles per wave lifetime={tot:.0f}  per tile={tot / tpw:.0f}")
 lab = {0: "B0 barrier wait", 1: "counts + M store + scans", 2: "Bs barrier wait", 3: "totals + emit lists", 4: "prefetch issue",
-       5: "B1 barrier wait", 6: "forward events (F x R, F x E)", 7: "reverse events (R x E)", 8: "-", 9: "flush / loop tail", 10: "-", 11: "-"}
+       5: "B1 barrier wait", 6: "events: forward x reverse pairs", 8: "events: forward x edges", 7: "events: reverse x edges, edge pairs",
+       9: "flush / loop tail", 10: "-", 11: "-"}
 for i in range(NS):
     print(f"  {lab[i]:32s} {a[:, :, i].mean() / tpw:9.0f} cyc/tile  {100 * a[:, :, i].sum() / a.sum():5.1f} %")
 for w in range(4):
