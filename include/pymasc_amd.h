@@ -135,7 +135,10 @@ int pmx_mappable_len(pmx_ctx *ctx, const uint64_t *h_M, uint64_t nbits, uint32_t
                      uint32_t flags, uint64_t *h_out);
 
 /* ---- measurement ------------------------------------------------------------------------- */
-/* With profiling on, every launch of a hot-path kernel is bracketed by HIP events on the context's
+/* on = 1: every launch of a hot-path kernel that does work is bracketed by HIP events; on = 2: also the window-kernel
+ * launches behind the event kernel, which return at once unless it flagged dense tiles (a bracket costs ~6 us of
+ * stream time); 0: off.
+ * With profiling on, every launch of a hot-path kernel is bracketed by HIP events on the context's
  * stream.  pmx_ctx_kernel_time synchronises and returns the summed duration and launch count of
  * kernel `kernel_id` since the last reset. */
 #define PMX_KERNEL_CC_DENSE     0

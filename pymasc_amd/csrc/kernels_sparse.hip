@@ -2007,7 +2007,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         plan_launch(ctx, &vjobs[lo], n, false, chunked ? (has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (has_m ? SP_WAVES : SP_WAVES_NCC), &tab, &total, &tpw, &nwg);
         rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
         if (rc) return rc;
-        rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl);
+        rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, use_events);
         if (rc) return rc;
 #define SP_LAUNCH(HM, NC, CK)                                                                                      \
     hipLaunchKernelGGL((k_cc_sparse<HM, NC, CK>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, c, lgG, \
@@ -2138,7 +2138,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         int rc = pmx_ensure_slab_ac(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
         if (rc) return rc;
         pmx_timed_launch tl;
-        rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
+        rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl, fused_done);
         if (rc) return rc;
         if (chunked)
             hipLaunchKernelGGL(k_autocorr_edges<true>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,

@@ -34,6 +34,7 @@ void pmx_set_error(const char *fmt, ...);
 
 struct pmx_timed_launch {
     int kernel_id;
+    bool active;
     hipEvent_t start, stop;
 };
 
@@ -46,7 +47,7 @@ struct pmx_ctx {
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join;
     int num_cus;
-    bool profiling;
+    int profiling;               // 0 off; 1: kernels that do work; 2: also the (usually empty) fallback launches behind the event kernel
     std::vector<pmx_timed_launch> timed;       // launches not yet folded into the totals
     std::vector<hipEvent_t> event_pool;
     double total_ms[PMX_KERNEL_COUNT_];
@@ -77,7 +78,7 @@ struct pmx_ctx {
 };
 
 // profiling helpers (pmx_api.hip)
-int pmx_prof_begin(pmx_ctx *ctx, int kernel_id, pmx_timed_launch *tl);
+int pmx_prof_begin(pmx_ctx *ctx, int kernel_id, pmx_timed_launch *tl, bool fallback = false);
 int pmx_prof_end(pmx_ctx *ctx, pmx_timed_launch *tl);
 int pmx_ensure_scratch(pmx_ctx *ctx, size_t words);
 

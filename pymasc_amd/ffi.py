@@ -239,8 +239,9 @@ class Context:
         return out
 
     # -- measurement
-    def set_profiling(self, on: bool):
-        _check(self._L, self._L.pmx_ctx_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, on):
+        """False / 0: off; True / 1: kernels that do work; 2: also the fallback launches behind the event kernel."""
+        _check(self._L, self._L.pmx_ctx_set_profiling(self._h, int(on)))
 
     def reset_kernel_times(self):
         _check(self._L, self._L.pmx_ctx_reset_kernel_times(self._h))
