@@ -38,6 +38,7 @@
 #define EV_CAPR 640u                      // reverse reads of the tile + of the max_shift bits above it
 #define EV_CAPE 384u                      // run edges of everything staged
 #define EV_POS 0x1ffffu                   // 17 bits of biased position
+#define EV_PAD 12u                        // sentinel entries behind the read lists
 #define EV_SEG_ROWS 6u                    // slab segment rows of 1024 u32: ncc, GF, cc, GR, scalars, EE
 #ifndef EV_WAVES
 #define EV_WAVES 4
@@ -72,16 +73,17 @@ struct EvLds {
     static constexpr u32 NROWS = HAS_M ? 5u : 1u;
     static constexpr u32 DUMP_A = HIST + NROWS * 1024;
     static constexpr u32 LF = DUMP_A + 64;
-    static constexpr u32 LE = LF + EV_CAPF;
+    static constexpr u32 LE = LF + EV_CAPF + EV_PAD;                // (+EV_PAD: sentinels; the loops read ahead of their entry)
     static constexpr u32 DUMP_B = HAS_M ? DUMP_A + 1024 : LE;
     static constexpr u32 LR = HAS_M ? DUMP_B + 64 : LE;
-    static constexpr u32 WT = LR + EV_CAPR + 4;                     // (+4: the event loops read two entries per trip, two ahead)
+    static constexpr u32 WT = LR + EV_CAPR + EV_PAD;
     static constexpr u32 MISC = WT + 32;                            // WT: [5][4 waves] scan totals
-    static constexpr u32 MT0 = MISC + 16;                           // [3] = the dword below the staged range, [4..] = M
-    static constexpr u32 PREF = MT0 + (HAS_M ? 4u + EV_MW : 0u);    // u16 per staged dword: edges before it
-    static constexpr u32 TOTAL = PREF + (HAS_M ? (EV_MW + 3) / 4 * 2 + 2 : 0u);
+    static constexpr u32 IDXF = MISC + 16;                          // u16 per 512-bit block of the tile (+ end): list index of
+    static constexpr u32 IDXR = IDXF + (HAS_M ? 66u : 0u);          // its first forward / reverse read
+    static constexpr u32 MT0 = IDXR + (HAS_M ? 66u : 0u);           // [3] = the dword below the staged range, [4..] = M
+    static constexpr u32 TOTAL = MT0 + (HAS_M ? 4u + EV_MW : 0u);
     static_assert(!HAS_M || LE + EV_CAPE + 4 <= DUMP_B, "the lists must fit between the dump areas");
-    static_assert(MT0 % 4 == 0 && PREF % 2 == 0, "alignment of the 16-byte / 8-byte stores");
+    static_assert(MT0 % 4 == 0, "alignment of the 16-byte stores");
 };
 
 struct EvRegs {
@@ -178,13 +180,6 @@ __device__ __forceinline__ void ev_emit_pos(const uint4 v, u32 idx, u32 base_bit
     }
 }
 
-// exclusive edge counts of the four dwords of a quad, as u16 x 4
-__device__ __forceinline__ void ev_store_pref(const uint4 e, u32 base, unsigned short *pref16, u32 dword)
-{
-    const u32 p0 = base, p1 = p0 + __popc(e.x), p2 = p1 + __popc(e.y), p3 = p2 + __popc(e.z);
-    *reinterpret_cast<uint2 *>(pref16 + dword) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
-}
-
 // the dword below this lane's quad: the last dword of the lane below it (lane 0: `first`, uniform over the wave)
 __device__ __forceinline__ u32 ev_below(u32 last_dword, u32 first)
 {
@@ -192,15 +187,6 @@ __device__ __forceinline__ u32 ev_below(u32 last_dword, u32 first)
 }
 
 __device__ __forceinline__ u32 ev_mbit(const u32 *MT, u32 q) { return (MT[q >> 5] >> (q & 31u)) & 1u; }
-
-// number of run edges at biased positions < q
-__device__ __forceinline__ u32 ev_rank_e(const u32 *MT, const unsigned short *pref16, u32 q)
-{
-    const u32 w = q >> 5;
-    const u32 mw = MT[w], mlo = MT[(int)w - 1];
-    const u32 ew = mw ^ __builtin_amdgcn_alignbit(mw, mlo, 31);
-    return (u32)pref16[w] + __popc(ew & ((1u << (q & 31u)) - 1u));
-}
 
 // slab segment of a (workgroup, job) pair: EV_SEG_ROWS rows of 1024 u32: ncc, GF, cc, GR, scalars (|F|, |R|, Bf, R0,
 // popcount(M), runs), EE
@@ -220,7 +206,8 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     u32 *const hGR = lds + L::HIST + (HAS_M ? 3 * 1024u : 0u);
     u32 *const hEE = lds + L::HIST + (HAS_M ? 4 * 1024u : 0u);
     u32 *const MT = lds + L::MT0 + 4;
-    unsigned short *const pref16 = reinterpret_cast<unsigned short *>(lds + L::PREF);
+    unsigned short *const idxF = reinterpret_cast<unsigned short *>(lds + L::IDXF);
+    unsigned short *const idxR = reinterpret_cast<unsigned short *>(lds + L::IDXR);
     u32 *const LF = lds + L::LF;
     u32 *const LR = lds + L::LR;
     u32 *const LE = lds + L::LE;
@@ -354,21 +341,32 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     const uint4 Eq = edge_words(er.m[q], ev_below(er.m[q].w, er.wb[q]));
                     const u32 o = q ? oE1 : oE0;
                     ap_emit(Eq, er.m[q], o, EV_BIAS + q * SP_TB + 128u * tid, LE);
-                    ev_store_pref(Eq, o, pref16, EV_LO + q * SP_TBW + 4 * tid);
                 }
                 const uint4 Eh = edge_words(er.h, ev_below(er.h.w, er.hbw));
                 if (h_below) {
                     ap_emit(Eh, er.h, eX & 0xffffu, 128u * lane, LE);
-                    ev_store_pref(Eh, eX & 0xffffu, pref16, 4 * lane);
                 } else if (h_above) {
                     const u32 oa = TXb + TE0 + TE1 + (eX >> 16);
                     ap_emit(Eh, er.h, oa, EV_BIAS + EV_TB + 128u * lane, LE);
-                    ev_store_pref(Eh, oa, pref16, EV_LO + EV_TBW + 4 * lane);
                 }
             }
-            // sentinels behind the lists: the event loops need no index bounds (and read two entries ahead)
-            if (tid < 4) LR[nR + tid] = 0x7fffffffu;
-            else if (HAS_M && tid < 8) LE[nE + tid - 4] = EV_POS;
+            // sentinels behind the lists: the event loops need no index bounds (and read ahead of their entry)
+            if (tid < EV_PAD) LR[nR + tid] = 0x7fffffffu;
+            else if (HAS_M && tid < 2 * EV_PAD) LF[nF + tid - EV_PAD] = EV_POS;
+            else if (HAS_M && tid < 2 * EV_PAD + 4) LE[nE + tid - 2 * EV_PAD] = EV_POS;
+            if (HAS_M) {
+                // list index of the first read of every 512-bit block of the tile (the edge-driven loops start there)
+                if ((tid & 3u) == 0) {
+                    idxF[tid >> 2] = (unsigned short)(eF & 0xffffu);
+                    idxF[64 + (tid >> 2)] = (unsigned short)(TF0 + (eF >> 16));
+                    idxR[tid >> 2] = (unsigned short)oR0;
+                    idxR[64 + (tid >> 2)] = (unsigned short)oR1;
+                }
+                if (tid == 255) {
+                    idxF[128] = (unsigned short)nF;
+                    idxR[128] = (unsigned short)nRt;
+                }
+            }
             cntF += cF[0] + cF[1];
             cntR += cR[0] + cR[1];
             cntM += pendM;
@@ -409,6 +407,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 const u32 ent = i < nF ? LF[i] : 0u;
                 const u32 x = ent & EV_POS, xc = x + c;
                 const u32 flm = (u32)((int32_t)ent >> 31);   // all ones: mappable
+                if (HAS_M && flm) cntB += ev_mbit(MT, xc);   // Bf = sum of M[x + c]
                 u32 r = (ent >> 17) & 0x3ffu;
                 u32 y0 = LR[r], y1 = LR[r + 1];
                 for (;;) {
@@ -436,66 +435,83 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             }
 #endif
             EV_STAMP(6)
-#ifndef EV_ABL_NOFE
-            // ---- mappable forward reads x edges in (x + c - S, x + c]: mscc.fsum ----
+#ifndef EV_ABL_NOREV
+            // ---- R0 = sum over the tile's reverse reads of M[p] M[p + c] ----
             if (HAS_M)
-                for (u32 b = (wave + 3) & 3; b < nbF; b += 4) {
+                for (u32 b = (wave + 2) & 3; b < nbR; b += 4) {
                     const u32 i = 64 * b + lane;
-                    const u32 ent = i < nF ? LF[i] : 0u;
-                    const bool lv = (ent >> 31) != 0;
-                    const u32 hi = (ent & EV_POS) + c;
-                    if (lv) cntB += ev_mbit(MT, hi);
-                    u32 e = lv ? ev_rank_e(MT, pref16, hi - S + 1) : nE;   // idle lanes sit on the sentinel
-                    u32 e0 = LE[e], e1 = LE[e + 1];
-                    for (;;) {
-                        const u32 p0 = e0 & EV_POS, p1 = e1 & EV_POS;
-                        const bool h0 = p0 <= hi, h1 = p1 <= hi;
-                        if (!__ballot(h0)) break;
-                        atomicAdd(&hGF[h0 ? hi - p0 + 1 : dumpGF], (u32)(((int32_t)e0 >> 31) | 1));   // E[j]: -1 falling, +1 rising
-                        atomicAdd(&hGF[h1 ? hi - p1 + 1 : dumpGF], (u32)(((int32_t)e1 >> 31) | 1));
-                        e = h1 ? e + 2 : nE;
-                        e0 = LE[e];
-                        e1 = LE[e + 1];
+                    if (i < nRt) {
+                        const u32 p = LR[i];
+                        cnt0 += ev_mbit(MT, p) & ev_mbit(MT, p + c);
                     }
                 }
 #endif
             EV_STAMP(8)
-#ifndef EV_ABL_NOREV
-            // ---- reverse reads x edges: mscc.rsum.  Both edge ranges of a read are walked in the same loop:
-            // type A: edges j in [p - S + 1, p],          d = p - j + 1,            weight M[p + c - 2d]
-            // type B: edges j in [p + c - 2S + 1, p + c], d = (p + c - j + 2) >> 1, weight M[p - d + 1]
+#ifndef EV_ABL_NOFE
+            // ---- the edge events of mscc.fsum and mscc.rsum, driven from the EDGES (~60 per tile, one block of lanes) instead
+            // of from the ~330 reads each: for an edge j (sign E[j]) the reads it meets are contiguous in the sorted lists,
+            //   forward reads x in [j - c, j - c + S):      GF[x + c - j + 1] += E[j]                  (mappable x only)
+            //   reverse reads p in [j, j + S)       (type A): d = p - j + 1,              GR[d] -= E[j] M[p + c - 2d]
+            //   reverse reads p in [j - c, j - c + 2S) (type B): d = (p - (j - c) + 2) >> 1, GR[d] -= E[j] M[p - d + 1]
+            // Every wave walks the same edges and takes every fourth read of a range (two per trip).  A range starts at the
+            // first read of its 512-bit block (idxF / idxR, written by the emit): the reads below the range are misses like
+            // any other, so there is no search.
             if (HAS_M)
-                for (u32 b = (wave + 2) & 3; b < nbR; b += 4) {
-                    const u32 i = 64 * b + lane;
-                    const bool in = i < nRt;
-                    const u32 p = in ? LR[i] : EV_BIAS, hi = p + c;
-                    if (in) cnt0 += ev_mbit(MT, p) & ev_mbit(MT, hi);
-                    u32 eA = in ? ev_rank_e(MT, pref16, p - S + 1) : nE, eB = in ? ev_rank_e(MT, pref16, hi - 2 * S + 1) : nE;
-                    u32 a0 = LE[eA], a1 = LE[eA + 1], b0 = LE[eB], b1 = LE[eB + 1];
-                    for (;;) {
-                        const u32 pa0 = a0 & EV_POS, pa1 = a1 & EV_POS, pb0 = b0 & EV_POS, pb1 = b1 & EV_POS;
-                        const bool hA0 = pa0 <= p, hA1 = pa1 <= p, hB0 = pb0 <= hi, hB1 = pb1 <= hi;
-                        if (!__ballot(hA0 || hB0)) break;
-                        // shifts (or the lane's dump slot) and the positions of the weights (a miss looks up a staged bit near p)
-                        const u32 dA0 = hA0 ? p - pa0 + 1 : 0u, dA1 = hA1 ? p - pa1 + 1 : 0u;
-                        const u32 dB0 = hB0 ? (hi - pb0 + 2) >> 1 : 0u, dB1 = hB1 ? (hi - pb1 + 2) >> 1 : 0u;
-                        const u32 tA0 = hA0 ? dA0 : dumpGR, tA1 = hA1 ? dA1 : dumpGR, tB0 = hB0 ? dB0 : dumpGR, tB1 = hB1 ? dB1 : dumpGR;
-                        const u32 qA0 = hi - 2 * dA0, qA1 = hi - 2 * dA1;
-                        const u32 qB0 = p + 1 - dB0, qB1 = p + 1 - dB1;
-                        const u32 mA0 = MT[qA0 >> 5], mA1 = MT[qA1 >> 5], mB0 = MT[qB0 >> 5], mB1 = MT[qB1 >> 5];
-                        // -E[j]: +1 falling, -1 rising
-                        const int32_t nA0 = ((int32_t)~a0 >> 31) | 1, nA1 = ((int32_t)~a1 >> 31) | 1;
-                        const int32_t nB0 = ((int32_t)~b0 >> 31) | 1, nB1 = ((int32_t)~b1 >> 31) | 1;
-                        eA = hA1 ? eA + 2 : nE;
-                        eB = hB1 ? eB + 2 : nE;
-                        a0 = LE[eA];
-                        a1 = LE[eA + 1];
-                        b0 = LE[eB];
-                        b1 = LE[eB + 1];
-                        atomicAdd(&hGR[tA0], (u32)(nA0 * (int32_t)((mA0 >> (qA0 & 31u)) & 1u)));
-                        atomicAdd(&hGR[tA1], (u32)(nA1 * (int32_t)((mA1 >> (qA1 & 31u)) & 1u)));
-                        atomicAdd(&hGR[tB0], (u32)(nB0 * (int32_t)((mB0 >> (qB0 & 31u)) & 1u)));
-                        atomicAdd(&hGR[tB1], (u32)(nB1 * (int32_t)((mB1 >> (qB1 & 31u)) & 1u)));
+                for (u32 eb = 0; eb < nE; eb += 64) {
+                    const u32 i = eb + lane;
+                    const bool in = i < nE;
+                    const u32 ee = in ? LE[i] : 0u;
+                    const int32_t j = (int32_t)(ee & EV_POS);
+                    const u32 sgn = (u32)(((int32_t)ee >> 31) | 1);   // E[j]: -1 falling, +1 rising
+                    const int32_t tile_end = (int32_t)(EV_BIAS + EV_TB);
+                    // -- forward reads --
+                    {
+                        const int32_t lo = j - (int32_t)c;
+                        const u32 span = in ? S : 0u;
+                        int32_t bb = (lo - (int32_t)EV_BIAS) >> 9;
+                        bb = bb < 0 ? 0 : (bb > 128 ? 128 : bb);
+                        u32 idx = (u32)idxF[bb] + wave;
+                        u32 e0 = LF[idx], e1 = LF[idx + 4];
+                        for (;;) {
+                            const u32 u0 = (e0 & EV_POS) - (u32)lo, u1 = (e1 & EV_POS) - (u32)lo;
+                            const bool more = (int32_t)u0 < (int32_t)span;   // this lane's entry is still below the end of its range
+                            if (!__ballot(more)) break;
+                            const bool h0 = u0 < span && (e0 >> 31) != 0, h1 = u1 < span && (e1 >> 31) != 0;
+                            atomicAdd(&hGF[h0 ? u0 + 1 : dumpGF], sgn);
+                            atomicAdd(&hGF[h1 ? u1 + 1 : dumpGF], sgn);
+                            idx = more ? idx + 8 : idx;
+                            e0 = LF[idx];
+                            e1 = LF[idx + 4];
+                        }
+                    }
+                    // -- reverse reads, type A and type B (the halo entries above the tile are not drivers: the span ends at the tile end) --
+#pragma unroll
+                    for (u32 kind = 0; kind < 2; kind++) {
+                        const int32_t lo = kind == 0 ? j : j - (int32_t)c;
+                        int32_t sp = tile_end - lo;
+                        const int32_t full = kind == 0 ? (int32_t)S : 2 * (int32_t)S;
+                        sp = sp < full ? sp : full;
+                        const u32 span = (in && sp > 0) ? (u32)sp : 0u;
+                        int32_t bb = (lo - (int32_t)EV_BIAS) >> 9;
+                        bb = bb < 0 ? 0 : (bb > 128 ? 128 : bb);
+                        u32 idx = (u32)idxR[bb] + wave;
+                        u32 p0 = LR[idx], p1 = LR[idx + 4];
+                        for (;;) {
+                            const u32 u0 = p0 - (u32)lo, u1 = p1 - (u32)lo;
+                            const bool more = (int32_t)u0 < (int32_t)span;
+                            if (!__ballot(more)) break;
+                            const bool h0 = u0 < span, h1 = u1 < span;
+                            const u32 d0 = kind == 0 ? u0 + 1 : (u0 + 2) >> 1, d1 = kind == 0 ? u1 + 1 : (u1 + 2) >> 1;
+                            const u32 q0 = h0 ? (kind == 0 ? p0 + c - 2 * d0 : p0 - d0 + 1) : EV_BIAS;
+                            const u32 q1 = h1 ? (kind == 0 ? p1 + c - 2 * d1 : p1 - d1 + 1) : EV_BIAS;
+                            const u32 m0 = MT[q0 >> 5], m1 = MT[q1 >> 5];
+                            idx = more ? idx + 8 : idx;
+                            p0 = LR[idx];
+                            p1 = LR[idx + 4];
+                            // -E[j] M[q]
+                            atomicAdd(&hGR[h0 ? d0 : dumpGR], (0u - sgn) * ((m0 >> (q0 & 31u)) & 1u));
+                            atomicAdd(&hGR[h1 ? d1 : dumpGR], (0u - sgn) * ((m1 >> (q1 & 31u)) & 1u));
+                        }
                     }
                 }
 #endif

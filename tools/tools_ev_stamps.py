@@ -39,7 +39,7 @@ a = buf.reshape(nwg, 4, NS).astype(np.float64)
 tot = a.sum(axis=2).mean()
 print(f"mode={mode} nwg={nwg} tiles/wg={tpw} cycles per wave lifetime={tot:.0f}  per tile={tot / tpw:.0f}")
 lab = {0: "B0 barrier wait", 1: "counts + M store + scans", 2: "Bs barrier wait", 3: "totals + emit lists", 4: "prefetch issue",
-       5: "B1 barrier wait", 6: "events: forward x reverse pairs", 8: "events: forward x edges", 7: "events: reverse x edges, edge pairs",
+       5: "B1 barrier wait", 6: "events: forward x reverse pairs", 8: "R0 (reverse reads: M[p] M[p+c])", 7: "events: edges x reads, edge pairs",
        9: "flush / loop tail", 10: "-", 11: "-"}
 for i in range(NS):
     print(f"  {lab[i]:32s} {a[:, :, i].mean() / tpw:9.0f} cyc/tile  {100 * a[:, :, i].sum() / a.sum():5.1f} %")
