@@ -18,13 +18,14 @@
 //                  rsum[d] = R0 + sum_{t=1..d} GR[t],  R0 = sum_p M[p] M[p+c]
 // All integer arithmetic; the histograms GF / GR are signed and k_events_finish takes their prefix sums.
 //
-// The lists are SORTED (position order comes out of block-wide scans of the per-thread popcounts), and the first
-// partner of every driver is known without searching: the rank of a position among the R bits of the tile is a
-// popcount of the emitting thread's own registers; among the edges it is a per-dword prefix count (u16 in LDS) plus a
-// masked popcount of one edge word.  Cost follows the number of events (~2700 per tile), not tile size x shift range.
+// The lists are SORTED (position order comes out of block-wide scans of the per-thread popcounts), and nothing is ever
+// searched: the first reverse partner of a forward read is its rank among the reverse reads = a popcount of the emitting
+// thread's own registers; the reads an EDGE meets (the edge events are driven from the ~60 edges, not from the ~660
+// reads) are a contiguous range of a list, entered at the first read of its 512-bit block (a u16 index per block, written
+// by the emit).  Cost follows the number of events (~3000 per tile), not tile size x shift range.
 //
-// Tiles whose lists would overflow (dense vectors: tests, pathological tracks) are flagged and left to k_cc_sparse,
-// which then processes the flagged tiles only; its sums are added to what this pass wrote.
+// Tiles whose lists would overflow (dense vectors: deep data, tests, tracks with very short runs) are flagged and left to
+// k_cc_sparse / k_autocorr_edges, which then process the flagged tiles only; their sums are added to what this pass wrote.
 #pragma once
 
 #define EV_NQ 2u                          // driver quads per thread and vector: a tile is EV_NQ x 32 Kbit

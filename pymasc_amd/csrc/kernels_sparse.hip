@@ -1,5 +1,7 @@
-// Set-bit driven cross-correlation kernels (gfx950): the default path for read-occupancy vectors, which are
-// sparse by nature (at most one bit per position and strand; ~0.5 % density for 15 M reads / 3.1 Gbp).
+// Set-bit driven cross-correlation kernels (gfx950) for read-occupancy vectors, which are sparse by nature (at most
+// one bit per position and strand; ~0.5 % density for 15 M reads / 3.1 Gbp).  k_cc_sparse below is the WINDOW kernel:
+// every tile when max_shift > 1023, otherwise the tiles the event kernel (kernels_events.h, included further down)
+// flags as too dense for its lists.
 //
 // Same outputs as the reference's per-shift loop (PyMaSC/core/bitarray/mscc.pyx:288-317), different algorithm:
 // instead of sliding the whole R vector past F once per shift (N/64 words x (S+1) shifts), every SET BIT x of
