@@ -40,6 +40,8 @@
 #define EV_CAPE 384u                      // run edges of everything staged
 #define EV_POS 0x1ffffu                   // 17 bits of biased position
 #define EV_PAD 12u                        // sentinel entries behind the read lists
+#define EV_RSENT 0x3fffffffu              // reverse-list sentinel: beyond every range, and (sentinel - lo) stays positive as
+                                          // an int32 for range starts lo >= -1023 (an edge below the tile minus read_len - 1)
 #define EV_SEG_ROWS 6u                    // slab segment rows of 1024 u32: ncc, GF, cc, GR, scalars, EE
 #ifndef EV_WAVES
 #define EV_WAVES 4
@@ -352,7 +354,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 }
             }
             // sentinels behind the lists: the event loops need no index bounds (and read ahead of their entry)
-            if (tid < EV_PAD) LR[nR + tid] = 0x7fffffffu;
+            if (tid < EV_PAD) LR[nR + tid] = EV_RSENT;
             else if (HAS_M && tid < 2 * EV_PAD) LF[nF + tid - EV_PAD] = EV_POS;
             else if (HAS_M && tid < 2 * EV_PAD + 4) LE[nE + tid - 2 * EV_PAD] = EV_POS;
             if (HAS_M) {

@@ -374,6 +374,40 @@ const char *pmx_kernel_name(int kernel_id)
 // ---- device bit-vectors ---------------------------------------------------------------------------
 
 // diagnostics only (not in the public header): copies `bytes` of the slab starting at byte offset `off`
+// diagnostic: leaves a pattern in every scratch buffer of the context and in the LDS of every CU, so that a kernel that
+// reads memory it has not written shows up as a deterministic mismatch (tools/repro_case.py)
+__global__ void __launch_bounds__(256) k_debug_poison_lds(u32 pattern, u32 *sink)
+{
+    __shared__ u32 lds[16 * 1024 - 64];   // just under 64 KB
+    for (u32 i = threadIdx.x; i < 16 * 1024 - 64; i += 256) lds[i] = pattern;
+    __syncthreads();
+    if (lds[(threadIdx.x * 61) % (16 * 1024 - 64)] != pattern) sink[0] = 1;   // keeps the stores alive
+}
+
+int pmx_debug_poison(pmx_ctx *ctx, uint32_t pattern, uint32_t mask)
+{
+    REQUIRE(ctx, "pmx_debug_poison: ctx is NULL");
+    const int byte = (int)(pattern & 0xff);
+    if ((mask & 1) && ctx->d_slab) PMX_HIP(hipMemsetAsync(ctx->d_slab, byte, ctx->slab_words * sizeof(u32), ctx->stream));
+    if ((mask & 2) && ctx->d_slab2) PMX_HIP(hipMemsetAsync(ctx->d_slab2, byte, ctx->slab2_words * sizeof(u32), ctx->stream));
+    if ((mask & 4) && ctx->d_slab_ac) PMX_HIP(hipMemsetAsync(ctx->d_slab_ac, byte, ctx->slab_ac_words * sizeof(u32), ctx->stream));
+    if ((mask & 8) && ctx->d_flags) PMX_HIP(hipMemsetAsync(ctx->d_flags, byte, ctx->flags_bytes, ctx->stream));
+    if ((mask & 16) && ctx->d_flags_cc) PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, byte, ctx->flags_cc_bytes, ctx->stream));
+    if ((mask & 32) && ctx->d_scratch) PMX_HIP(hipMemsetAsync(ctx->d_scratch, byte, ctx->scratch_words * sizeof(u64), ctx->stream));
+    for (int i = 0; i < 3; i++)
+        if ((mask & 64) && ctx->d_stage[i])
+            PMX_HIP(hipMemsetAsync(ctx->d_stage[i], byte, ctx->stage_words[i] * sizeof(uint64_t), ctx->stream));
+    if ((mask & 128) && ctx->d_out_stage) PMX_HIP(hipMemsetAsync(ctx->d_out_stage, byte, ctx->out_stage_words * sizeof(u64), ctx->stream));
+    if (mask & 256) {
+        int rc = pmx_ensure_scratch(ctx, 64);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_debug_poison_lds, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, pattern, (u32 *)ctx->d_scratch + 32);
+        PMX_CHECK_LAUNCH("k_debug_poison_lds");
+    }
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
 int pmx_debug_read_slab(pmx_ctx *ctx, uint64_t off, void *dst, uint64_t bytes)
 {
     REQUIRE(ctx && dst && ctx->d_slab, "pmx_debug_read_slab: bad argument");

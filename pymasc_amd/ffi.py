@@ -252,6 +252,14 @@ class Context:
         _check(self._L, self._L.pmx_ctx_kernel_time(self._h, int(kernel_id), ctypes.byref(ms), ctypes.byref(n)))
         return float(ms.value), int(n.value)
 
+    def debug_poison(self, pattern: int, mask: int = 511) -> None:
+        """Diagnostic: fill the context's scratch buffers (mask bits 0-7) and the LDS of every CU (bit 8) with a byte /
+        dword pattern, so that a kernel reading memory it has not written fails deterministically (tests, fuzz)."""
+        fn = self._L.pmx_debug_poison
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+        fn.restype = ctypes.c_int
+        _check(self._L, fn(self._h, int(pattern) & 0xffffffff, int(mask)))
+
     def kernel_name(self, kernel_id: int) -> str:
         return self._L.pmx_kernel_name(int(kernel_id)).decode()
 

@@ -330,3 +330,28 @@ def test_window_kernel_alone_matches_the_event_path(ctx):
     here = np.asarray(ctx.calc_correlation(F, R, M, nbits, 1000, 36, ffi.PMX_FLAG_FORCE_SPARSE)).astype(np.int64)
     np.testing.assert_array_equal(child, here)
     check_block(here, oracle.calc_correlation(F, R, M, nbits, 1000, 36), 1000, True)
+
+
+@pytest.mark.parametrize("pattern", [0x00000000, 0xffffffff, 0x80808080, 0x7fffffff, 0x5a5a5a5a])
+def test_results_do_not_depend_on_stale_scratch_or_lds(ctx, pattern):
+    """Every scratch buffer of the context and the LDS of every CU are filled with a pattern before the call: a kernel
+    that reads memory it has not written fails here deterministically.  The first geometry is the one a fuzz run caught
+    (a dense tile followed by a short sparse tile whose edges sit in the halo and which holds no reverse read: the
+    edge-driven loops then walk an EMPTY reverse list and must stop on its sentinel for range starts below zero)."""
+    cases = [
+        (1846347302, 65536, 1023, 151, 1.0, 0.0005, 30.0, 5.0, False),
+        (802336588, 70001, 1023, 151, 0.02, 0.0, 30.0, 5.0, False),
+        (698984044, 65536, 33, 36, 0.0005, 0.005, 30.0, 5.0, False),
+        (3, 200000, 1000, 36, 0.005, 0.005, 300.0, 80.0, False),
+        (1511311730, 65536, 512, 175, 0.0, 0.0, 300.0, 5.0, True),
+    ]
+    for seed, clen, S, L, fd, rd, on, off, full in cases:
+        nbits, F, R, M = synth.make_case(seed, clen, S, L, fd, rd, True, mean_on=on, mean_off=off, full_range=full)
+        ref = oracle.calc_correlation(F, R, M, nbits, S, L)
+        ctx.debug_poison(pattern)
+        out = ctx.calc_correlation(F, R, M, nbits, S, L, ffi.PMX_FLAG_FORCE_SPARSE)
+        check_block(out, ref, S, True)
+        want_lag = max(L - 1, S - (L - 1) if S > L - 1 else 0)
+        ctx.debug_poison(pattern)
+        got = ctx.mappable_len(M, nbits, want_lag, 0)
+        np.testing.assert_array_equal(got.astype(np.int64), oracle.mappable_len_readless(M, nbits, want_lag).astype(np.int64))

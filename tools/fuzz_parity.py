@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
+    poison_rng = np.random.default_rng(a.seed + 12345)   # separate stream: the case sequence of a seed stays what it was
     oracle.lib()
     t_end = time.time() + a.seconds
     n = bad = 0
@@ -80,6 +81,10 @@ def main():
     with ffi.Context(0) as ctx:
         while time.time() < t_end:
             S, L, clen, fd, rd, with_m, mean_on, mean_off = draw_case(rng)
+            if poison_rng.random() < 0.2:
+                # stale scratch buffers / LDS must not matter: leave a pattern in all of them now and then
+                ctx.debug_poison(int(poison_rng.choice([0, 0xffffffff, 0x80808080, 0x7fffffff, 0x00010001,
+                                                        int(poison_rng.integers(0, 2**32))])))
             # keep the oracle's (S+1) * words * passes affordable
             if (S + 1) * (clen + S + L + 100) > 1.5e9:
                 continue
