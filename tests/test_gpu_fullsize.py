@@ -98,6 +98,7 @@ def _torch_reference(v, d: int, read_len: int = L):
 def _run_batch(ctx, dev, vecs, max_shift, flags=0, read_len=L):
     out = torch.full((len(vecs), ROWS, max_shift + 1), -1, dtype=torch.int64, device=dev)   # garbage: must be overwritten
     with_m = vecs[0].M is not None
+    ctx.debug_poison(0xffffffff)   # stale scratch buffers / LDS must not matter (0xffffffff: ones as bits, -1 / huge as numbers)
     ctx.cc_batch_dev([v.F.data_ptr() for v in vecs], [v.R.data_ptr() for v in vecs],
                      [v.M.data_ptr() for v in vecs] if with_m else None,
                      [v.nbits for v in vecs], max_shift, read_len, flags, [out[i].data_ptr() for i in range(len(vecs))])
