@@ -594,40 +594,100 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 #endif
 }
 
-// fsum[d] = Bf - sum_{t<=d} GF[t], rsum[d] = R0 + sum_{t<=d} GR[t]: k_reduce_segments left the (signed) sums of GF / GR
-// over the workgroups in rows MSCC_FSUM / MSCC_RSUM of the result block; Bf and R0 are summed from the slab here.
-// One block per job.
+// The tail of the event pass, ONE launch per batch (grid: jobs x 2, the second half only with the mappable-length fusion):
+//   y = 0: fsum[d] = Bf - sum_{t<=d} GF[t], rsum[d] = R0 + sum_{t<=d} GR[t] (k_reduce_segments left the signed sums of GF /
+//          GR over the workgroups in rows MSCC_FSUM / MSCC_RSUM of the result block; Bf and R0 are summed from the slab
+//          here), then -- only if the event kernel flagged dense tiles -- the sums of the cross-correlation window kernel
+//          (its private slab) are added to the four rows and the two read counts;
+//   y = 1: the same for the autocorrelation window kernel (P, N, popcount, runs in the per-job scratch), then the
+//          recurrence of k_autocorr_finish.
+// The additions are a slow path (one block sums every workgroup segment of its job) that costs nothing when nothing was
+// flagged; it replaces two gated reduce launches and a finish launch of ~6 us each in every step.
+struct EvTailPlan {
+    u32 cc_first[SP_MAXJOBS], cc_last[SP_MAXJOBS];   // workgroup range of each job in the cc window launch
+    u32 ac_first[SP_MAXJOBS], ac_last[SP_MAXJOBS];   // ... in the autocorrelation window launch
+};
+
 __global__ void __launch_bounds__(256)
-k_events_finish(const u32 *__restrict__ slab, const SpJobTable jobs, u32 S, u32 out_stride)
+k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailPlan plan, const u32 *__restrict__ slab_cc,
+              const u32 *__restrict__ slab_ac, const u32 *__restrict__ n_flagged, u32 S, u32 out_stride, u32 has_m, u32 do_ncc,
+              u32 max_lag, u32 lagcap, int32_t c)
 {
     __shared__ long long part[256];
+    __shared__ long long tot[2];
     const u32 job = blockIdx.x, tid = threadIdx.x;
     const SpJobDev &jb = jobs.j[job];
-    long long bf = 0, r0 = 0;
-    for (u32 w = jb.wg_first + tid; w <= jb.wg_last; w += 256) {
-        const u32 *sc = slab + (size_t)(w + job) * EV_SEG_ROWS * 1024 + 4 * 1024;
-        bf += sc[2];
-        r0 += sc[3];
-    }
-    __shared__ long long tot[2];
-    const long long eb = block_exclusive_offset(bf, part, tid);   // (ends with a barrier)
-    if (tid == 255) tot[0] = eb + bf;
-    const long long e0 = block_exclusive_offset(r0, part, tid);
-    if (tid == 255) tot[1] = e0 + r0;
-    __syncthreads();
-    const long long Bf = tot[0], R0 = tot[1];
-    const u32 seg = (S + 1 + 255) / 256;
-    const u32 k0 = tid * seg, k1 = (k0 + seg < S + 1) ? k0 + seg : S + 1;
-#pragma unroll
-    for (u32 row = 0; row < 2; row++) {
-        long long *v = reinterpret_cast<long long *>(jb.out + (size_t)(row ? PMX_ROW_MSCC_RSUM : PMX_ROW_MSCC_FSUM) * out_stride);
-        long long sum = 0;
-        for (u32 k = k0; k < k1; k++) sum += v[k];
-        long long run = block_exclusive_offset(sum, part, tid);
-        for (u32 k = k0; k < k1; k++) {
-            run += v[k];
-            v[k] = row ? R0 + run : Bf - run;
+    const bool flagged = *n_flagged != 0;
+    if (blockIdx.y == 1) {
+        if (flagged) {
+            u64 *P = jb.out2, *N = jb.out2 + lagcap, *scal = jb.out2 + 2 * (size_t)lagcap;
+            const size_t stride = (size_t)AC_SEG_ROWS * 1024;
+            for (u32 k = tid; k <= max_lag; k += 256) {
+                u64 sp = 0, sn = 0;
+                for (u32 w = plan.ac_first[job]; w <= plan.ac_last[job]; w++) {
+                    const u32 *seg = slab_ac + (size_t)(w + job) * stride;
+                    sp += seg[k];
+                    sn += seg[1024 + k];
+                }
+                P[k] += sp;
+                N[k] += sn;
+            }
+            if (tid < 2) {
+                u64 sc = 0;
+                for (u32 w = plan.ac_first[job]; w <= plan.ac_last[job]; w++) sc += slab_ac[(size_t)(w + job) * stride + 2 * 1024 + tid];
+                scal[tid] += sc;
+            }
+            __threadfence_block();
+            __syncthreads();
         }
+        autocorr_finish_job(jb, part, max_lag, lagcap, 1u, c, S, out_stride);
+        return;
+    }
+    if (has_m) {
+        long long bf = 0, r0 = 0;
+        for (u32 w = jb.wg_first + tid; w <= jb.wg_last; w += 256) {
+            const u32 *sc = slab + (size_t)(w + job) * EV_SEG_ROWS * 1024 + 4 * 1024;
+            bf += sc[2];
+            r0 += sc[3];
+        }
+        const long long eb = block_exclusive_offset(bf, part, tid);   // (ends with a barrier)
+        if (tid == 255) tot[0] = eb + bf;
+        const long long e0 = block_exclusive_offset(r0, part, tid);
+        if (tid == 255) tot[1] = e0 + r0;
         __syncthreads();
+        const long long Bf = tot[0], R0 = tot[1];
+        const u32 seg = (S + 1 + 255) / 256;
+        const u32 k0 = tid * seg, k1 = (k0 + seg < S + 1) ? k0 + seg : S + 1;
+#pragma unroll
+        for (u32 row = 0; row < 2; row++) {
+            long long *v = reinterpret_cast<long long *>(jb.out + (size_t)(row ? PMX_ROW_MSCC_RSUM : PMX_ROW_MSCC_FSUM) * out_stride);
+            long long sum = 0;
+            for (u32 k = k0; k < k1; k++) sum += v[k];
+            long long run = block_exclusive_offset(sum, part, tid);
+            for (u32 k = k0; k < k1; k++) {
+                run += v[k];
+                v[k] = row ? R0 + run : Bf - run;
+            }
+            __syncthreads();
+        }
+    }
+    if (flagged) {
+        // rows of the window kernel's segments: 0 ncc, 1 fsum, 2 cc, 3 rsum, 4 scalars (|F|, |R|)
+        const u32 dst_row[4] = {PMX_ROW_NCC_CCBINS, PMX_ROW_MSCC_FSUM, PMX_ROW_MSCC_CCBINS, PMX_ROW_MSCC_RSUM};
+        const size_t stride = (size_t)SP_SEG_ROWS * 1024;
+        for (u32 r = 0; r < 4; r++) {
+            if (r == 0 ? !do_ncc : !has_m) continue;
+            u64 *dst = jb.out + (size_t)dst_row[r] * out_stride;
+            for (u32 d = tid; d <= S; d += 256) {
+                u64 sum = 0;
+                for (u32 w = plan.cc_first[job]; w <= plan.cc_last[job]; w++) sum += slab_cc[(size_t)(w + job) * stride + r * 1024 + d];
+                dst[d] += sum;
+            }
+        }
+        if (tid < 2) {
+            u64 sc = 0;
+            for (u32 w = plan.cc_first[job]; w <= plan.cc_last[job]; w++) sc += slab_cc[(size_t)(w + job) * stride + 4 * 1024 + tid];
+            jb.out[(size_t)PMX_ROW_SCALARS * out_stride + tid] += sc;
+        }
     }
 }

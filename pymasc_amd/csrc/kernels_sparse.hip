@@ -1037,22 +1037,23 @@ struct ReduceSpec {
     u32 zero_row[5];
 };
 
-__device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab, const SpJobTable &jobs, u32 seg_rows,
-                                                    const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r)
+#define RS_NBX 32u   // chunks of 32 elements per row (1024 shifts); a block takes the chunks blockIdx.x, + gridDim.x, ...
+__device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ slab, const SpJobTable &jobs, u32 seg_rows,
+                                                      const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r, u32 bx,
+                                                      u64 (*part)[32])
 {
     const bool live = !gate || *gate != 0;   // gate == 0: the producing kernel did not run, every sum is zero
     if (!live && rs.accumulate) return;      // ... and there is nothing to add
     // 32 consecutive elements x 8 workgroup phases per block: every load is a full 128-B line
-    __shared__ u64 part[8][32];
     const u32 job = blockIdx.z;
     const SpJobDev &jb = jobs.j[job];
     const u32 e = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const u32 i = blockIdx.x * 32 + e;
+    const u32 i = bx * 32 + e;
     if (r >= rs.nrows) {   // a row this batch leaves empty
         if ((jb.flags & 1u) && g == 0 && !rs.accumulate) {
             u64 *dst = rs.use_out2 ? jb.out2 + rs.zero_row[r - rs.nrows] : jb.out + (size_t)rs.zero_row[r - rs.nrows] * rs.out_stride;
             const u32 cnt = rs.use_out2 ? (rs.n_override ? rs.n_override : jb.d_n) : rs.out_stride;
-            for (u32 k = i; k < cnt; k += gridDim.x * 32) dst[k] = 0;
+            for (u32 k = i; k < cnt; k += RS_NBX * 32) dst[k] = 0;
         }
         return;
     }
@@ -1081,7 +1082,7 @@ __device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab
         }
     } else if (scalar) {
         u64 *dst = jb.out + (size_t)rs.dst_row[r] * rs.out_stride;
-        for (u32 k = i; k < rs.out_stride; k += gridDim.x * 32) {   // [0],[1] sums, [3] path, everything else zero
+        for (u32 k = i; k < rs.out_stride; k += RS_NBX * 32) {   // [0],[1] sums, [3] path, everything else zero
             if (k == 2 && rs.keep_scalar2) continue;
             if (rs.accumulate) {
                 if (k < 2) dst[k] += t;
@@ -1092,6 +1093,16 @@ __device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab
     } else if (i < n) {
         u64 *dst = jb.out + (size_t)rs.dst_row[r] * rs.out_stride + jb.d_off + i;
         *dst = rs.accumulate ? *dst + t : t;
+    }
+}
+
+__device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab, const SpJobTable &jobs, u32 seg_rows,
+                                                    const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r)
+{
+    __shared__ u64 part[8][32];
+    for (u32 bx = blockIdx.x; bx < RS_NBX; bx += gridDim.x) {   // (uniform over the block)
+        reduce_segments_chunk(slab, jobs, seg_rows, rs, gate, r, bx, part);
+        __syncthreads();
     }
 }
 
@@ -1734,12 +1745,9 @@ __device__ __forceinline__ long long block_exclusive_offset(long long local_sum,
     return base + x - local_sum;
 }
 
-__global__ void __launch_bounds__(256)
-k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 lagcap, u32 mode, int32_t c, u32 max_shift, u32 out_stride)
+__device__ __forceinline__ void autocorr_finish_job(const SpJobDev &jb, long long *part, u32 max_lag, u32 lagcap, u32 mode,
+                                                    int32_t c, u32 max_shift, u32 out_stride)
 {
-    __shared__ long long part[256];
-    const SpJobDev &jb = jobs.j[blockIdx.x];
-    if (!(jb.flags & 1u)) return;   // one finish per chromosome (its chunk-0 job)
     const u64 *P = jb.out2, *N = jb.out2 + lagcap, *scal = jb.out2 + 2 * (size_t)lagcap;
     long long *A = reinterpret_cast<long long *>(jb.out2 + 2 * (size_t)lagcap + 16);
     const u32 tid = threadIdx.x;
@@ -1775,6 +1783,15 @@ k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 lagcap, u32 mode, int3
             dst[d] = (u64)A[k < 0 ? -k : k];
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 lagcap, u32 mode, int32_t c, u32 max_shift, u32 out_stride)
+{
+    __shared__ long long part[256];
+    const SpJobDev &jb = jobs.j[blockIdx.x];
+    if (!(jb.flags & 1u)) return;   // one finish per chromosome (its chunk-0 job)
+    autocorr_finish_job(jb, part, max_lag, lagcap, mode, c, max_shift, out_stride);
 }
 
 #include "kernels_events.h"
@@ -1937,18 +1954,11 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         d_flags_ac = ctx->d_flags_cc + flag_bytes;   // tiles of the autocorrelation window kernel (64 Kbit), same flag0 per job
         d_nflagged = (u32 *)(ctx->d_flags_cc + 2 * flag_bytes);
         PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, 2 * flag_bytes + 16, ctx->stream));
-        if (fuse_mlen) {
-            fused->done = true;
-            fused->d_flags = d_flags_ac;
-            fused->d_nflagged = d_nflagged;
-            fused->flag0.resize(njobs);
-            for (uint32_t i = 0; i < njobs; i++) fused->flag0[i] = vjobs[i].flag0;
-        }
+        if (fuse_mlen) fused->done = true;   // row MLEN and scalar [2] are written by this call (k_events_tail)
     }
     ReduceSpec rs_ev = rs;
     for (u32 i = 0; i < nr; i++)
         if (rs.dst_row[i] == PMX_ROW_MSCC_FSUM || rs.dst_row[i] == PMX_ROW_MSCC_RSUM) rs_ev.is_signed[i] = 1;
-    if (use_events) rs.accumulate = 1;
 
     for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS) {
         const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS ? vjobs.size() - lo : SP_MAXJOBS);
@@ -1997,23 +2007,21 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
                                    tab, (u32)EV_SEG_ROWS, rs_ev, (const u32 *)nullptr);
             }
             PMX_CHECK_LAUNCH("k_reduce_segments");
-            if (has_m) {
-                hipLaunchKernelGGL(k_events_finish, dim3(n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, max_shift,
-                                   out_stride);
-                PMX_CHECK_LAUNCH("k_events_finish");
-            }
         }
         // Pass 2 (window kernel): every tile, or -- behind the event pass -- only the tiles it flagged (the whole grid returns
-        // at once when there are none); its sums are then ADDED to the result blocks.
-        memset(&tab, 0, sizeof tab);
-        plan_launch(ctx, &vjobs[lo], n, false, chunked ? (has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (has_m ? SP_WAVES : SP_WAVES_NCC), &tab, &total, &tpw, &nwg);
-        rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
+        // at once when there are none).  Behind the event pass it writes a slab of its own and k_events_tail adds its sums.
+        SpJobTable tabW;
+        memset(&tabW, 0, sizeof tabW);
+        plan_launch(ctx, &vjobs[lo], n, false, chunked ? (has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (has_m ? SP_WAVES : SP_WAVES_NCC), &tabW, &total, &tpw, &nwg);
+        const size_t wwords = (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64;
+        rc = use_events ? pmx_ensure_slab_fb(ctx, wwords) : pmx_ensure_slab(ctx, wwords);
         if (rc) return rc;
+        u32 *const wslab = use_events ? ctx->d_slab_fb : ctx->d_slab;
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, use_events);
         if (rc) return rc;
-#define SP_LAUNCH(HM, NC, CK)                                                                                      \
-    hipLaunchKernelGGL((k_cc_sparse<HM, NC, CK>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, c, lgG, \
-                       ctx->d_slab, (const unsigned char *)d_flags, (const u32 *)d_nflagged)
+#define SP_LAUNCH(HM, NC, CK)                                                                                       \
+    hipLaunchKernelGGL((k_cc_sparse<HM, NC, CK>), dim3(nwg), dim3(256), 0, ctx->stream, tabW, n, total, tpw, c, lgG, \
+                       wslab, (const unsigned char *)d_flags, (const u32 *)d_nflagged)
         if (chunked) {
             if (has_m && do_ncc) SP_LAUNCH(true, true, true);
             else if (has_m) SP_LAUNCH(true, false, true);
@@ -2027,10 +2035,50 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         PMX_CHECK_LAUNCH("k_cc_sparse");
         rc = pmx_prof_end(ctx, &tl);
         if (rc) return rc;
-        // sum the per-workgroup slab segments into the result blocks
-        hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab,
-                           (u32)SP_SEG_ROWS, rs, (const u32 *)d_nflagged);
-        PMX_CHECK_LAUNCH("k_reduce_segments");
+        if (!use_events) {
+            // sum the per-workgroup slab segments into the result blocks
+            hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tabW,
+                               (u32)SP_SEG_ROWS, rs, (const u32 *)nullptr);
+            PMX_CHECK_LAUNCH("k_reduce_segments");
+            continue;
+        }
+        EvTailPlan tp;
+        memset(&tp, 0, sizeof tp);
+        for (uint32_t i = 0; i < n; i++) {
+            tp.cc_first[i] = tabW.j[i].wg_first;
+            tp.cc_last[i] = tabW.j[i].wg_last;
+        }
+        const u32 lagcap = (u32)(((size_t)(fuse_mlen ? fused_lag : 0) + 1 + 1023) / 1024 * 1024);
+        if (fuse_mlen) {
+            // the autocorrelation window kernel for the flagged tiles (its own slab), same gate
+            std::vector<VJob> va(n);
+            for (uint32_t i = 0; i < n; i++) {
+                va[i].job = vjobs[lo + i].job;
+                va[i].d_off = 0;
+                va[i].d_n = fused_lag + 1;
+                va[i].flag0 = vjobs[lo + i].flag0;
+            }
+            SpJobTable tabA;
+            memset(&tabA, 0, sizeof tabA);
+            plan_launch(ctx, va.data(), n, true, AC_WAVES, &tabA, &total, &tpw, &nwg);
+            rc = pmx_ensure_slab_ac(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
+            if (rc) return rc;
+            rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl, true);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwg), dim3(256), 0, ctx->stream, tabA, n, total, tpw,
+                               lg_slot_lanes(fused_lag + 1), ctx->d_slab_ac, (const unsigned char *)d_flags_ac, (const u32 *)d_nflagged);
+            PMX_CHECK_LAUNCH("k_autocorr_edges");
+            rc = pmx_prof_end(ctx, &tl);
+            if (rc) return rc;
+            for (uint32_t i = 0; i < n; i++) {
+                tp.ac_first[i] = tabA.j[i].wg_first;
+                tp.ac_last[i] = tabA.j[i].wg_last;
+            }
+        }
+        hipLaunchKernelGGL(k_events_tail, dim3(n, fuse_mlen ? 2 : 1), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
+                           (const u32 *)ctx->d_slab_fb, (const u32 *)ctx->d_slab_ac, (const u32 *)d_nflagged, max_shift, out_stride,
+                           has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c);
+        PMX_CHECK_LAUNCH("k_events_tail");
     }
     return PMX_OK;
 }
@@ -2045,7 +2093,7 @@ size_t pmx_autocorr_scratch_words(uint32_t max_lag)
 // mode 0: jobs[i].d_out[k] = A(k), k <= max_lag.  mode 1: jobs[i].d_out is a result block: row MLEN[d] = A(|L-1-d|),
 // scalar [2] = popcount(M).
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag, uint32_t mode,
-                                    uint32_t read_len, uint32_t max_shift, uint32_t out_stride, const pmx_fused_mlen *fused)
+                                    uint32_t read_len, uint32_t max_shift, uint32_t out_stride)
 {
     if (njobs == 0) return PMX_OK;
     const bool chunked = max_lag > 1023;
@@ -2058,17 +2106,12 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         const char *e = getenv("PMX_AUTOCORR_PAIRS");
         return !(e && e[0] == '0');
     }();
-    const bool fused_done = fused && fused->done && fused->flag0.size() == njobs;   // the event kernel was pass 1
-    const bool use_pairs = fused_done || (pairs_enabled && max_lag + 1 <= AP_MAX_LAGS);
+    const bool use_pairs = pairs_enabled && max_lag + 1 <= AP_MAX_LAGS;
     std::vector<uint32_t> flag0(njobs, 0);
     unsigned char *d_flags = nullptr;
     u32 *d_nflagged = nullptr;
     const u32 nl = (max_lag + 1 + 63) / 64 * 64;
-    if (fused_done) {
-        flag0 = fused->flag0;
-        d_flags = const_cast<unsigned char *>(fused->d_flags);
-        d_nflagged = const_cast<u32 *>(fused->d_nflagged);
-    } else if (use_pairs) {
+    if (use_pairs) {
         uint64_t total_flags = 0;
         for (uint32_t i = 0; i < njobs; i++) {
             flag0[i] = (uint32_t)total_flags;
@@ -2140,7 +2183,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         int rc = pmx_ensure_slab_ac(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
         if (rc) return rc;
         pmx_timed_launch tl;
-        rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl, fused_done);
+        rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
         if (rc) return rc;
         if (chunked)
             hipLaunchKernelGGL(k_autocorr_edges<true>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,

@@ -78,6 +78,8 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->flags_cc_bytes = 0;
     ctx->d_slab_ac = nullptr;
     ctx->slab_ac_words = 0;
+    ctx->d_slab_fb = nullptr;
+    ctx->slab_fb_words = 0;
     ctx->aux_stream = nullptr;
     ctx->ev_fork = nullptr;
     ctx->ev_join = nullptr;
@@ -141,6 +143,7 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_flags_cc) (void)hipFree(ctx->d_flags_cc);
     if (ctx->d_slab_ac) (void)hipFree(ctx->d_slab_ac);
+    if (ctx->d_slab_fb) (void)hipFree(ctx->d_slab_fb);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
@@ -213,6 +216,20 @@ int pmx_ensure_slab_ac(pmx_ctx *ctx, size_t u32_words)
     }
     PMX_HIP(hipMalloc((void **)&ctx->d_slab_ac, u32_words * sizeof(u32)));
     ctx->slab_ac_words = u32_words;
+    return PMX_OK;
+}
+
+int pmx_ensure_slab_fb(pmx_ctx *ctx, size_t u32_words)
+{
+    if (ctx->slab_fb_words >= u32_words) return PMX_OK;
+    if (ctx->d_slab_fb) {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_HIP(hipFree(ctx->d_slab_fb));
+        ctx->d_slab_fb = nullptr;
+        ctx->slab_fb_words = 0;
+    }
+    PMX_HIP(hipMalloc((void **)&ctx->d_slab_fb, u32_words * sizeof(u32)));
+    ctx->slab_fb_words = u32_words;
     return PMX_OK;
 }
 
@@ -391,6 +408,7 @@ int pmx_debug_poison(pmx_ctx *ctx, uint32_t pattern, uint32_t mask)
     if ((mask & 1) && ctx->d_slab) PMX_HIP(hipMemsetAsync(ctx->d_slab, byte, ctx->slab_words * sizeof(u32), ctx->stream));
     if ((mask & 2) && ctx->d_slab2) PMX_HIP(hipMemsetAsync(ctx->d_slab2, byte, ctx->slab2_words * sizeof(u32), ctx->stream));
     if ((mask & 4) && ctx->d_slab_ac) PMX_HIP(hipMemsetAsync(ctx->d_slab_ac, byte, ctx->slab_ac_words * sizeof(u32), ctx->stream));
+    if ((mask & 4) && ctx->d_slab_fb) PMX_HIP(hipMemsetAsync(ctx->d_slab_fb, byte, ctx->slab_fb_words * sizeof(u32), ctx->stream));
     if ((mask & 8) && ctx->d_flags) PMX_HIP(hipMemsetAsync(ctx->d_flags, byte, ctx->flags_bytes, ctx->stream));
     if ((mask & 16) && ctx->d_flags_cc) PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, byte, ctx->flags_cc_bytes, ctx->stream));
     if ((mask & 32) && ctx->d_scratch) PMX_HIP(hipMemsetAsync(ctx->d_scratch, byte, ctx->scratch_words * sizeof(u64), ctx->stream));
@@ -726,8 +744,10 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             pmx_fused_mlen fm;
             rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, false, max_lag, &fm);
             if (rc) return rc;
-            rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride, &fm);
-            if (rc) return rc;
+            if (!fm.done) {   // (not expected: the launcher declined the fusion)
+                rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
+                if (rc) return rc;
+            }
             continue;
         }
         if (do_mlen && !fork) {

@@ -67,6 +67,8 @@ struct pmx_ctx {
     size_t flags_cc_bytes;
     u32 *d_slab_ac;              // slab of the window autocorrelation kernel (separate: it may run beside k_cc_sparse)
     size_t slab_ac_words;
+    u32 *d_slab_fb;              // slab of k_cc_sparse when it runs as the fallback behind the event kernel
+    size_t slab_fb_words;
     // staging for the host-pointer entry points
     uint64_t *d_stage[3];
     size_t stage_words[3];
@@ -103,14 +105,10 @@ struct pmx_job {
     uint64_t *d_out;                   // result block [PMX_NROWS][out_stride] (or the lag row, autocorr mode 0)
     uint64_t *d_out2;                  // autocorrelation only: pmx_autocorr_scratch_words(max_lag) u64 of per-job scratch
 };
-// What the event kernel already did of the mappable-length pass (pmx_launch_cc_sparse_batch hands this to
-// pmx_launch_autocorr_edges_batch): the edge-pair sums and scalars of every tile it took are in the jobs' d_out2; the tiles
-// it flagged as dense are left to the window kernel.
+// Whether the event kernel took the mappable-length pass as well (edge pairs in k_cc_events, the autocorrelation window
+// kernel for the tiles it flagged, the recurrence in k_events_tail).
 struct pmx_fused_mlen {
-    bool done;
-    const unsigned char *d_flags;      // indexed flag0[job] + tile (tiles of 64 Kbit)
-    const u32 *d_nflagged;
-    std::vector<uint32_t> flag0;
+    bool done;   // row MLEN and scalar [2] of every job were written by pmx_launch_cc_sparse_batch: no autocorrelation pass
 };
 int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len);
 // the event kernel can also take the edge pairs of the mappable-length pass for this geometry (and is not disabled)
@@ -126,11 +124,11 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
 // Run-edge autocorrelation of every job's d_M.  mode 0: d_out[k] = A(k), k <= max_lag.
 // mode 1: d_out is a result block: row MLEN[d] = A(|read_len - 1 - d|), d <= max_shift; scalar [2] = popcount(M).
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag,
-                                    uint32_t mode, uint32_t read_len, uint32_t max_shift, uint32_t out_stride,
-                                    const pmx_fused_mlen *fused = nullptr);
+                                    uint32_t mode, uint32_t read_len, uint32_t max_shift, uint32_t out_stride);
 int pmx_ensure_slab(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_slab2(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_slab_ac(pmx_ctx *ctx, size_t u32_words);
+int pmx_ensure_slab_fb(pmx_ctx *ctx, size_t u32_words);
 int pmx_ensure_flags(pmx_ctx *ctx, size_t bytes);
 int pmx_ensure_flags_cc(pmx_ctx *ctx, size_t bytes);
 size_t pmx_autocorr_scratch_words(uint32_t max_lag);
