@@ -16,7 +16,7 @@
 //                  a(d)-a(d-1) = -E[p-d+1]                    -> edge j = p-d+1:        GR[d] -= E[j] M[p+c-2d]   (type A)
 //                  b(d)-b(d-1) = -E[p+c-2d+1] - E[p+c-2d+2]   -> d = (p+c-j+2) >> 1:    GR[d] -= E[j] M[p-d+1]    (type B)
 //                  rsum[d] = R0 + sum_{t=1..d} GR[t],  R0 = sum_p M[p] M[p+c]
-// All integer arithmetic; the histograms GF / GR are signed and k_events_finish takes their prefix sums.
+// All integer arithmetic; the histograms GF / GR are signed and k_events_tail takes their prefix sums.
 //
 // The lists are SORTED (position order comes out of block-wide scans of the per-thread popcounts), and nothing is ever
 // searched: the first reverse partner of a forward read is its rank among the reverse reads = a popcount of the emitting
