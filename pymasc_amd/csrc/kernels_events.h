@@ -43,6 +43,18 @@
 #define EV_RSENT 0x3fffffffu              // reverse-list sentinel: beyond every range, and (sentinel - lo) stays positive as
                                           // an int32 for range starts lo >= -1023 (an edge below the tile minus read_len - 1)
 #define EV_SEG_ROWS 6u                    // slab segment rows of 1024 u32: ncc, GF, cc, GR, scalars, EE
+// s_setprio per phase (as in k_cc_sparse): with equal priorities the SIMD arbitrates by age and the co-resident workgroups
+// move in lockstep through the same phase; the staging + emit phase above the event loops: 0.519 -> 0.47 ms (same-box A/B,
+// every assignment with staging > events within +-2 % of each other; events above staging: 0.496; events alone raised: 0.52)
+#ifndef EV_PRIO_STAGE
+#define EV_PRIO_STAGE 3
+#endif
+#ifndef EV_PRIO_EVENTS
+#define EV_PRIO_EVENTS 1
+#endif
+#ifndef EV_PRIO_EDGES
+#define EV_PRIO_EDGES EV_PRIO_EVENTS
+#endif
 #ifndef EV_WAVES
 #define EV_WAVES 4
 #endif
@@ -248,6 +260,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         EV_STAMP(9)
         __syncthreads();   // B0: every wave is done with the previous tile's lists and M words
         EV_STAMP(0)
+        if (EV_PRIO_STAGE) __builtin_amdgcn_s_setprio(EV_PRIO_STAGE);
         // ---- phase A: from the prefetched registers ----
         // (thread-index derived addresses are recomputed per tile from an opaque copy: hoisted out of the tile loop they
         // cost ~30 registers for its whole lifetime and push the allocation into scratch)
@@ -391,7 +404,9 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             ev_fetch_job<HAS_M>(er, pj, g + 1 - pj.tile0, tid, nhr);
         }
         EV_STAMP(4)
+        if (EV_PRIO_STAGE) __builtin_amdgcn_s_setprio(0);
         __syncthreads();   // B1: lists, M words and edge ranks visible
+        if (EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(EV_PRIO_EVENTS);
         EV_STAMP(5)
         if (!dense) {
             // Work items are blocks of 64 drivers of three kinds; kind k deals its blocks to the waves starting at a
@@ -450,6 +465,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 }
 #endif
             EV_STAMP(8)
+            if (EV_PRIO_EDGES != EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(EV_PRIO_EDGES);
 #ifndef EV_ABL_NOFE
             // ---- the edge events of mscc.fsum and mscc.rsum, driven from the EDGES (~60 per tile, one block of lanes) instead
             // of from the ~330 reads each: for an edge j (sign E[j]) the reads it meets are contiguous in the sorted lists,
@@ -541,6 +557,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 }
             }
         }
+        if (EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(0);
         EV_STAMP(7)
         const bool leaving = jn != ji || g + 1 == g1;
         if (leaving) {
