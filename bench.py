@@ -203,6 +203,11 @@ def main():
     ev_free = [torch.cuda.Event() for _ in range(2)]     # the exchange of the step has read d_rows[b]
     nstep = [0]
 
+    # the hint the calculator gives from the read counts it holds (pymasc_amd/calculator.py: DENSE_READS_PER_BP)
+    from pymasc_amd.calculator import DENSE_READS_PER_BP
+    dense_reads = bool(vecs) and max(max(v.n_forward, v.n_reverse) / max(v.length, 1) for v in vecs) > DENSE_READS_PER_BP
+    step_flags = flags | (ffi.PMX_FLAG_WINDOW_ONLY if dense_reads and args.path == "auto" else 0)
+
     def step():
         # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev) on tstream, then the exchange
         # on xstream (double-buffered result blocks)
@@ -211,7 +216,7 @@ def main():
             tstream.wait_event(ev_free[b])
         nstep[0] += 1
         if vecs:
-            ctx.cc_batch_dev(pF, pR, pM, pN, S, L, flags, pO[b])
+            ctx.cc_batch_dev(pF, pR, pM, pN, S, L, step_flags, pO[b])
         ev_done[b].record(tstream)
         with torch.cuda.stream(xstream):
             xstream.wait_event(ev_done[b])

@@ -50,6 +50,10 @@ extern "C" {
 #define PMX_FLAG_SKIP_NCC     1u  /* skip_ncc=True (mscc.pyx:235,313): row 0 left zero (popcounts still reported) */
 #define PMX_FLAG_FORCE_DENSE  2u  /* use the dense word-parallel kernels (one lane per shift)          */
 #define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven kernels (error if unsupported)        */
+#define PMX_FLAG_WINDOW_ONLY 16u  /* hint: the caller knows the reads are dense (more than ~1 % of the positions of a
+                                   * strand hold a read start: > 60 M reads on hg38): go straight to the window
+                                   * kernel instead of letting the event kernel find that out tile by tile.  Same
+                                   * integers either way */
 #define PMX_FLAG_SKIP_MLEN    8u  /* the caller holds mappable_len already (the *_mappability.json cache,
                                    * handler/mappability.py:239-259): no autocorrelation pass; row 4 and
                                    * scalars[2] are written as zeros */

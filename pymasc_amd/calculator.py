@@ -31,6 +31,7 @@ from .result import (BothChromResult, BothGenomeWideResult, EmptyMSCCResult, Emp
 logger = logging.getLogger(__name__)
 
 _CHUNK = 1 << 16
+DENSE_READS_PER_BP = 0.0105      # reads of one strand per position above which PMX_FLAG_WINDOW_ONLY is passed
 
 
 class _PosBuffer:
@@ -271,6 +272,10 @@ class CCHipCalculator:
 
         self._logging_info("Calculate cross-correlation for {}...".format(chrom))
         flags = self._kernel_flags | (ffi.PMX_FLAG_SKIP_NCC if self.skip_ncc else 0)
+        # deep data: above ~1 % read starts per position and strand every tile overflows the event kernel's lists
+        # (EV_CAPF / EV_CAPR per 64 Kbit) -- say so instead of letting it find out (same integers either way)
+        if max(fbits.size, rbits.size) > DENSE_READS_PER_BP * max(glen, 1):
+            flags |= ffi.PMX_FLAG_WINDOW_ONLY
         c = L - 1
         known = self._known_mlen.get(chrom) if d_m is not None else None
         if known is not None and len(known) <= max(c, S - c):      # cache too short for this run: recompute

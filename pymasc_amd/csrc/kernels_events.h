@@ -35,8 +35,8 @@
 #define EV_HI 36u                         // ... and above it (read_len - 1 bits, + the partners' M bits)
 #define EV_MW (EV_LO + EV_TBW + EV_HI)    // 2148 dwords
 #define EV_BIAS (EV_LO * 32u)             // list positions are relative to the first staged bit of M
-#define EV_CAPF 512u                      // list capacities = the dense-tile thresholds
-#define EV_CAPR 640u                      // reverse reads of the tile + of the max_shift bits above it
+#define EV_CAPF 768u                      // list capacities = the dense-tile thresholds (read density ~1 % per strand)
+#define EV_CAPR 1000u                     // reverse reads of the tile + of the max_shift bits above it (< 1024: rank field)
 #define EV_CAPE 384u                      // run edges of everything staged
 #define EV_POS 0x1ffffu                   // 17 bits of biased position
 #define EV_PAD 12u                        // sentinel entries behind the read lists
@@ -80,24 +80,24 @@
 // LDS (dwords).  Histogram rows of 1024 i32: ncc, cc, GF, GR, EE (NCC-only: ncc).  An event that misses is not predicated
 // away but added to a DUMP slot, one per lane (LDS atomics of a wave to ONE address are serialised): a row r reaches the 64
 // slots of DUMP_A with the row-relative index (NROWS - r) * 1024 + lane.  The pair loop adds to rows ncc AND cc with ONE
-// index, so the same index must be harmless from row cc too: that is DUMP_B, 1024 dwords after DUMP_A, and the forward and
-// edge lists live in the gap.
+// index, so the same index must be harmless from row cc too: that is DUMP_B, 1024 dwords after DUMP_A, and the forward list
+// lives in the gap.
 template <bool HAS_M>
 struct EvLds {
     static constexpr u32 HIST = 0;
     static constexpr u32 NROWS = HAS_M ? 5u : 1u;
     static constexpr u32 DUMP_A = HIST + NROWS * 1024;
-    static constexpr u32 LF = DUMP_A + 64;
-    static constexpr u32 LE = LF + EV_CAPF + EV_PAD;                // (+EV_PAD: sentinels; the loops read ahead of their entry)
-    static constexpr u32 DUMP_B = HAS_M ? DUMP_A + 1024 : LE;
-    static constexpr u32 LR = HAS_M ? DUMP_B + 64 : LE;
-    static constexpr u32 WT = LR + EV_CAPR + EV_PAD;
+    static constexpr u32 LF = DUMP_A + 64;                          // (+EV_PAD: sentinels; the loops read ahead of their entry)
+    static constexpr u32 DUMP_B = HAS_M ? DUMP_A + 1024 : LF + EV_CAPF + EV_PAD;
+    static constexpr u32 LR = HAS_M ? DUMP_B + 64 : DUMP_B;
+    static constexpr u32 LE = LR + EV_CAPR + EV_PAD;
+    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE + 4 : 0u);
     static constexpr u32 MISC = WT + 32;                            // WT: [5][4 waves] scan totals
     static constexpr u32 IDXF = MISC + 16;                          // u16 per 512-bit block of the tile (+ end): list index of
     static constexpr u32 IDXR = IDXF + (HAS_M ? 66u : 0u);          // its first forward / reverse read
     static constexpr u32 MT0 = IDXR + (HAS_M ? 66u : 0u);           // [3] = the dword below the staged range, [4..] = M
     static constexpr u32 TOTAL = MT0 + (HAS_M ? 4u + EV_MW : 0u);
-    static_assert(!HAS_M || LE + EV_CAPE + 4 <= DUMP_B, "the lists must fit between the dump areas");
+    static_assert(!HAS_M || LF + EV_CAPF + EV_PAD <= DUMP_B, "the forward list must fit between the dump areas");
     static_assert(MT0 % 4 == 0, "alignment of the 16-byte stores");
 };
 
@@ -247,6 +247,10 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     SpJobRegs pj;   // job of the tile being prefetched (index jn), held in scalar registers
     load_job(pj, jobs.j[ji]);
     ev_fetch_job<HAS_M>(er, pj, g0 - pj.tile0, tid_, nhr);
+    // Read-dense stretches (deep data: every tile far above the list capacities): after two such tiles in a row the
+    // workgroup hands the REST of its tile range in this chromosome to the window kernels in one go (flags only, nothing
+    // staged): the event kernel then costs two tiles per workgroup instead of a wasted pass over everything.
+    u32 dense_run = 0;   // (uniform)
     u32 cur_tile0 = pj.tile0, cur_flag0 = pj.flag0;   // of the job whose tile is being processed (index ji)
     u32 cntF = 0, cntR = 0, cntB = 0, cnt0 = 0;   // per-thread: |F|, |R|, Bf, R0 of the tiles taken here
     u32 cntM = 0, cntU = 0;                       // DO_MLEN: popcount(M), runs starting in them
@@ -256,7 +260,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
 
-    for (u32 g = g0; g < g1; g++) {
+    for (u32 g = g0; g < g1;) {
         EV_STAMP(9)
         __syncthreads();   // B0: every wave is done with the previous tile's lists and M words
         EV_STAMP(0)
@@ -336,12 +340,15 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         const u32 nRt = __builtin_amdgcn_readfirstlane(TR0 + (tR >> 16));   // reverse reads inside the tile: the rsum drivers
         const u32 nR = __builtin_amdgcn_readfirstlane(nRt + tH);            // + the partners above it
         const u32 nE = __builtin_amdgcn_readfirstlane(TXb + TE0 + TE1 + (tX >> 16));
-        const bool dense = nF > EV_CAPF || nR > EV_CAPR || nE > EV_CAPE;
-#ifdef EV_ABL_NOEMIT
-        if (S == 0xffffffffu) {
-#else
+        // A tile is left to the window kernels when its lists would overflow.  Too many EDGES: both window kernels take it.
+        // Too many READS only: the cross-correlation window kernel takes it, but its run edges are still listed here for the
+        // edge pairs of the mappable-length pass (DO_MLEN), so that deep data on an ordinary track does not push that pass onto
+        // its window kernel as well.
+        const bool dense_e = HAS_M && nE > EV_CAPE;
+        const bool dense_r = nF > EV_CAPF || nR > EV_CAPR;
+        const bool dense = dense_e || dense_r;
+        const bool do_edges = HAS_M && !dense_e && (!dense || DO_MLEN);
         if (!dense) {
-#endif
             const u32 eF = bF + sF - pF, eR = bR + sR - pR;   // exclusive, per row
             const u32 oR0 = eR & 0xffffu, oR1 = TR0 + (eR >> 16);
             ev_emit_f(er.f[0], er.r[0], er.m[0], eF & 0xffffu, oR0, EV_BIAS + 0 * SP_TB + 128u * tid, LF);
@@ -349,27 +356,9 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             ev_emit_pos(er.r[0], oR0, EV_BIAS + 0 * SP_TB + 128u * tid, LR);
             ev_emit_pos(er.r[1], oR1, EV_BIAS + 1 * SP_TB + 128u * tid, LR);
             if (h_r) ev_emit_pos(er.h, nRt + bH + sH - cRh, EV_BIAS + EV_TB + 128u * lane, LR);
-            if (HAS_M) {
-                const u32 eE = bE + sE - pE, eX = bX + sX - pH;
-                const u32 oE0 = TXb + (eE & 0xffffu), oE1 = TXb + TE0 + (eE >> 16);
-#pragma unroll
-                for (u32 q = 0; q < EV_NQ; q++) {
-                    const uint4 Eq = edge_words(er.m[q], ev_below(er.m[q].w, er.wb[q]));
-                    const u32 o = q ? oE1 : oE0;
-                    ap_emit(Eq, er.m[q], o, EV_BIAS + q * SP_TB + 128u * tid, LE);
-                }
-                const uint4 Eh = edge_words(er.h, ev_below(er.h.w, er.hbw));
-                if (h_below) {
-                    ap_emit(Eh, er.h, eX & 0xffffu, 128u * lane, LE);
-                } else if (h_above) {
-                    const u32 oa = TXb + TE0 + TE1 + (eX >> 16);
-                    ap_emit(Eh, er.h, oa, EV_BIAS + EV_TB + 128u * lane, LE);
-                }
-            }
             // sentinels behind the lists: the event loops need no index bounds (and read ahead of their entry)
             if (tid < EV_PAD) LR[nR + tid] = EV_RSENT;
             else if (HAS_M && tid < 2 * EV_PAD) LF[nF + tid - EV_PAD] = EV_POS;
-            else if (HAS_M && tid < 2 * EV_PAD + 4) LE[nE + tid - 2 * EV_PAD] = EV_POS;
             if (HAS_M) {
                 // list index of the first read of every 512-bit block of the tile (the edge-driven loops start there)
                 if ((tid & 3u) == 0) {
@@ -385,23 +374,63 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             }
             cntF += cF[0] + cF[1];
             cntR += cR[0] + cR[1];
-            cntM += pendM;
-            cntU += pendU;
         } else if (tid == 0) {
             // dense tile: left to k_cc_sparse (both of its 32-Kbit tiles; the flag array is padded per job)
             const u32 f = cur_flag0 + EV_NQ * (g - cur_tile0);
             for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
-            if (DO_MLEN) tile_flags_ac[cur_flag0 + (g - cur_tile0)] = 1;   // (its window tile is this tile; same padded indexing)
+            if (DO_MLEN && dense_e) tile_flags_ac[cur_flag0 + (g - cur_tile0)] = 1;   // (its window tile is this tile; same padded indexing)
             atomicAdd(n_flagged, 1u);
+            if (DO_MLEN && dense_e) atomicAdd(n_flagged + 1, 1u);
+        }
+        if (do_edges) {
+            // the run edges (+ those of the halos) in position order
+            const u32 eE = bE + sE - pE, eX = bX + sX - pH;
+            const u32 oE0 = TXb + (eE & 0xffffu), oE1 = TXb + TE0 + (eE >> 16);
+#pragma unroll
+            for (u32 q = 0; q < EV_NQ; q++) {
+                const uint4 Eq = edge_words(er.m[q], ev_below(er.m[q].w, er.wb[q]));
+                const u32 o = q ? oE1 : oE0;
+                ap_emit(Eq, er.m[q], o, EV_BIAS + q * SP_TB + 128u * tid, LE);
+            }
+            const uint4 Eh = edge_words(er.h, ev_below(er.h.w, er.hbw));
+            if (h_below) {
+                ap_emit(Eh, er.h, eX & 0xffffu, 128u * lane, LE);
+            } else if (h_above) {
+                const u32 oa = TXb + TE0 + TE1 + (eX >> 16);
+                ap_emit(Eh, er.h, oa, EV_BIAS + EV_TB + 128u * lane, LE);
+            }
+            if (tid >= 2 * EV_PAD && tid < 2 * EV_PAD + 4) LE[nE + tid - 2 * EV_PAD] = EV_POS;   // sentinels
+            cntM += pendM;
+            cntU += pendU;
+        }
+        // stretch state (uniform): the second tile in a row FAR above the capacities (deep data, not a marginal density or a
+        // local pile-up) ends this workgroup's work in the chromosome.  Marginal tiles are flagged one by one: handing
+        // whole ranges over on their account would leave the window kernel with a few fully loaded workgroups.
+        dense_run = (2 * nF > 3 * EV_CAPF || 2 * nR > 3 * EV_CAPR) ? dense_run + 1 : 0u;
+        u32 gnext = g + 1;
+        if (dense_run >= 2) {
+            const u32 end = pj.tile_end < g1 ? pj.tile_end : g1;   // (pj is still the job of tile g here)
+            for (u32 t = g + 1 + tid; t < end; t += 256) {
+                const u32 f = cur_flag0 + EV_NQ * (t - cur_tile0);
+                for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
+                if (DO_MLEN) tile_flags_ac[cur_flag0 + (t - cur_tile0)] = 1;
+            }
+            if (tid == 0 && end > g + 1) {
+                atomicAdd(n_flagged, end - (g + 1));
+                if (DO_MLEN) atomicAdd(n_flagged + 1, end - (g + 1));
+            }
+            gnext = end;
+            dense_run = 0;
         }
         EV_STAMP(3)
         // ---- prefetch the next tile into the (now free) registers ----
-        if (g + 1 < g1) {
-            if (g + 1 >= pj.tile_end) {   // rare: the next tile belongs to the next job
+        if (gnext < g1) {
+            if (gnext >= pj.tile_end) {   // rare: the next tile belongs to the next job
                 jn = ji + 1;
                 load_job(pj, jobs.j[jn]);
+                dense_run = 0;
             }
-            ev_fetch_job<HAS_M>(er, pj, g + 1 - pj.tile0, tid, nhr);
+            ev_fetch_job<HAS_M>(er, pj, gnext - pj.tile0, tid, nhr);
         }
         EV_STAMP(4)
         if (EV_PRIO_STAGE) __builtin_amdgcn_s_setprio(0);
@@ -534,8 +563,12 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     }
                 }
 #endif
-            // ---- run edges of the tile x the edges within max_lag above them: the mappable-length autocorrelation ----
-            if (DO_MLEN) {
+        }
+        {
+            // ---- run edges of the tile x the edges within max_lag above them: the mappable-length autocorrelation (also
+            // for a tile whose READS went to the window kernel) ----
+            if (DO_MLEN && do_edges) {
+                const u32 dumpEE = L::NROWS * 1024 + lane - 4096;
                 const u32 nEt = TE0 + TE1;   // the tile's own edges sit at list indices [TXb, TXb + nEt)
                 for (u32 b = (wave + 1) & 3; 64 * b < nEt; b += 4) {
                     const u32 i = 64 * b + lane;
@@ -559,7 +592,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         }
         if (EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(0);
         EV_STAMP(7)
-        const bool leaving = jn != ji || g + 1 == g1;
+        const bool leaving = jn != ji || gnext >= g1;
         if (leaving) {
             // histograms + scalars of this (workgroup, job) -> its slab segment; cleared for the next job
             __syncthreads();
@@ -602,6 +635,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         ji = jn;
         cur_tile0 = pj.tile0;
         cur_flag0 = pj.flag0;
+        g = gnext;
     }
 #ifdef EV_STAMPS
     if ((tid_ & 63) == 0) {
@@ -625,7 +659,8 @@ struct EvTailPlan {
     u32 ac_first[SP_MAXJOBS], ac_last[SP_MAXJOBS];   // ... in the autocorrelation window launch
 };
 
-__global__ void __launch_bounds__(256)
+#define EV_TAIL_THREADS 1024u   // (the additions of the slow path are one block per chromosome: as many threads as shifts)
+__global__ void __launch_bounds__(EV_TAIL_THREADS)
 k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailPlan plan, const u32 *__restrict__ slab_cc,
               const u32 *__restrict__ slab_ac, const u32 *__restrict__ n_flagged, u32 S, u32 out_stride, u32 has_m, u32 do_ncc,
               u32 max_lag, u32 lagcap, int32_t c)
@@ -634,12 +669,12 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
     __shared__ long long tot[2];
     const u32 job = blockIdx.x, tid = threadIdx.x;
     const SpJobDev &jb = jobs.j[job];
-    const bool flagged = *n_flagged != 0;
+    const bool flagged = n_flagged[blockIdx.y] != 0;   // [0]: tiles flagged for k_cc_sparse, [1]: for k_autocorr_edges
     if (blockIdx.y == 1) {
         if (flagged) {
             u64 *P = jb.out2, *N = jb.out2 + lagcap, *scal = jb.out2 + 2 * (size_t)lagcap;
             const size_t stride = (size_t)AC_SEG_ROWS * 1024;
-            for (u32 k = tid; k <= max_lag; k += 256) {
+            for (u32 k = tid; k <= max_lag; k += EV_TAIL_THREADS) {
                 u64 sp = 0, sn = 0;
                 for (u32 w = plan.ac_first[job]; w <= plan.ac_last[job]; w++) {
                     const u32 *seg = slab_ac + (size_t)(w + job) * stride;
@@ -657,23 +692,23 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
             __threadfence_block();
             __syncthreads();
         }
-        autocorr_finish_job(jb, part, max_lag, lagcap, 1u, c, S, out_stride);
+        autocorr_finish_job(jb, part, max_lag, lagcap, 1u, c, S, out_stride, EV_TAIL_THREADS);
         return;
     }
     if (has_m) {
         long long bf = 0, r0 = 0;
-        for (u32 w = jb.wg_first + tid; w <= jb.wg_last; w += 256) {
+        for (u32 w = jb.wg_first + tid; w <= jb.wg_last; w += EV_TAIL_THREADS) {
             const u32 *sc = slab + (size_t)(w + job) * EV_SEG_ROWS * 1024 + 4 * 1024;
             bf += sc[2];
             r0 += sc[3];
         }
         const long long eb = block_exclusive_offset(bf, part, tid);   // (ends with a barrier)
-        if (tid == 255) tot[0] = eb + bf;
+        if (tid == EV_TAIL_THREADS - 1) tot[0] = eb + bf;
         const long long e0 = block_exclusive_offset(r0, part, tid);
-        if (tid == 255) tot[1] = e0 + r0;
+        if (tid == EV_TAIL_THREADS - 1) tot[1] = e0 + r0;
         __syncthreads();
         const long long Bf = tot[0], R0 = tot[1];
-        const u32 seg = (S + 1 + 255) / 256;
+        const u32 seg = (S + 1 + EV_TAIL_THREADS - 1) / EV_TAIL_THREADS;
         const u32 k0 = tid * seg, k1 = (k0 + seg < S + 1) ? k0 + seg : S + 1;
 #pragma unroll
         for (u32 row = 0; row < 2; row++) {
@@ -695,7 +730,7 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
         for (u32 r = 0; r < 4; r++) {
             if (r == 0 ? !do_ncc : !has_m) continue;
             u64 *dst = jb.out + (size_t)dst_row[r] * out_stride;
-            for (u32 d = tid; d <= S; d += 256) {
+            for (u32 d = tid; d <= S; d += EV_TAIL_THREADS) {
                 u64 sum = 0;
                 for (u32 w = plan.cc_first[job]; w <= plan.cc_last[job]; w++) sum += slab_cc[(size_t)(w + job) * stride + r * 1024 + d];
                 dst[d] += sum;

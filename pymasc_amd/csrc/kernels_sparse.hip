@@ -698,7 +698,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 
     // The loop runs over (tile, round) pairs plus one final drain pass, so that the fold / convert code below is
     // inlined exactly once (one round per tile unless a vector has more than SP_CAP set bits in the tile).
-    u32 g = g0, round_lo = 0, jn = ji;
+    u32 g = g0, gnext = g0, round_lo = 0, jn = ji;
     u32 nF = 0, nR = 0, iF = 0, iR = 0, nmax = 0, pendR = 0;
     bool leaving = false;   // the previous tile was the last of its job (for this workgroup): convert before going on
     u32 leave_job = 0;
@@ -733,13 +733,20 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 #endif
             if (tid < 2) cursor[2 * (par ^ 1) + tid] = 0;   // next tile's cursors (last read before B0)
             SP_STAMP(3)
-            // fetch the next tile into the (now free) registers; consumed after the next tile's B0
-            if (g + 1 < g1) {
-                if (g + 1 >= pj.tile_end) {   // rare: the next tile belongs to the next job
+            // fetch the next tile into the (now free) registers; consumed after the next tile's B0.  Behind the event kernel
+            // the unflagged tiles of this chromosome are skipped (pj is still the job of tile g here); the first tile of every
+            // chromosome in this workgroup's range is visited whatever its flag, so that its slab segment gets written.
+            gnext = g + 1;
+            if (!CH && tile_flags) {
+                const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
+                while (gnext < lim && !tile_flags[pj.flag0 + gnext - pj.tile0]) gnext++;
+            }
+            if (gnext < g1) {
+                if (gnext >= pj.tile_end) {   // rare: the next tile belongs to the next job
                     jn = ji + 1;
                     load_job(pj, jobs.j[jn]);
                 }
-                tile_fetch_job<HAS_M, CH>(tr, tx, pj, g + 1 - pj.tile0, tid, tile_flags);
+                tile_fetch_job<HAS_M, CH>(tr, tx, pj, gnext - pj.tile0, tid, tile_flags);
             }
             SP_STAMP(4)
             if (SP_PRIO_STAGE) __builtin_amdgcn_s_setprio(0);
@@ -1004,12 +1011,12 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         round_lo += RCAP;
         if (round_lo >= nmax) {
             round_lo = 0;
-            if (jn != ji || g + 1 == g1) {
+            if (jn != ji || gnext >= g1) {
                 leaving = true;
                 leave_job = ji;
             }
             ji = jn;
-            g++;
+            g = gnext;
         }
     }
 #ifdef SP_STAMPS
@@ -1286,7 +1293,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     const u32 lane_in_slot = sg.l4 >> 2;
 
     // (tile, round) pairs + one drain pass; the fold / convert code is inlined once (see k_cc_sparse)
-    u32 g = g0, round_lo = 0, jn = ji, n = 0, i0 = 0, pendM = 0, pendU = 0;
+    u32 g = g0, gnext = g0, round_lo = 0, jn = ji, n = 0, i0 = 0, pendM = 0, pendU = 0;
     bool leaving = false;
     u32 leave_job = 0;
     for (;;) {
@@ -1334,9 +1341,16 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
             }
             if (tid == 0) cursor[par ^ 1] = 0;
             jn = ji;
-            if (g + 1 < g1) {
-                if (g + 1 >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
-                ac_fetch_job<CH>(ar, jobs.j[jn], g + 1 - jobs.j[jn].tile0, tid, tile_flags);
+            // behind the pair / event kernel the unflagged tiles of this chromosome are skipped; the first tile of every
+            // chromosome in this workgroup's range is visited whatever its flag, so that its slab segment gets written
+            gnext = g + 1;
+            if (!CH && tile_flags) {
+                const u32 je = jobs.j[ji].tile0 + jobs.j[ji].ntiles, lim = je < g1 ? je : g1;
+                while (gnext < lim && !tile_flags[jobs.j[ji].flag0 + gnext - jobs.j[ji].tile0]) gnext++;
+            }
+            if (gnext < g1) {
+                if (gnext >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
+                ac_fetch_job<CH>(ar, jobs.j[jn], gnext - jobs.j[jn].tile0, tid, tile_flags);
             }
             __syncthreads();   // B1: tiles and records visible
             n = cursor[par];
@@ -1422,12 +1436,12 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
         round_lo += SP_CAP;
         if (round_lo >= n) {
             round_lo = 0;
-            if (jn != ji || g + 1 == g1) {
+            if (jn != ji || gnext >= g1) {
                 leaving = true;
                 leave_job = ji;
             }
             ji = jn;
-            g++;
+            g = gnext;
         }
     }
 }
@@ -1746,13 +1760,13 @@ __device__ __forceinline__ long long block_exclusive_offset(long long local_sum,
 }
 
 __device__ __forceinline__ void autocorr_finish_job(const SpJobDev &jb, long long *part, u32 max_lag, u32 lagcap, u32 mode,
-                                                    int32_t c, u32 max_shift, u32 out_stride)
+                                                    int32_t c, u32 max_shift, u32 out_stride, u32 nthreads = 256)
 {
     const u64 *P = jb.out2, *N = jb.out2 + lagcap, *scal = jb.out2 + 2 * (size_t)lagcap;
     long long *A = reinterpret_cast<long long *>(jb.out2 + 2 * (size_t)lagcap + 16);
     const u32 tid = threadIdx.x;
     const long long a0 = (long long)scal[0], runs = (long long)scal[1];
-    const u32 seg = (max_lag + 1 + 255) / 256;
+    const u32 seg = (max_lag + 1 + nthreads - 1) / nthreads;
     const u32 k0 = tid * seg, k1 = (k0 + seg < max_lag + 1) ? k0 + seg : max_lag + 1;
     // pass 1: Delta(k) = inclusive prefix of x(k), x(0) = -runs, x(k) = -(P[k] - N[k])
     long long sum = 0;
@@ -1774,11 +1788,11 @@ __device__ __forceinline__ void autocorr_finish_job(const SpJobDev &jb, long lon
     }
     __syncthreads();
     if (mode == 0) {
-        for (u32 k = tid; k <= max_lag; k += 256) jb.out[k] = (u64)A[k];
+        for (u32 k = tid; k <= max_lag; k += nthreads) jb.out[k] = (u64)A[k];
     } else {
         if (tid == 0) jb.out[(size_t)PMX_ROW_SCALARS * out_stride + 2] = (u64)a0;
         u64 *dst = jb.out + (size_t)PMX_ROW_MLEN * out_stride;
-        for (u32 d = tid; d <= max_shift; d += 256) {
+        for (u32 d = tid; d <= max_shift; d += nthreads) {
             const int32_t k = c - (int32_t)d;
             dst[d] = (u64)A[k < 0 ? -k : k];
         }
@@ -1937,7 +1951,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     rs.keep_scalar2 = (has_m && !zero_mlen) ? 1 : 0;
 
     // Pass 1 (sparse tiles): the event kernel over every chromosome; tiles whose lists would overflow are flagged.
-    const bool use_events = events_enabled() && !chunked;
+    const bool use_events = events_enabled() && !ctx->window_only && !chunked;
     const bool fuse_mlen = use_events && has_m && fused && njobs <= SP_MAXJOBS && pmx_events_can_fuse_mlen(max_shift, fused_lag);
     unsigned char *d_flags = nullptr, *d_flags_ac = nullptr;
     u32 *d_nflagged = nullptr;
@@ -2066,7 +2080,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl, true);
             if (rc) return rc;
             hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwg), dim3(256), 0, ctx->stream, tabA, n, total, tpw,
-                               lg_slot_lanes(fused_lag + 1), ctx->d_slab_ac, (const unsigned char *)d_flags_ac, (const u32 *)d_nflagged);
+                               lg_slot_lanes(fused_lag + 1), ctx->d_slab_ac, (const unsigned char *)d_flags_ac, (const u32 *)(d_nflagged + 1));
             PMX_CHECK_LAUNCH("k_autocorr_edges");
             rc = pmx_prof_end(ctx, &tl);
             if (rc) return rc;
@@ -2075,7 +2089,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
                 tp.ac_last[i] = tabA.j[i].wg_last;
             }
         }
-        hipLaunchKernelGGL(k_events_tail, dim3(n, fuse_mlen ? 2 : 1), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
+        hipLaunchKernelGGL(k_events_tail, dim3(n, fuse_mlen ? 2 : 1), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
                            (const u32 *)ctx->d_slab_fb, (const u32 *)ctx->d_slab_ac, (const u32 *)d_nflagged, max_shift, out_stride,
                            has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c);
         PMX_CHECK_LAUNCH("k_events_tail");

@@ -66,6 +66,7 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->profiling = 0;
+    ctx->window_only = false;
     ctx->d_scratch = nullptr;
     ctx->scratch_words = 0;
     ctx->d_slab = nullptr;
@@ -738,7 +739,8 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         // forked, 16.5 ms in sequence): the pair pass then holds 40 KB of histograms per workgroup
         const bool fork = fork_enabled && max_shift <= 1023;
         int rc;
-        if (do_mlen && pmx_events_can_fuse_mlen(max_shift, max_lag)) {
+        ctx->window_only = (flags & PMX_FLAG_WINDOW_ONLY) != 0;
+        if (do_mlen && !ctx->window_only && pmx_events_can_fuse_mlen(max_shift, max_lag)) {
             // the event kernel stages M and lists its run edges anyway: it takes the edge pairs of the mappable-length pass
             // too, and only the window kernel for the tiles it flagged + the recurrence remain of that pass
             pmx_fused_mlen fm;

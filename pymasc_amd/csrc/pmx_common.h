@@ -47,6 +47,7 @@ struct pmx_ctx {
     hipStream_t aux_stream;
     hipEvent_t ev_fork, ev_join;
     int num_cus;
+    bool window_only;            // PMX_FLAG_WINDOW_ONLY of the call in progress (pmx_cc_batch_dev)
     int profiling;               // 0 off; 1: kernels that do work; 2: also the (usually empty) fallback launches behind the event kernel
     std::vector<pmx_timed_launch> timed;       // launches not yet folded into the totals
     std::vector<hipEvent_t> event_pool;

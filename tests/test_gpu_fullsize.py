@@ -242,3 +242,40 @@ def test_stress_genome_as_specified(env, with_m):
     # a chromosome alone == its slot of the 200-chromosome batch (job table reuse across launches)
     for i in (31, 32, 199):
         np.testing.assert_array_equal(_run_batch(ctx, dev, [vecs[i]], S5, read_len=L5)[0], rows[i])
+
+
+def _pile_up(ctx, dev, v, lo, hi, density, seed):
+    """More reads on both strands inside [lo, hi): a local pile-up on an otherwise ordinary chromosome."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    n = int((hi - lo) * density)
+    for vec in (v.F, v.R):
+        pos = torch.randint(lo, hi, (n,), generator=g, device=dev, dtype=torch.int64)
+        torch.cuda.current_stream(dev).synchronize()
+        ctx.bits_set_positions_dev(vec.data_ptr(), v.nbits, pos.data_ptr(), pos.numel())
+    ctx.sync()
+
+
+@pytest.mark.parametrize("with_m", [True, False])
+def test_deep_and_marginal_data_hand_over_to_the_window_kernels(env, with_m):
+    """Chromosomes of several tiles per workgroup at read densities around and far above the event kernel's list
+    capacities (~1 % per strand): a deep one (every tile far above: the workgroups hand their whole ranges over after two
+    tiles), a marginal one (tiles flagged one by one, the window kernels skip the others), an ordinary one with a 3-Mbp
+    pile-up in the middle, an ordinary one.  The event path must give the integers of the window kernels alone
+    (PMX_FLAG_WINDOW_ONLY), and both must match torch at selected shifts."""
+    ctx, dev = env
+    shape = [("deep", 90_000_000, 0.02), ("marginal", 70_000_000, 0.0118), ("pileup", 80_000_000, 0.004), ("plain", 40_000_000, 0.005)]
+    vecs = [synth.make_chromosome(ctx, dev, n, ln, S, L, 0xD00D + i, density=rho, with_m=with_m)
+            for i, (n, ln, rho) in enumerate(shape)]
+    _pile_up(ctx, dev, vecs[2], 30_000_000, 33_000_000, 0.03, 77)
+    ev = _run_batch(ctx, dev, vecs, S)
+    win = _run_batch(ctx, dev, vecs, S, ffi.PMX_FLAG_WINDOW_ONLY)
+    np.testing.assert_array_equal(ev, win)
+    for i, v in enumerate(vecs):
+        for d in (0, 35, 36, 500, S):
+            ref = _torch_reference(v, d) if with_m else {"ncc": _torch_reference(v, d)["ncc"]}
+            assert int(ev[i, ffi.PMX_ROW_NCC_CCBINS, d]) == ref["ncc"], (v.name, d)
+            if with_m:
+                assert int(ev[i, ffi.PMX_ROW_MSCC_FSUM, d]) == ref["fsum"], (v.name, d)
+                assert int(ev[i, ffi.PMX_ROW_MSCC_RSUM, d]) == ref["rsum"], (v.name, d)
+                assert int(ev[i, ffi.PMX_ROW_MSCC_CCBINS, d]) == ref["cc"], (v.name, d)
+                assert int(ev[i, ffi.PMX_ROW_MLEN, d]) == ref["mlen"], (v.name, d)
