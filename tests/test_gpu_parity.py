@@ -212,8 +212,8 @@ def test_bits_builders_match_oracle(ctx):
 
 # ---- the event kernel (sparse tiles) and its hand-over to the window kernel (dense tiles) ----------------------------
 EVENT_TILE = 65536      # kernels_events.h: EV_TB
-EVENT_CAP_F = 512       # EV_CAPF: forward reads of one tile
-EVENT_CAP_R = 640       # EV_CAPR: reverse reads of the tile + of the max_shift bits above it
+EVENT_CAP_F = 768       # EV_CAPF: forward reads of one tile
+EVENT_CAP_R = 1000      # EV_CAPR: reverse reads of the tile + of the max_shift bits above it
 EVENT_CAP_E = 384       # EV_CAPE: run edges of everything staged for the tile
 
 
