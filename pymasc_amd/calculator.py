@@ -32,6 +32,7 @@ logger = logging.getLogger(__name__)
 
 _CHUNK = 1 << 16
 DENSE_READS_PER_BP = 0.0105      # reads of one strand per position above which PMX_FLAG_WINDOW_ONLY is passed
+DENSE_RUNS_PER_BP = 0.0025       # mappable runs per position above which it is passed (the event kernel lists 384 edges per 64 Kbit)
 
 
 class _PosBuffer:
@@ -223,6 +224,7 @@ class CCHipCalculator:
         d_m = self._device_vector("M", nbits)
         if first.size:
             self._ctx.bits_set_regions(d_m, nbits, first, last)   # set(begin + 1, end), mscc.pyx:343-344
+        self._n_runs = int(first.size)   # two run edges per interval: the other density the event kernel's lists depend on
         return d_m
 
     def _calc_correlation(self):
@@ -276,6 +278,8 @@ class CCHipCalculator:
         # (EV_CAPF / EV_CAPR per 64 Kbit) -- say so instead of letting it find out (same integers either way)
         if max(fbits.size, rbits.size) > DENSE_READS_PER_BP * max(glen, 1):
             flags |= ffi.PMX_FLAG_WINDOW_ONLY
+        if d_m is not None and getattr(self, "_n_runs", 0) > DENSE_RUNS_PER_BP * max(glen, 1):
+            flags |= ffi.PMX_FLAG_WINDOW_ONLY   # a track of short runs (> ~330 run edges per 64 Kbit on average)
         c = L - 1
         known = self._known_mlen.get(chrom) if d_m is not None else None
         if known is not None and len(known) <= max(c, S - c):      # cache too short for this run: recompute

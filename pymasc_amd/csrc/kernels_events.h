@@ -406,7 +406,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         // stretch state (uniform): the second tile in a row FAR above the capacities (deep data, not a marginal density or a
         // local pile-up) ends this workgroup's work in the chromosome.  Marginal tiles are flagged one by one: handing
         // whole ranges over on their account would leave the window kernel with a few fully loaded workgroups.
-        dense_run = (2 * nF > 3 * EV_CAPF || 2 * nR > 3 * EV_CAPR) ? dense_run + 1 : 0u;
+        dense_run = (2 * nF > 3 * EV_CAPF || 2 * nR > 3 * EV_CAPR || dense_e) ? dense_run + 1 : 0u;   // (run edges: dense stretches of a track are regional, the capacity itself is the trigger)
         u32 gnext = g + 1;
         if (dense_run >= 2) {
             const u32 end = pj.tile_end < g1 ? pj.tile_end : g1;   // (pj is still the job of tile g here)
