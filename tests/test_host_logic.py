@@ -199,3 +199,39 @@ def test_tiny_shift_ranges_host():
 def test_tiny_shift_ranges_gpu():
     from pymasc_amd import ffi
     _check_tiny_shift_ranges(lambda: ffi.Context(0))
+
+
+def test_dense_data_hint_from_the_counts_the_calculator_holds():
+    """PMX_FLAG_WINDOW_ONLY (skip the event kernel) is passed for a chromosome whose reads or mappable runs are too dense
+    for its lists, and only for that one; results are the oracle's either way."""
+    from pymasc_amd import calculator as C, ffi
+
+    class Recording(FakeContext):
+        def __init__(self):
+            super().__init__()
+            self.flags = []
+
+        def cc_dev(self, d_F, d_R, d_M, nbits, max_shift, read_len, flags, d_out):
+            self.flags.append(int(flags))
+            return super().cc_dev(d_F, d_R, d_M, nbits, max_shift, read_len, flags, d_out)
+
+    names, lens = ["sparse", "deep", "shortruns"], [6000, 6000, 6000]
+    rng = np.random.default_rng(5)
+    tracks = {"sparse": [(100, 5000, 1.0)], "deep": [(100, 5000, 1.0)],
+              "shortruns": [(b, b + 20, 1.0) for b in range(100, 5900, 100)]}          # 58 runs / 6000 bp > DENSE_RUNS_PER_BP
+    reads = []
+    for chrom, n in (("sparse", 30), ("deep", int(6000 * C.DENSE_READS_PER_BP * 2)), ("shortruns", 30)):
+        pos = np.sort(rng.choice(np.arange(1, 5900), size=n, replace=False))
+        reads += [(False, chrom, int(p), 36) for p in pos]
+        reads += [(True, chrom, int(p), 36) for p in pos]
+    reads.sort(key=lambda r: (names.index(r[1]), r[2]))
+    ctx = Recording()
+    calc = CCHipCalculator(100, 36, names, lens, bwfeeder=DictFeeder(tracks), context=ctx)
+    ocalc = oracle.OracleCalculator(100, 36, names, lens, mappability=tracks)
+    feed_all(calc, reads)
+    feed_all(ocalc, reads)
+    calc.finishup_calculation()
+    ocalc.finishup_calculation()
+    assert_matches_oracle(calc, ocalc, names)
+    hinted = [bool(f & ffi.PMX_FLAG_WINDOW_ONLY) for f in ctx.flags]
+    assert hinted == [False, True, True]
