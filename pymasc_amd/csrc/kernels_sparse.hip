@@ -1047,12 +1047,12 @@ struct ReduceSpec {
 #define RS_NBX 32u   // chunks of 32 elements per row (1024 shifts); a block takes the chunks blockIdx.x, + gridDim.x, ...
 __device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ slab, const SpJobTable &jobs, u32 seg_rows,
                                                       const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r, u32 bx,
-                                                      u64 (*part)[32])
+                                                      u64 (*part)[32])   // part[blockDim.x / 32][32]
 {
     const bool live = !gate || *gate != 0;   // gate == 0: the producing kernel did not run, every sum is zero
     if (!live && rs.accumulate) return;      // ... and there is nothing to add
-    // 32 consecutive elements x 8 workgroup phases per block: every load is a full 128-B line
-    const u32 job = blockIdx.z;
+    // 32 consecutive elements x (blockDim.x / 32) workgroup phases per block: every load is a full 128-B line
+    const u32 job = blockIdx.z, ng = blockDim.x >> 5;
     const SpJobDev &jb = jobs.j[job];
     const u32 e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const u32 i = bx * 32 + e;
@@ -1072,16 +1072,15 @@ __device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ sl
         const size_t stride = (size_t)seg_rows * 1024;
         const u32 *p = slab + (size_t)rs.src_row[r] * 1024 + (scalar ? rs.scalar_off : 0u) + i;
         if (rs.is_signed[r])
-            for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 8) sum += (u64)(long long)(int32_t)p[(size_t)(w + job) * stride];
+            for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += ng) sum += (u64)(long long)(int32_t)p[(size_t)(w + job) * stride];
         else
-            for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 8) sum += p[(size_t)(w + job) * stride];
+            for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += ng) sum += p[(size_t)(w + job) * stride];
     }
     part[g][e] = sum;
     __syncthreads();
     if (g != 0) return;
     u64 t = 0;
-#pragma unroll
-    for (u32 k = 0; k < 8; k++) t += part[k][e];
+    for (u32 k = 0; k < ng; k++) t += part[k][e];
     if (rs.use_out2) {
         if (i < n) {
             u64 *dst = jb.out2 + (size_t)rs.dst_row[r] + (scalar ? 0u : jb.d_off) + i;
@@ -1106,7 +1105,7 @@ __device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ sl
 __device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab, const SpJobTable &jobs, u32 seg_rows,
                                                     const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r)
 {
-    __shared__ u64 part[8][32];
+    __shared__ u64 part[32][32];   // (blocks of 256 or 1024 threads)
     for (u32 bx = blockIdx.x; bx < RS_NBX; bx += gridDim.x) {   // (uniform over the block)
         reduce_segments_chunk(slab, jobs, seg_rows, rs, gate, r, bx, part);
         __syncthreads();
@@ -1121,7 +1120,7 @@ k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_r
 }
 
 // two specifications over the same slab in one launch (grid.y = rows of A + rows of B)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_reduce_segments2(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_rows, ReduceSpec rsA, ReduceSpec rsB)
 {
     const u32 rowsA = rsA.nrows + rsA.nzero;   // (uniform over the block)
@@ -2014,7 +2013,8 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
                 r2.use_out2 = 1;
                 r2.n_override = fused_lag + 1;
                 r2.out_stride = out_stride;
-                hipLaunchKernelGGL(k_reduce_segments2, dim3(32, nr + nz + 3, n), dim3(256), 0, ctx->stream,
+                // (few chromosomes with many workgroups each -- a shard of a multi-GPU run --: more phases per block)
+                hipLaunchKernelGGL(k_reduce_segments2, dim3(32, nr + nz + 3, n), dim3(nwg > 128u * n ? 1024 : 256), 0, ctx->stream,
                                    (const u32 *)ctx->d_slab, tab, (u32)EV_SEG_ROWS, rs_ev, r2);
             } else {
                 hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab,
