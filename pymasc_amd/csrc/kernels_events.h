@@ -444,7 +444,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             // and the M bits of both are looked up together.
             const u32 nbF = (nF + 63) >> 6, nbR = (nRt + 63) >> 6;
             // row-relative dump indices (see EvLds)
-            const u32 dumpN = L::NROWS * 1024 + lane, dumpGF = dumpN - 2048, dumpGR = dumpN - 3072, dumpEE = dumpN - 4096;
+            const u32 dumpN = L::NROWS * 1024 + lane, dumpGF = dumpN - 2048, dumpGR = dumpN - 3072;
 #ifndef EV_ABL_NOFR
             // ---- forward reads x reverse reads in [x, x + S]: ncc, mscc.cc ----
             // No predication: an event that misses is added to the lane's dump slot of the row; idle lanes carry x = 0
