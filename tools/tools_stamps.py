@@ -8,6 +8,8 @@ lib = "/tmp/libstamps.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP", "-fPIC", "-shared", "-DSP_STAMPS",
                        "-o", lib] + sorted(glob.glob(os.path.join(ROOT, "pymasc_amd/csrc/*.hip"))))
 os.environ["PYMASC_AMD_LIB"] = lib
+os.environ["PMX_CC_EVENTS"] = "0"       # the window kernel on every tile (otherwise it only sees what the event kernel flags)
+os.environ["PMX_AUTOCORR_FORK"] = "0"
 import torch
 from pymasc_amd import ffi, synth
 mode = sys.argv[1] if len(sys.argv) > 1 else "both"
