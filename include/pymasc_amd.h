@@ -155,6 +155,15 @@ int pmx_ctx_reset_kernel_times(pmx_ctx *ctx);
 int pmx_ctx_kernel_time(pmx_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
 const char *pmx_kernel_name(int kernel_id);
 
+/* ---- diagnostics (tests, tools/) ----------------------------------------------------------- */
+/* Fills the context's scratch buffers (mask bits 0..7: slab, pair slab, window slabs, flag arrays, scratch, staging,
+ * output staging) and the LDS of every CU (bit 8) with `pattern`, so that a kernel reading memory it has not written
+ * fails deterministically.  No effect on results. */
+int pmx_debug_poison(pmx_ctx *ctx, uint32_t pattern, uint32_t mask);
+/* Copies `bytes` from byte offset `off` of the event / window kernels' slab to host memory (phase stamps of the
+ * diagnostic builds -DEV_STAMPS / -DSP_STAMPS). */
+int pmx_debug_read_slab(pmx_ctx *ctx, uint64_t off, void *dst, uint64_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ EXPORTS = [
     "pmx_bits_count",
     "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
     "pmx_ctx_set_profiling", "pmx_ctx_reset_kernel_times", "pmx_ctx_kernel_time", "pmx_kernel_name",
+    "pmx_debug_poison", "pmx_debug_read_slab",
 ]
 
 
@@ -95,6 +96,8 @@ def load_library(path: Optional[str] = None):
     L.pmx_ctx_kernel_time.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
     L.pmx_kernel_name.restype = ctypes.c_char_p
     L.pmx_kernel_name.argtypes = [i32]
+    L.pmx_debug_poison.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32]
+    L.pmx_debug_read_slab.argtypes = [vp, u64, vp, u64]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("pmx_version",):
@@ -256,10 +259,7 @@ class Context:
     def debug_poison(self, pattern: int, mask: int = 511) -> None:
         """Diagnostic: fill the context's scratch buffers (mask bits 0-7) and the LDS of every CU (bit 8) with a byte /
         dword pattern, so that a kernel reading memory it has not written fails deterministically (tests, fuzz)."""
-        fn = self._L.pmx_debug_poison
-        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
-        fn.restype = ctypes.c_int
-        _check(self._L, fn(self._h, int(pattern) & 0xffffffff, int(mask)))
+        _check(self._L, self._L.pmx_debug_poison(self._h, int(pattern) & 0xffffffff, int(mask)))
 
     def kernel_name(self, kernel_id: int) -> str:
         return self._L.pmx_kernel_name(int(kernel_id)).decode()
