@@ -663,13 +663,15 @@ struct EvTailPlan {
 __global__ void __launch_bounds__(EV_TAIL_THREADS)
 k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailPlan plan, const u32 *__restrict__ slab_cc,
               const u32 *__restrict__ slab_ac, const u32 *__restrict__ n_flagged, u32 S, u32 out_stride, u32 has_m, u32 do_ncc,
-              u32 max_lag, u32 lagcap, int32_t c)
+              u32 max_lag, u32 lagcap, int32_t c, u32 fused)
 {
     __shared__ long long part[256];
     __shared__ long long tot[2];
     const u32 job = blockIdx.x, tid = threadIdx.x;
     const SpJobDev &jb = jobs.j[job];
-    const bool flagged = n_flagged[blockIdx.y] != 0;   // [0]: tiles flagged for k_cc_sparse, [1]: for k_autocorr_edges
+    // blockIdx.y: 0 prefix sums (+ slow path: fsum, rsum), 1 autocorrelation, 2 / 3 slow path only: ncc + read counts / cc
+    const bool flagged = n_flagged[blockIdx.y == 1 ? 1 : 0] != 0;   // [0]: tiles flagged for k_cc_sparse, [1]: for k_autocorr_edges
+    if ((blockIdx.y >= 2 && !flagged) || (blockIdx.y == 1 && !fused)) return;
     if (blockIdx.y == 1) {
         if (flagged) {
             u64 *P = jb.out2, *N = jb.out2 + lagcap, *scal = jb.out2 + 2 * (size_t)lagcap;
@@ -695,7 +697,7 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
         autocorr_finish_job(jb, part, max_lag, lagcap, 1u, c, S, out_stride, EV_TAIL_THREADS);
         return;
     }
-    if (has_m) {
+    if (has_m && blockIdx.y == 0) {
         long long bf = 0, r0 = 0;
         for (u32 w = jb.wg_first + tid; w <= jb.wg_last; w += EV_TAIL_THREADS) {
             const u32 *sc = slab + (size_t)(w + job) * EV_SEG_ROWS * 1024 + 4 * 1024;
@@ -729,14 +731,17 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
         const size_t stride = (size_t)SP_SEG_ROWS * 1024;
         for (u32 r = 0; r < 4; r++) {
             if (r == 0 ? !do_ncc : !has_m) continue;
+            // the rows with prefix sums stay with the block that took them (y = 0); ncc -> y = 2, cc -> y = 3
+            if (blockIdx.y != (r == 0 ? 2u : (r == 2 ? 3u : 0u))) continue;
             u64 *dst = jb.out + (size_t)dst_row[r] * out_stride;
             for (u32 d = tid; d <= S; d += EV_TAIL_THREADS) {
                 u64 sum = 0;
+#pragma unroll 4
                 for (u32 w = plan.cc_first[job]; w <= plan.cc_last[job]; w++) sum += slab_cc[(size_t)(w + job) * stride + r * 1024 + d];
                 dst[d] += sum;
             }
         }
-        if (tid < 2) {
+        if (blockIdx.y == 2 && tid < 2) {
             u64 sc = 0;
             for (u32 w = plan.cc_first[job]; w <= plan.cc_last[job]; w++) sc += slab_cc[(size_t)(w + job) * stride + 4 * 1024 + tid];
             jb.out[(size_t)PMX_ROW_SCALARS * out_stride + tid] += sc;

@@ -2089,9 +2089,9 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
                 tp.ac_last[i] = tabA.j[i].wg_last;
             }
         }
-        hipLaunchKernelGGL(k_events_tail, dim3(n, fuse_mlen ? 2 : 1), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
+        hipLaunchKernelGGL(k_events_tail, dim3(n, 4), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
                            (const u32 *)ctx->d_slab_fb, (const u32 *)ctx->d_slab_ac, (const u32 *)d_nflagged, max_shift, out_stride,
-                           has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c);
+                           has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c, fuse_mlen ? 1u : 0u);
         PMX_CHECK_LAUNCH("k_events_tail");
     }
     return PMX_OK;
