@@ -645,7 +645,8 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 #endif
 }
 
-// The tail of the event pass, ONE launch per batch (grid: jobs x 2, the second half only with the mappable-length fusion):
+// The tail of the event pass, ONE launch per batch (grid: jobs x 4; y = 1 only with the mappable-length fusion, y = 2, 3 take
+// the ncc / cc rows of the slow path and return at once when nothing was flagged):
 //   y = 0: fsum[d] = Bf - sum_{t<=d} GF[t], rsum[d] = R0 + sum_{t<=d} GR[t] (k_reduce_segments left the signed sums of GF /
 //          GR over the workgroups in rows MSCC_FSUM / MSCC_RSUM of the result block; Bf and R0 are summed from the slab
 //          here), then -- only if the event kernel flagged dense tiles -- the sums of the cross-correlation window kernel
