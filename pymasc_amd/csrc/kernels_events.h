@@ -31,18 +31,18 @@
 #define EV_NQ 2u                          // driver quads per thread and vector: a tile is EV_NQ x 32 Kbit
 #define EV_TBW (EV_NQ * SP_TBW)           // 2048 dwords
 #define EV_TB (EV_NQ * SP_TB)             // 65536 bits
-#define EV_LO 64u                         // dwords of M staged below the tile (2 x max_shift bits)
+#define EV_LO 64u                         // dwords of M staged below the tile (2 x max_shift bits), max_shift <= 1023
+#define EV_LO_MAX 512u                    // ... in the BIG instantiations (max_shift <= 8191): a kernel argument
 #define EV_HI 36u                         // ... and above it (read_len - 1 bits, + the partners' M bits)
-#define EV_MW (EV_LO + EV_TBW + EV_HI)    // 2148 dwords
-#define EV_BIAS (EV_LO * 32u)             // list positions are relative to the first staged bit of M
 #define EV_CAPF 768u                      // list capacities = the dense-tile thresholds (read density ~1 % per strand)
 #define EV_CAPR 1000u                     // reverse reads of the tile + of the max_shift bits above it (< 1024: rank field)
 #define EV_CAPE 384u                      // run edges of everything staged
-#define EV_POS 0x1ffffu                   // 17 bits of biased position
+#define EV_POS 0x1ffffu                   // 17 bits of biased position (BIG: 16384 + 65536 + 8192 + 1152 staged bits at most)
 #define EV_PAD 12u                        // sentinel entries behind the read lists
 #define EV_RSENT 0x3fffffffu              // reverse-list sentinel: beyond every range, and (sentinel - lo) stays positive as
                                           // an int32 for range starts lo >= -1023 (an edge below the tile minus read_len - 1)
-#define EV_SEG_ROWS 6u                    // slab segment rows of 1024 u32: ncc, GF, cc, GR, scalars, EE
+#define EV_SEG_ROWS 6u                    // slab segment rows of `rowlen` u32: ncc, GF, cc, GR, scalars, EE
+#define EV_MAX_SHIFT 8191u                // largest max_shift of the event formulation (BIG instantiations)
 // s_setprio per phase (as in k_cc_sparse): with equal priorities the SIMD arbitrates by age and the co-resident workgroups
 // move in lockstep through the same phase; the staging + emit phase above the event loops: 0.519 -> 0.47 ms (same-box A/B,
 // every assignment with staging > events within +-2 % of each other; events above staging: 0.496; events alone raised: 0.52)
@@ -77,28 +77,43 @@
 #define EV_STAMP(i)
 #endif
 
-// LDS (dwords).  Histogram rows of 1024 i32: ncc, cc, GF, GR, EE (NCC-only: ncc).  An event that misses is not predicated
-// away but added to a DUMP slot, one per lane (LDS atomics of a wave to ONE address are serialised): a row r reaches the 64
-// slots of DUMP_A with the row-relative index (NROWS - r) * 1024 + lane.  The pair loop adds to rows ncc AND cc with ONE
-// index, so the same index must be harmless from row cc too: that is DUMP_B, 1024 dwords after DUMP_A, and the forward list
-// lives in the gap.
-template <bool HAS_M>
+// ---- LDS (dwords) -------------------------------------------------------------------------------------------------
+// One set of HISTOGRAMS per workgroup, shared by its NSG sub-groups of 256 threads (a sub-group = four wavefronts that
+// take one 64-Kbit tile per iteration with lists and M words of their own):
+//   NC [HN]      one cell per shift: ncc in the low half, mscc.ccbins in the high half -- ONE LDS atomic per pair
+//                (NCC-only: plain 32-bit ncc).  Both are counts of pairs of listed forward reads, at most one pair
+//                per forward read and shift: the row is flushed to the slab before 65535 listed forward reads.
+//   GF, GR, EE   signed.  !BIG: [HN] i32 each.  BIG: 16-bit cells, two per dword (cell k: dword k >> 1, half k & 1),
+//                added to with value << 16 (k & 1): the dword is lo + 65536 hi as an integer, recovered as
+//                lo = int16(w), hi = int16((w - lo) >> 16) while |lo|, |hi| < 32768; |GF[t]| <= listed forward reads,
+//                |GR[d]| <= 3 x listed reverse reads (type A: one edge per read and shift, type B: two), and the
+//                rows are flushed before those bounds reach 32767.
+//   DUMP [64]    an event that misses is not predicated away but added to a dump slot, one per lane (LDS atomics of a wave
+//                to ONE address are serialised); every row reaches the slots with a row-relative index.
+// 10 (BIG: 8, without EE) bytes of LDS per shift instead of round 2's 20: max_shift 2047 in the LDS of max_shift 1023,
+// and 8191 shifts + four sub-groups' lists (16 waves per CU) in 145 KB.
+template <bool HAS_M, bool BIG>
 struct EvLds {
-    static constexpr u32 HIST = 0;
-    static constexpr u32 NROWS = HAS_M ? 5u : 1u;
-    static constexpr u32 DUMP_A = HIST + NROWS * 1024;
-    static constexpr u32 LF = DUMP_A + 64;                          // (+EV_PAD: sentinels; the loops read ahead of their entry)
-    static constexpr u32 DUMP_B = HAS_M ? DUMP_A + 1024 : LF + EV_CAPF + EV_PAD;
-    static constexpr u32 LR = HAS_M ? DUMP_B + 64 : DUMP_B;
+    // per sub-group block
+    static constexpr u32 LF = 0;                                    // (+EV_PAD: sentinels; the loops read ahead of their entry)
+    static constexpr u32 LR = LF + EV_CAPF + EV_PAD;
     static constexpr u32 LE = LR + EV_CAPR + EV_PAD;
-    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE + 4 : 0u);
-    static constexpr u32 MISC = WT + 32;                            // WT: [5][4 waves] scan totals
+    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE + 4 : 0u);      // WT: [5][4 waves] scan totals
+    static constexpr u32 MISC = WT + 32;
     static constexpr u32 IDXF = MISC + 16;                          // u16 per 512-bit block of the tile (+ end): list index of
     static constexpr u32 IDXR = IDXF + (HAS_M ? 66u : 0u);          // its first forward / reverse read
     static constexpr u32 MT0 = IDXR + (HAS_M ? 66u : 0u);           // [3] = the dword below the staged range, [4..] = M
-    static constexpr u32 TOTAL = MT0 + (HAS_M ? 4u + EV_MW : 0u);
-    static_assert(!HAS_M || LF + EV_CAPF + EV_PAD <= DUMP_B, "the forward list must fit between the dump areas");
     static_assert(MT0 % 4 == 0, "alignment of the 16-byte stores");
+    __host__ __device__ static constexpr u32 sg_words(u32 lo) { return MT0 + (HAS_M ? 4u + lo + EV_TBW + EV_HI : 0u); }
+    // shared block (hn: entries per row, a multiple of 128)
+    __host__ __device__ static constexpr u32 row_words(u32 hn) { return BIG ? hn / 2 : hn; }
+    __host__ __device__ static constexpr u32 o_gf(u32 hn) { return hn; }
+    __host__ __device__ static constexpr u32 o_gr(u32 hn) { return o_gf(hn) + (HAS_M ? row_words(hn) : 0u); }
+    __host__ __device__ static constexpr u32 o_ee(u32 hn) { return o_gr(hn) + (HAS_M ? row_words(hn) : 0u); }
+    __host__ __device__ static constexpr u32 o_dump(u32 hn) { return o_ee(hn) + ((HAS_M && !BIG) ? hn : 0u); }
+    __host__ __device__ static constexpr u32 o_xch(u32 hn) { return o_dump(hn) + 64; }    // [0..7] sub-group counts, [8..13] scalars
+    __host__ __device__ static constexpr u32 o_sg(u32 hn) { return o_xch(hn) + 16; }
+    __host__ __device__ static constexpr u32 total(u32 hn, u32 lo, u32 nsg) { return o_sg(hn) + nsg * sg_words(lo); }
 };
 
 struct EvRegs {
@@ -109,11 +124,17 @@ struct EvRegs {
                                              // register shuffle that waits for the prefetch right where it is issued.
 };
 
-// halo quads, one role per wave so that no wave carries all the extra emission: threads [64,80) M below the tile,
-// [128,137) M above it, [192, 192+nhr) R above it
-template <bool HAS_M, bool GUARD>
+// halo quads, one role per wave so that no wave carries all the extra emission:
+//   !BIG: threads [64,80) M below the tile, [128,137) M above it, [192, 192+nhr) R above it
+//   BIG:  threads [0, lo/4) M below the tile (up to two waves: 2 x 8191 bits), the other two as above
+template <bool BIG>
+__device__ __forceinline__ bool ev_role_mlo(u32 tid, u32 lo) { return BIG ? tid < (lo >> 2) : (tid >> 6) == 1 && (tid & 63u) < 16; }
+template <bool BIG>
+__device__ __forceinline__ u32 ev_role_mlo_index(u32 tid) { return BIG ? tid : (tid & 63u); }
+
+template <bool HAS_M, bool GUARD, bool BIG>
 __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, const u32 *__restrict__ R,
-                                         const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid, u32 nhr)
+                                         const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid, u32 nhr, u32 lo)
 {
 #pragma unroll
     for (u32 q = 0; q < EV_NQ; q++) {
@@ -132,30 +153,33 @@ __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, 
     // ONE halo load for every lane (lanes without a role re-read their own quad and ignore it): loads of the roles in
     // separate branches target the same registers, and the compiler then waits for everything in flight between them
     const u32 ht = tid & 63u, hw = tid >> 6;
-    const bool m_lo = HAS_M && hw == 1 && ht < 16, m_hi = HAS_M && hw == 2 && ht < 9, r_hi = hw == 3 && ht < nhr;
+    const bool m_lo = HAS_M && ev_role_mlo<BIG>(tid, lo), m_hi = HAS_M && hw == 2 && ht < 9, r_hi = hw == 3 && ht < nhr;
     const u32 *hp = (m_lo || m_hi) ? M : R;
     int64_t jh = d0 + 4 * (int64_t)tid;
-    if (m_lo) jh = d0 - (int64_t)EV_LO + 4 * (int64_t)ht;
+    if (m_lo) jh = d0 - (int64_t)lo + 4 * (int64_t)ev_role_mlo_index<BIG>(tid);
     if (m_hi || r_hi) jh = d0 + EV_TBW + 4 * (int64_t)ht;
     er.h = ld_quad<GUARD>(hp, jh, nbits);
     er.hbw = 0;
     if (HAS_M) {
-        const int64_t jh0 = (hw == 1 ? d0 - (int64_t)EV_LO : d0 + EV_TBW) - 1;   // uniform over the wave
+        // the dword below lane 0's halo quad (uniform over the wave): waves with quads of M below the tile, else above it
+        const bool lo_wave = BIG ? hw < 2 : hw == 1;
+        const int64_t jh0 = (lo_wave ? d0 - (int64_t)lo + (BIG ? 256 * (int64_t)hw : 0) : d0 + EV_TBW) - 1;
         er.hbw = GUARD ? ld_dword_guarded(M, jh0, nbits) : M[jh0];
     }
 }
 
-template <bool HAS_M>
-__device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u32 local_tile, u32 tid, u32 nhr)
+template <bool HAS_M, bool BIG>
+__device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u32 local_tile, u32 tid, u32 nhr, u32 lo)
 {
     const int64_t d0 = (int64_t)local_tile * EV_TBW;
-    const int64_t lo = d0 - (int64_t)EV_LO - 1;
-    const uint64_t hi = (uint64_t)d0 + EV_TBW + EV_HI;
-    const bool interior = jb.aligned16 && lo >= 0 && hi + 2 <= jb.nbits / 32;
+    const int64_t low = d0 - (int64_t)lo - 1;
+    const u32 above = (BIG && 4 * nhr > EV_HI) ? 4 * nhr : EV_HI;   // dwords read above the tile (M: EV_HI, R: 4 nhr)
+    const uint64_t hi = (uint64_t)d0 + EV_TBW + above;
+    const bool interior = jb.aligned16 && low >= 0 && hi + 2 <= jb.nbits / 32;
     if (interior)
-        ev_fetch<HAS_M, false>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr);
+        ev_fetch<HAS_M, false, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo);
     else
-        ev_fetch<HAS_M, true>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr);
+        ev_fetch<HAS_M, true, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo);
 }
 
 // forward list entry: bits 0..16 biased position, 17..26 index of the first reverse read at or above it, 31 = M[x]
@@ -203,57 +227,87 @@ __device__ __forceinline__ u32 ev_below(u32 last_dword, u32 first)
 
 __device__ __forceinline__ u32 ev_mbit(const u32 *MT, u32 q) { return (MT[q >> 5] >> (q & 31u)) & 1u; }
 
-// slab segment of a (workgroup, job) pair: EV_SEG_ROWS rows of 1024 u32: ncc, GF, cc, GR, scalars (|F|, |R|, Bf, R0,
+// signed add to cell `cell` of a GF / GR / EE row (see EvLds)
+template <bool BIG>
+__device__ __forceinline__ void ev_add_cell(u32 *row, u32 cell, u32 val)
+{
+    if (BIG)
+        atomicAdd(&row[cell >> 1], val << ((cell & 1u) << 4));
+    else
+        atomicAdd(&row[cell], val);
+}
+
+// slab segment of a (workgroup, job) pair: EV_SEG_ROWS rows of `hn` u32: ncc, GF, cc, GR, scalars (|F|, |R|, Bf, R0,
 // popcount(M), runs), EE
 // DO_MLEN: also the pairs of run edges (the mappable-length autocorrelation, see k_autocorr_pairs): EE[k] = sum of
 // E[j] E[j + k] over the edges j of the tile, k = 1..max_lag, and popcount(M) / the runs starting in the tile.
-template <bool HAS_M, bool DO_NCC, bool DO_MLEN>
-__global__ void __launch_bounds__(256, HAS_M ? EV_WAVES : EV_WAVES_NCC)
+// NSG sub-groups of 256 threads; BIG: max_shift up to EV_MAX_SHIFT, geometry in the arguments `hn_arg` (entries per
+// histogram row) and `lo_arg` (dwords of M staged below a tile), histograms in dynamic LDS; !BIG: max_shift <= 1023.
+template <bool HAS_M, bool DO_NCC, bool DO_MLEN, u32 NSG, bool BIG>
+__global__ void __launch_bounds__(256 * NSG, (HAS_M || BIG) ? EV_WAVES : EV_WAVES_NCC)
 k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr, u32 max_lag,
-            u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags, unsigned char *__restrict__ tile_flags_ac,
-            u32 *__restrict__ n_flagged)
+            u32 hn_arg, u32 lo_arg, u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags,
+            unsigned char *__restrict__ tile_flags_ac, u32 *__restrict__ n_flagged)
 {
-    typedef EvLds<HAS_M> L;
-    __shared__ __align__(16) u32 lds[L::TOTAL];
-    u32 *const hN = lds + L::HIST;
-    u32 *const hC = lds + L::HIST + (HAS_M ? 1 * 1024u : 0u);
-    u32 *const hGF = lds + L::HIST + (HAS_M ? 2 * 1024u : 0u);
-    u32 *const hGR = lds + L::HIST + (HAS_M ? 3 * 1024u : 0u);
-    u32 *const hEE = lds + L::HIST + (HAS_M ? 4 * 1024u : 0u);
-    u32 *const MT = lds + L::MT0 + 4;
-    unsigned short *const idxF = reinterpret_cast<unsigned short *>(lds + L::IDXF);
-    unsigned short *const idxR = reinterpret_cast<unsigned short *>(lds + L::IDXR);
-    u32 *const LF = lds + L::LF;
-    u32 *const LR = lds + L::LR;
-    u32 *const LE = lds + L::LE;
-    u32 *const wt = lds + L::WT;
-    u32 *const misc = lds + L::MISC;
+    typedef EvLds<HAS_M, BIG> L;
+    static_assert(BIG || NSG == 1, "the max_shift <= 1023 instantiations are one sub-group per workgroup");
+    static_assert(!(BIG && DO_MLEN), "the edge pairs of the mappable-length pass are not fused beyond 1023 lags");
+    constexpr u32 NT = 256 * NSG;
+    extern __shared__ __align__(16) u32 ev_dyn_lds[];
+    __shared__ __align__(16) u32 ev_static_lds[BIG ? 4 : L::total(1024, EV_LO, 1)];
+    u32 *const lds = BIG ? ev_dyn_lds : ev_static_lds;
+    const u32 HN = BIG ? hn_arg : 1024u;      // entries per histogram row
+    const u32 LO = BIG ? lo_arg : EV_LO;      // dwords of M staged below the tile
+    const u32 BIAS = LO * 32u;                // list positions are relative to the first staged bit of M
+    const u32 sg = NSG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0u;
+    u32 *const hN = lds;
+    u32 *const hGF = lds + L::o_gf(HN);
+    u32 *const hGR = lds + L::o_gr(HN);
+    u32 *const hEE = lds + L::o_ee(HN);
+    u32 *const xch = lds + L::o_xch(HN);
+    u32 *const sgb = lds + L::o_sg(HN) + sg * L::sg_words(LO);
+    u32 *const MT = sgb + L::MT0 + 4;
+    unsigned short *const idxF = reinterpret_cast<unsigned short *>(sgb + L::IDXF);
+    unsigned short *const idxR = reinterpret_cast<unsigned short *>(sgb + L::IDXR);
+    u32 *const LF = sgb + L::LF;
+    u32 *const LR = sgb + L::LR;
+    u32 *const LE = sgb + L::LE;
+    u32 *const wt = sgb + L::WT;
 
-    const u32 tid_ = threadIdx.x;
-    const u32 wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const u32 gt = threadIdx.x;              // thread of the workgroup (histogram clears / flushes)
+    const u32 tid_ = NSG > 1 ? (threadIdx.x & 255u) : threadIdx.x;   // thread of the sub-group
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);      // wave of the sub-group
     const u32 g0 = blockIdx.x * tiles_per_wg;
     const u32 g1 = g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles;
     if (g0 >= g1) return;
     {
-        const u32 tid = tid_;
 #pragma nounroll
-        for (u32 i = tid; i < L::NROWS * 1024; i += 256) lds[L::HIST + i] = 0;
+        for (u32 i = gt; i < L::o_sg(HN); i += NT) lds[i] = 0;
     }
 
     u32 ji = 0;
     while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
     u32 jn = ji;
     EvRegs er;
-    SpJobRegs pj;   // job of the tile being prefetched (index jn), held in scalar registers
+    SpJobRegs pj;   // job of the tiles being prefetched (index jn), held in scalar registers
     load_job(pj, jobs.j[ji]);
-    ev_fetch_job<HAS_M>(er, pj, g0 - pj.tile0, tid_, nhr);
+    // an iteration takes the NSG tiles g .. g + NSG - 1 of ONE job (the histograms belong to a (workgroup, job) pair);
+    // sub-groups beyond the end of the job / of the workgroup's range sit the iteration out (they keep the barriers)
+    bool act_var = true;
+    if (NSG > 1) {
+        const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
+        act_var = g0 + sg < lim;
+    }
+    if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, g0 + sg - pj.tile0, tid_, nhr, LO);
     // Read-dense stretches (deep data: every tile far above the list capacities): after two such tiles in a row the
     // workgroup hands the REST of its tile range in this chromosome to the window kernels in one go (flags only, nothing
-    // staged): the event kernel then costs two tiles per workgroup instead of a wasted pass over everything.
+    // staged): the event kernel then costs two tiles per workgroup instead of a wasted pass over everything.  (NSG == 1)
     u32 dense_run = 0;   // (uniform)
-    u32 cur_tile0 = pj.tile0, cur_flag0 = pj.flag0;   // of the job whose tile is being processed (index ji)
+    u32 cur_tile0 = pj.tile0, cur_flag0 = pj.flag0;   // of the job whose tiles are being processed (index ji)
     u32 cntF = 0, cntR = 0, cntB = 0, cnt0 = 0;   // per-thread: |F|, |R|, Bf, R0 of the tiles taken here
     u32 cntM = 0, cntU = 0;                       // DO_MLEN: popcount(M), runs starting in them
+    u32 accF = 0, accR = 0;                       // (uniform) listed forward / reverse reads since the histograms' last flush
+    bool seg_written = false;                     // (uniform) this (workgroup, job) segment already holds a flush
 #ifdef EV_STAMPS
     unsigned long long stamp_acc[EV_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last;
@@ -261,6 +315,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 #endif
 
     for (u32 g = g0; g < g1;) {
+        const bool act = NSG == 1 ? true : act_var;   // (uniform over the sub-group)
         EV_STAMP(9)
         __syncthreads();   // B0: every wave is done with the previous tile's lists and M words
         EV_STAMP(0)
@@ -271,156 +326,179 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         u32 tid = tid_;
         asm volatile("" : "+v"(tid));
         const u32 lane = tid & 63;
-        u32 cF[EV_NQ], cR[EV_NQ], cE[EV_NQ] = {0, 0}, cEh = 0, cRh = 0, pendM = 0, pendU = 0;
+        u32 cF[EV_NQ] = {0, 0}, cR[EV_NQ] = {0, 0}, cE[EV_NQ] = {0, 0}, cEh = 0, cRh = 0, pendM = 0, pendU = 0;
+        const bool h_below = HAS_M && ev_role_mlo<BIG>(tid, LO), h_above = HAS_M && wave == 2 && lane < 9;
+        const u32 hb = ev_role_mlo_index<BIG>(tid);
+        const bool h_r = wave == 3 && lane < nhr;
+        u32 pF = 0, pR = 0, pE = 0, pH = 0, sF = 0, sR = 0, sH = 0, sE = 0, sX = 0;
+        if (act) {
 #pragma unroll
-        for (u32 q = 0; q < EV_NQ; q++) {
-            cF[q] = popc4(er.f[q]);
-            cR[q] = popc4(er.r[q]);
-            if (HAS_M) {
-                const u32 bel = ev_below(er.m[q].w, er.wb[q]);
-                cE[q] = popc4(edge_words(er.m[q], bel));   // (the edge words are recomputed when they are emitted)
-                *reinterpret_cast<uint4 *>(MT + EV_LO + q * SP_TBW + 4 * tid) = er.m[q];
-                if (DO_MLEN) {
-                    pendM += popc4(er.m[q]);
-                    // run starts = rising edges; rising - falling = M[last bit of the quad] - M[bit before it]
-                    pendU += (cE[q] + (er.m[q].w >> 31) - (bel >> 31)) >> 1;
+            for (u32 q = 0; q < EV_NQ; q++) {
+                cF[q] = popc4(er.f[q]);
+                cR[q] = popc4(er.r[q]);
+                if (HAS_M) {
+                    const u32 bel = ev_below(er.m[q].w, er.wb[q]);
+                    cE[q] = popc4(edge_words(er.m[q], bel));   // (the edge words are recomputed when they are emitted)
+                    *reinterpret_cast<uint4 *>(MT + LO + q * SP_TBW + 4 * tid) = er.m[q];
+                    if (DO_MLEN) {
+                        pendM += popc4(er.m[q]);
+                        // run starts = rising edges; rising - falling = M[last bit of the quad] - M[bit before it]
+                        pendU += (cE[q] + (er.m[q].w >> 31) - (bel >> 31)) >> 1;
+                    }
                 }
             }
-        }
-        const bool h_below = HAS_M && wave == 1 && lane < 16, h_above = HAS_M && wave == 2 && lane < 9;
-        const bool h_r = wave == 3 && lane < nhr;
-        const u32 hbel = HAS_M ? ev_below(er.h.w, er.hbw) : 0u;   // (all lanes: DPP reads the lane below)
-        if (h_below || h_above) {
-            cEh = popc4(edge_words(er.h, hbel));
-            *reinterpret_cast<uint4 *>(MT + (h_below ? 4 * lane : EV_LO + EV_TBW + 4 * lane)) = er.h;
-            if (h_below && lane == 0) MT[-1] = er.hbw;
-        }
-        if (h_r) cRh = popc4(er.h);
-        // position order = (row q, thread, word, bit): exclusive offsets from packed block scans (a row holds <= 32768
-        // bits and the halos <= 2048, so the 16-bit fields never carry)
-        const u32 pF = cF[0] | (cF[1] << 16), pR = cR[0] | (cR[1] << 16), pE = cE[0] | (cE[1] << 16);
-        const u32 pH = h_below ? cEh : cEh << 16;   // below | above
-        const u32 sF = wave_inclusive_scan(pF), sR = wave_inclusive_scan(pR), sH = wave_inclusive_scan(cRh);
-        u32 sE = 0, sX = 0;
-        if (HAS_M) {
-            sE = wave_inclusive_scan(pE);
-            sX = wave_inclusive_scan(pH);
-        }
-        if (lane == 63) {
-            wt[0 + wave] = sF;
-            wt[4 + wave] = sR;
-            wt[8 + wave] = sH;
+            const u32 hbel = HAS_M ? ev_below(er.h.w, er.hbw) : 0u;   // (all lanes: DPP reads the lane below)
+            if (h_below || h_above) {
+                cEh = popc4(edge_words(er.h, hbel));
+                *reinterpret_cast<uint4 *>(MT + (h_below ? 4 * hb : LO + EV_TBW + 4 * lane)) = er.h;
+                if (h_below && hb == 0) MT[-1] = er.hbw;
+            }
+            if (h_r) cRh = popc4(er.h);
+            // position order = (row q, thread, word, bit): exclusive offsets from packed block scans (a row holds <= 32768
+            // bits and the halos <= 16384, so the 16-bit fields never carry)
+            pF = cF[0] | (cF[1] << 16);
+            pR = cR[0] | (cR[1] << 16);
+            pE = cE[0] | (cE[1] << 16);
+            pH = h_below ? cEh : cEh << 16;   // below | above
+            sF = wave_inclusive_scan(pF);
+            sR = wave_inclusive_scan(pR);
+            sH = wave_inclusive_scan(cRh);
             if (HAS_M) {
-                wt[12 + wave] = sE;
-                wt[16 + wave] = sX;
+                sE = wave_inclusive_scan(pE);
+                sX = wave_inclusive_scan(pH);
+            }
+            if (lane == 63) {
+                wt[0 + wave] = sF;
+                wt[4 + wave] = sR;
+                wt[8 + wave] = sH;
+                if (HAS_M) {
+                    wt[12 + wave] = sE;
+                    wt[16 + wave] = sX;
+                }
             }
         }
         EV_STAMP(1)
         __syncthreads();   // Bs
         EV_STAMP(2)
-        u32 bF = 0, bR = 0, bH = 0, bE = 0, bX = 0, tF = 0, tR = 0, tH = 0, tE = 0, tX = 0;
+        u32 nF = 0, nRt = 0, nR = 0, nE = 0, TXb = 0, TE0 = 0, TE1 = 0;
+        bool dense = false, do_edges = false;
+        u32 gnext = g + NSG;
+        if (act) {
+            u32 bF = 0, bR = 0, bH = 0, bE = 0, bX = 0, tF = 0, tR = 0, tH = 0, tE = 0, tX = 0;
 #pragma unroll
-        for (u32 w = 0; w < 4; w++) {
-            const u32 xF = wt[w], xR = wt[4 + w], xH = wt[8 + w], xE = HAS_M ? wt[12 + w] : 0u, xX = HAS_M ? wt[16 + w] : 0u;
-            if (w < wave) {
-                bF += xF;
-                bR += xR;
-                bH += xH;
-                bE += xE;
-                bX += xX;
-            }
-            tF += xF;
-            tR += xR;
-            tH += xH;
-            tE += xE;
-            tX += xX;
-        }
-        const u32 TF0 = tF & 0xffffu, TR0 = tR & 0xffffu, TE0 = tE & 0xffffu, TE1 = tE >> 16, TXb = tX & 0xffffu;
-        const u32 nF = __builtin_amdgcn_readfirstlane(TF0 + (tF >> 16));
-        const u32 nRt = __builtin_amdgcn_readfirstlane(TR0 + (tR >> 16));   // reverse reads inside the tile: the rsum drivers
-        const u32 nR = __builtin_amdgcn_readfirstlane(nRt + tH);            // + the partners above it
-        const u32 nE = __builtin_amdgcn_readfirstlane(TXb + TE0 + TE1 + (tX >> 16));
-        // A tile is left to the window kernels when its lists would overflow.  Too many EDGES: both window kernels take it.
-        // Too many READS only: the cross-correlation window kernel takes it, but its run edges are still listed here for the
-        // edge pairs of the mappable-length pass (DO_MLEN), so that deep data on an ordinary track does not push that pass onto
-        // its window kernel as well.
-        const bool dense_e = HAS_M && nE > EV_CAPE;
-        const bool dense_r = nF > EV_CAPF || nR > EV_CAPR;
-        const bool dense = dense_e || dense_r;
-        const bool do_edges = HAS_M && !dense_e && (!dense || DO_MLEN);
-        if (!dense) {
-            const u32 eF = bF + sF - pF, eR = bR + sR - pR;   // exclusive, per row
-            const u32 oR0 = eR & 0xffffu, oR1 = TR0 + (eR >> 16);
-            ev_emit_f(er.f[0], er.r[0], er.m[0], eF & 0xffffu, oR0, EV_BIAS + 0 * SP_TB + 128u * tid, LF);
-            ev_emit_f(er.f[1], er.r[1], er.m[1], TF0 + (eF >> 16), oR1, EV_BIAS + 1 * SP_TB + 128u * tid, LF);
-            ev_emit_pos(er.r[0], oR0, EV_BIAS + 0 * SP_TB + 128u * tid, LR);
-            ev_emit_pos(er.r[1], oR1, EV_BIAS + 1 * SP_TB + 128u * tid, LR);
-            if (h_r) ev_emit_pos(er.h, nRt + bH + sH - cRh, EV_BIAS + EV_TB + 128u * lane, LR);
-            // sentinels behind the lists: the event loops need no index bounds (and read ahead of their entry)
-            if (tid < EV_PAD) LR[nR + tid] = EV_RSENT;
-            else if (HAS_M && tid < 2 * EV_PAD) LF[nF + tid - EV_PAD] = EV_POS;
-            if (HAS_M) {
-                // list index of the first read of every 512-bit block of the tile (the edge-driven loops start there)
-                if ((tid & 3u) == 0) {
-                    idxF[tid >> 2] = (unsigned short)(eF & 0xffffu);
-                    idxF[64 + (tid >> 2)] = (unsigned short)(TF0 + (eF >> 16));
-                    idxR[tid >> 2] = (unsigned short)oR0;
-                    idxR[64 + (tid >> 2)] = (unsigned short)oR1;
+            for (u32 w = 0; w < 4; w++) {
+                const u32 xF = wt[w], xR = wt[4 + w], xH = wt[8 + w], xE = HAS_M ? wt[12 + w] : 0u, xX = HAS_M ? wt[16 + w] : 0u;
+                if (w < wave) {
+                    bF += xF;
+                    bR += xR;
+                    bH += xH;
+                    bE += xE;
+                    bX += xX;
                 }
-                if (tid == 255) {
-                    idxF[128] = (unsigned short)nF;
-                    idxR[128] = (unsigned short)nRt;
+                tF += xF;
+                tR += xR;
+                tH += xH;
+                tE += xE;
+                tX += xX;
+            }
+            const u32 TF0 = tF & 0xffffu, TR0 = tR & 0xffffu;
+            TE0 = tE & 0xffffu;
+            TE1 = tE >> 16;
+            TXb = tX & 0xffffu;
+            nF = __builtin_amdgcn_readfirstlane(TF0 + (tF >> 16));
+            nRt = __builtin_amdgcn_readfirstlane(TR0 + (tR >> 16));   // reverse reads inside the tile: the rsum drivers
+            nR = __builtin_amdgcn_readfirstlane(nRt + tH);            // + the partners above it
+            nE = __builtin_amdgcn_readfirstlane(TXb + TE0 + TE1 + (tX >> 16));
+            // A tile is left to the window kernels when its lists would overflow.  Too many EDGES: both window kernels take it.
+            // Too many READS only: the cross-correlation window kernel takes it, but its run edges are still listed here for the
+            // edge pairs of the mappable-length pass (DO_MLEN), so that deep data on an ordinary track does not push that pass onto
+            // its window kernel as well.
+            const bool dense_e = HAS_M && nE > EV_CAPE;
+            const bool dense_r = nF > EV_CAPF || nR > EV_CAPR;
+            dense = dense_e || dense_r;
+            do_edges = HAS_M && !dense_e && (!dense || DO_MLEN);
+            const u32 my_tile = g + sg;
+            if (!dense) {
+                const u32 eF = bF + sF - pF, eR = bR + sR - pR;   // exclusive, per row
+                const u32 oR0 = eR & 0xffffu, oR1 = TR0 + (eR >> 16);
+                ev_emit_f(er.f[0], er.r[0], er.m[0], eF & 0xffffu, oR0, BIAS + 0 * SP_TB + 128u * tid, LF);
+                ev_emit_f(er.f[1], er.r[1], er.m[1], TF0 + (eF >> 16), oR1, BIAS + 1 * SP_TB + 128u * tid, LF);
+                ev_emit_pos(er.r[0], oR0, BIAS + 0 * SP_TB + 128u * tid, LR);
+                ev_emit_pos(er.r[1], oR1, BIAS + 1 * SP_TB + 128u * tid, LR);
+                if (h_r) ev_emit_pos(er.h, nRt + bH + sH - cRh, BIAS + EV_TB + 128u * lane, LR);
+                // sentinels behind the lists: the event loops need no index bounds (and read ahead of their entry)
+                if (tid < EV_PAD) LR[nR + tid] = EV_RSENT;
+                else if (HAS_M && tid < 2 * EV_PAD) LF[nF + tid - EV_PAD] = EV_POS;
+                if (HAS_M) {
+                    // list index of the first read of every 512-bit block of the tile (the edge-driven loops start there)
+                    if ((tid & 3u) == 0) {
+                        idxF[tid >> 2] = (unsigned short)(eF & 0xffffu);
+                        idxF[64 + (tid >> 2)] = (unsigned short)(TF0 + (eF >> 16));
+                        idxR[tid >> 2] = (unsigned short)oR0;
+                        idxR[64 + (tid >> 2)] = (unsigned short)oR1;
+                    }
+                    if (tid == 255) {
+                        idxF[128] = (unsigned short)nF;
+                        idxR[128] = (unsigned short)nRt;
+                    }
                 }
-            }
-            cntF += cF[0] + cF[1];
-            cntR += cR[0] + cR[1];
-        } else if (tid == 0) {
-            // dense tile: left to k_cc_sparse (both of its 32-Kbit tiles; the flag array is padded per job)
-            const u32 f = cur_flag0 + EV_NQ * (g - cur_tile0);
-            for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
-            if (DO_MLEN && dense_e) tile_flags_ac[cur_flag0 + (g - cur_tile0)] = 1;   // (its window tile is this tile; same padded indexing)
-            atomicAdd(n_flagged, 1u);
-            if (DO_MLEN && dense_e) atomicAdd(n_flagged + 1, 1u);
-        }
-        if (do_edges) {
-            // the run edges (+ those of the halos) in position order
-            const u32 eE = bE + sE - pE, eX = bX + sX - pH;
-            const u32 oE0 = TXb + (eE & 0xffffu), oE1 = TXb + TE0 + (eE >> 16);
-#pragma unroll
-            for (u32 q = 0; q < EV_NQ; q++) {
-                const uint4 Eq = edge_words(er.m[q], ev_below(er.m[q].w, er.wb[q]));
-                const u32 o = q ? oE1 : oE0;
-                ap_emit(Eq, er.m[q], o, EV_BIAS + q * SP_TB + 128u * tid, LE);
-            }
-            const uint4 Eh = edge_words(er.h, ev_below(er.h.w, er.hbw));
-            if (h_below) {
-                ap_emit(Eh, er.h, eX & 0xffffu, 128u * lane, LE);
-            } else if (h_above) {
-                const u32 oa = TXb + TE0 + TE1 + (eX >> 16);
-                ap_emit(Eh, er.h, oa, EV_BIAS + EV_TB + 128u * lane, LE);
-            }
-            if (tid >= 2 * EV_PAD && tid < 2 * EV_PAD + 4) LE[nE + tid - 2 * EV_PAD] = EV_POS;   // sentinels
-            cntM += pendM;
-            cntU += pendU;
-        }
-        // stretch state (uniform): the second tile in a row FAR above the capacities (deep data, not a marginal density or a
-        // local pile-up) ends this workgroup's work in the chromosome.  Marginal tiles are flagged one by one: handing
-        // whole ranges over on their account would leave the window kernel with a few fully loaded workgroups.
-        dense_run = (2 * nF > 3 * EV_CAPF || 2 * nR > 3 * EV_CAPR || dense_e) ? dense_run + 1 : 0u;   // (run edges: dense stretches of a track are regional, the capacity itself is the trigger)
-        u32 gnext = g + 1;
-        if (dense_run >= 2) {
-            const u32 end = pj.tile_end < g1 ? pj.tile_end : g1;   // (pj is still the job of tile g here)
-            for (u32 t = g + 1 + tid; t < end; t += 256) {
-                const u32 f = cur_flag0 + EV_NQ * (t - cur_tile0);
+                cntF += cF[0] + cF[1];
+                cntR += cR[0] + cR[1];
+            } else if (tid == 0) {
+                // dense tile: left to k_cc_sparse (both of its 32-Kbit tiles; the flag array is padded per job)
+                const u32 f = cur_flag0 + EV_NQ * (my_tile - cur_tile0);
                 for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
-                if (DO_MLEN) tile_flags_ac[cur_flag0 + (t - cur_tile0)] = 1;
+                if (DO_MLEN && dense_e) tile_flags_ac[cur_flag0 + (my_tile - cur_tile0)] = 1;   // (its window tile is this tile; same padded indexing)
+                atomicAdd(n_flagged, 1u);
+                if (DO_MLEN && dense_e) atomicAdd(n_flagged + 1, 1u);
             }
-            if (tid == 0 && end > g + 1) {
-                atomicAdd(n_flagged, end - (g + 1));
-                if (DO_MLEN) atomicAdd(n_flagged + 1, end - (g + 1));
+            if (do_edges) {
+                // the run edges (+ those of the halos) in position order
+                const u32 eE = bE + sE - pE, eX = bX + sX - pH;
+                const u32 oE0 = TXb + (eE & 0xffffu), oE1 = TXb + TE0 + (eE >> 16);
+#pragma unroll
+                for (u32 q = 0; q < EV_NQ; q++) {
+                    const uint4 Eq = edge_words(er.m[q], ev_below(er.m[q].w, er.wb[q]));
+                    const u32 o = q ? oE1 : oE0;
+                    ap_emit(Eq, er.m[q], o, BIAS + q * SP_TB + 128u * tid, LE);
+                }
+                const uint4 Eh = edge_words(er.h, ev_below(er.h.w, er.hbw));
+                if (h_below) {
+                    ap_emit(Eh, er.h, eX & 0xffffu, 128u * hb, LE);
+                } else if (h_above) {
+                    const u32 oa = TXb + TE0 + TE1 + (eX >> 16);
+                    ap_emit(Eh, er.h, oa, BIAS + EV_TB + 128u * lane, LE);
+                }
+                if (tid >= 2 * EV_PAD && tid < 2 * EV_PAD + 4) LE[nE + tid - 2 * EV_PAD] = EV_POS;   // sentinels
+                cntM += pendM;
+                cntU += pendU;
             }
-            gnext = end;
-            dense_run = 0;
+            if (NSG == 1) {
+                // stretch state (uniform): the second tile in a row FAR above the capacities (deep data, not a marginal density or a
+                // local pile-up) ends this workgroup's work in the chromosome.  Marginal tiles are flagged one by one: handing
+                // whole ranges over on their account would leave the window kernel with a few fully loaded workgroups.
+                dense_run = (2 * nF > 3 * EV_CAPF || 2 * nR > 3 * EV_CAPR || dense_e) ? dense_run + 1 : 0u;   // (run edges: dense stretches of a track are regional, the capacity itself is the trigger)
+                if (dense_run >= 2) {
+                    const u32 end = pj.tile_end < g1 ? pj.tile_end : g1;   // (pj is still the job of tile g here)
+                    for (u32 t = g + 1 + tid; t < end; t += 256) {
+                        const u32 f = cur_flag0 + EV_NQ * (t - cur_tile0);
+                        for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
+                        if (DO_MLEN) tile_flags_ac[cur_flag0 + (t - cur_tile0)] = 1;
+                    }
+                    if (tid == 0 && end > g + 1) {
+                        atomicAdd(n_flagged, end - (g + 1));
+                        if (DO_MLEN) atomicAdd(n_flagged + 1, end - (g + 1));
+                    }
+                    gnext = end;
+                    dense_run = 0;
+                }
+            }
+        }
+        if (NSG > 1) {
+            // the listed reads of every sub-group (flush bookkeeping), and the end of the iteration's job
+            if (tid == 0) xch[sg] = (act && !dense) ? (nF | (nRt << 16)) : 0u;
+            const u32 end = pj.tile_end < g1 ? pj.tile_end : g1;   // (pj is still the job of tile g here)
+            if (gnext > end) gnext = end;
         }
         EV_STAMP(3)
         // ---- prefetch the next tile into the (now free) registers ----
@@ -430,30 +508,38 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 load_job(pj, jobs.j[jn]);
                 dense_run = 0;
             }
-            ev_fetch_job<HAS_M>(er, pj, gnext - pj.tile0, tid, nhr);
+            if (NSG > 1) {
+                const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
+                act_var = gnext + sg < lim;
+            }
+            if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, gnext + sg - pj.tile0, tid, nhr, LO);
+        } else if (NSG > 1) {
+            act_var = false;
         }
         EV_STAMP(4)
         if (EV_PRIO_STAGE) __builtin_amdgcn_s_setprio(0);
         __syncthreads();   // B1: lists, M words and edge ranks visible
         if (EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(EV_PRIO_EVENTS);
         EV_STAMP(5)
-        if (!dense) {
+        if (act && !dense) {
             // Work items are blocks of 64 drivers of three kinds; kind k deals its blocks to the waves starting at a
             // different wave, so that the odd blocks of the kinds land on different waves.  The loops are bound by LDS
             // round trips, not by instruction issue: every trip takes two list entries, the next two are already in flight,
             // and the M bits of both are looked up together.
             const u32 nbF = (nF + 63) >> 6, nbR = (nRt + 63) >> 6;
-            // row-relative dump indices (see EvLds)
-            const u32 dumpN = L::NROWS * 1024 + lane, dumpGF = dumpN - 2048, dumpGR = dumpN - 3072;
+            // row-relative dump cells (see EvLds)
+            const u32 dumpN = L::o_dump(HN) + lane;
+            const u32 dumpGF = (L::o_dump(HN) - L::o_gf(HN) + lane) << (BIG ? 1 : 0);
+            const u32 dumpGR = (L::o_dump(HN) - L::o_gr(HN) + lane) << (BIG ? 1 : 0);
 #ifndef EV_ABL_NOFR
             // ---- forward reads x reverse reads in [x, x + S]: ncc, mscc.cc ----
             // No predication: an event that misses is added to the lane's dump slot of the row; idle lanes carry x = 0
-            // (every distance from it exceeds S: list positions start at EV_BIAS), finished lanes park on the sentinel.
+            // (every distance from it exceeds S: list positions start at BIAS), finished lanes park on the sentinel.
             for (u32 b = wave; b < nbF; b += 4) {
                 const u32 i = 64 * b + lane;
                 const u32 ent = i < nF ? LF[i] : 0u;
                 const u32 x = ent & EV_POS, xc = x + c;
-                const u32 flm = (u32)((int32_t)ent >> 31);   // all ones: mappable
+                const u32 flm = HAS_M ? (ent >> 31) << 16 : 0u;   // mappable: the increment of the cc half
                 if (HAS_M && flm) cntB += ev_mbit(MT, xc);   // Bf = sum of M[x + c]
                 u32 r = (ent >> 17) & 0x3ffu;
                 u32 y0 = LR[r], y1 = LR[r + 1];
@@ -464,16 +550,13 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     r = h1 ? r + 2 : nR;
                     y0 = LR[r];
                     y1 = LR[r + 1];
-                    const u32 a0 = h0 ? d0 : dumpN, a1 = h1 ? d1 : dumpN;   // (row cc reaches DUMP_B with the same index)
+                    const u32 a0 = h0 ? d0 : dumpN, a1 = h1 ? d1 : dumpN;
                     if (HAS_M) {
                         const u32 q0 = xc - (h0 ? d0 : 0u), q1 = xc - (h1 ? d1 : 0u);
                         const u32 m0 = MT[q0 >> 5], m1 = MT[q1 >> 5];
-                        if (DO_NCC) {
-                            atomicAdd(&hN[a0], 1u);
-                            atomicAdd(&hN[a1], 1u);
-                        }
-                        atomicAdd(&hC[a0], (m0 >> (q0 & 31u)) & flm & 1u);
-                        atomicAdd(&hC[a1], (m1 >> (q1 & 31u)) & flm & 1u);
+                        // ncc + 1, cc + M[x + c - d] M[x]: one atomic for both
+                        atomicAdd(&hN[a0], (DO_NCC ? 1u : 0u) | (((m0 >> (q0 & 31u)) << 16) & flm));
+                        atomicAdd(&hN[a1], (DO_NCC ? 1u : 0u) | (((m1 >> (q1 & 31u)) << 16) & flm));
                     } else {
                         atomicAdd(&hN[a0], 1u);
                         atomicAdd(&hN[a1], 1u);
@@ -511,12 +594,12 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                     const u32 ee = in ? LE[i] : 0u;
                     const int32_t j = (int32_t)(ee & EV_POS);
                     const u32 sgn = (u32)(((int32_t)ee >> 31) | 1);   // E[j]: -1 falling, +1 rising
-                    const int32_t tile_end = (int32_t)(EV_BIAS + EV_TB);
+                    const int32_t tile_end = (int32_t)(BIAS + EV_TB);
                     // -- forward reads --
                     {
                         const int32_t lo = j - (int32_t)c;
                         const u32 span = in ? S : 0u;
-                        int32_t bb = (lo - (int32_t)EV_BIAS) >> 9;
+                        int32_t bb = (lo - (int32_t)BIAS) >> 9;
                         bb = bb < 0 ? 0 : (bb > 128 ? 128 : bb);
                         u32 idx = (u32)idxF[bb] + wave;
                         u32 e0 = LF[idx], e1 = LF[idx + 4];
@@ -525,8 +608,8 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                             const bool more = (int32_t)u0 < (int32_t)span;   // this lane's entry is still below the end of its range
                             if (!__ballot(more)) break;
                             const bool h0 = u0 < span && (e0 >> 31) != 0, h1 = u1 < span && (e1 >> 31) != 0;
-                            atomicAdd(&hGF[h0 ? u0 + 1 : dumpGF], sgn);
-                            atomicAdd(&hGF[h1 ? u1 + 1 : dumpGF], sgn);
+                            ev_add_cell<BIG>(hGF, h0 ? u0 + 1 : dumpGF, sgn);
+                            ev_add_cell<BIG>(hGF, h1 ? u1 + 1 : dumpGF, sgn);
                             idx = more ? idx + 8 : idx;
                             e0 = LF[idx];
                             e1 = LF[idx + 4];
@@ -540,7 +623,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                         const int32_t full = kind == 0 ? (int32_t)S : 2 * (int32_t)S;
                         sp = sp < full ? sp : full;
                         const u32 span = (in && sp > 0) ? (u32)sp : 0u;
-                        int32_t bb = (lo - (int32_t)EV_BIAS) >> 9;
+                        int32_t bb = (lo - (int32_t)BIAS) >> 9;
                         bb = bb < 0 ? 0 : (bb > 128 ? 128 : bb);
                         u32 idx = (u32)idxR[bb] + wave;
                         u32 p0 = LR[idx], p1 = LR[idx + 4];
@@ -550,15 +633,15 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                             if (!__ballot(more)) break;
                             const bool h0 = u0 < span, h1 = u1 < span;
                             const u32 d0 = kind == 0 ? u0 + 1 : (u0 + 2) >> 1, d1 = kind == 0 ? u1 + 1 : (u1 + 2) >> 1;
-                            const u32 q0 = h0 ? (kind == 0 ? p0 + c - 2 * d0 : p0 - d0 + 1) : EV_BIAS;
-                            const u32 q1 = h1 ? (kind == 0 ? p1 + c - 2 * d1 : p1 - d1 + 1) : EV_BIAS;
+                            const u32 q0 = h0 ? (kind == 0 ? p0 + c - 2 * d0 : p0 - d0 + 1) : BIAS;
+                            const u32 q1 = h1 ? (kind == 0 ? p1 + c - 2 * d1 : p1 - d1 + 1) : BIAS;
                             const u32 m0 = MT[q0 >> 5], m1 = MT[q1 >> 5];
                             idx = more ? idx + 8 : idx;
                             p0 = LR[idx];
                             p1 = LR[idx + 4];
                             // -E[j] M[q]
-                            atomicAdd(&hGR[h0 ? d0 : dumpGR], (0u - sgn) * ((m0 >> (q0 & 31u)) & 1u));
-                            atomicAdd(&hGR[h1 ? d1 : dumpGR], (0u - sgn) * ((m1 >> (q1 & 31u)) & 1u));
+                            ev_add_cell<BIG>(hGR, h0 ? d0 : dumpGR, (0u - sgn) * ((m0 >> (q0 & 31u)) & 1u));
+                            ev_add_cell<BIG>(hGR, h1 ? d1 : dumpGR, (0u - sgn) * ((m1 >> (q1 & 31u)) & 1u));
                         }
                     }
                 }
@@ -568,7 +651,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             // ---- run edges of the tile x the edges within max_lag above them: the mappable-length autocorrelation (also
             // for a tile whose READS went to the window kernel) ----
             if (DO_MLEN && do_edges) {
-                const u32 dumpEE = L::NROWS * 1024 + lane - 4096;
+                const u32 dumpEE = L::o_dump(HN) - L::o_ee(HN) + lane;
                 const u32 nEt = TE0 + TE1;   // the tile's own edges sit at list indices [TXb, TXb + nEt)
                 for (u32 b = (wave + 1) & 3; 64 * b < nEt; b += 4) {
                     const u32 i = 64 * b + lane;
@@ -592,45 +675,101 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         }
         if (EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(0);
         EV_STAMP(7)
-        const bool leaving = jn != ji || gnext >= g1;
-        if (leaving) {
-            // histograms + scalars of this (workgroup, job) -> its slab segment; cleared for the next job
-            __syncthreads();
-            u32 *seg = slab + (size_t)(blockIdx.x + ji) * EV_SEG_ROWS * 1024;
-#pragma nounroll   // (unrolled, its index registers are hoisted out of the tile loop and spill)
-            for (u32 i = tid; i < L::NROWS * 1024; i += 256) {
-                // LDS rows ncc, cc, GF, GR, EE -> segment rows 0, 2, 1, 3, 5
-                const u32 r = i >> 10, sr = r == 1 ? 2u : (r == 2 ? 1u : (r == 4 ? 5u : r));
-                if (r < 4 || DO_MLEN) seg[sr * 1024 + (i & 1023u)] = lds[L::HIST + i];
-                lds[L::HIST + i] = 0;
+        // listed reads since the last flush (uniform over the workgroup: xch was written before B1)
+        if (NSG == 1) {
+            if (!dense) {
+                accF += nF;
+                accR += nRt;
             }
-            // scalars: |F|, |R|, Bf, R0, popcount(M), runs -> row 4 of the segment (two rounds through misc[16])
-            u32 v[6] = {cntF, cntR, cntB, cnt0, cntM, cntU};
+        } else {
 #pragma unroll
-            for (u32 k = 0; k < 6; k++)
-                for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
-#pragma unroll
-            for (u32 round = 0; round < 2; round++) {
-                if (round == 1 && !DO_MLEN) break;
-                if (lane == 0) {
-                    misc[wave] = v[round * 4 + 0];
-                    misc[4 + wave] = v[round * 4 + 1];
-                    if (round == 0) {
-                        misc[8 + wave] = v[2];
-                        misc[12 + wave] = v[3];
+            for (u32 k = 0; k < NSG; k++) {
+                const u32 v = xch[k];
+                accF += v & 0xffffu;
+                accR += v >> 16;
+            }
+            accF = __builtin_amdgcn_readfirstlane(accF);
+            accR = __builtin_amdgcn_readfirstlane(accR);
+        }
+        const bool leaving = jn != ji || gnext >= g1;
+        // another iteration could overflow a 16-bit cell (bounds in the comment of EvLds): flush now
+        const bool risk = HAS_M && (BIG ? (accF + NSG * EV_CAPF > 32767u || 3u * (accR + NSG * EV_CAPR) > 32767u)
+                                        : accF + EV_CAPF > 65535u);
+        if (leaving || risk) {
+            // histograms of this (workgroup, job) -> its slab segment (added to it from the second flush on); cleared
+            __syncthreads();
+            u32 *seg = slab + (size_t)(blockIdx.x + ji) * EV_SEG_ROWS * HN;
+            const bool add = seg_written;
+#pragma nounroll   // (unrolled, its index registers are hoisted out of the tile loop and spill)
+            for (u32 i = gt; i < HN; i += NT) {
+                const u32 w = hN[i];
+                hN[i] = 0;
+                if (HAS_M) {
+                    const u32 lo16 = w & 0xffffu, hi16 = w >> 16;
+                    seg[i] = add ? seg[i] + lo16 : lo16;
+                    seg[2 * HN + i] = add ? seg[2 * HN + i] + hi16 : hi16;
+                } else {
+                    seg[i] = add ? seg[i] + w : w;
+                }
+            }
+            if (HAS_M) {
+                if (BIG) {
+#pragma nounroll
+                    for (u32 i = gt; i < HN; i += NT) {   // rows GF (i < HN / 2) and GR: two cells per dword
+                        const u32 half = HN >> 1, row = i >= half ? 1u : 0u, k = i - row * half;
+                        u32 *src = (row ? hGR : hGF) + k;
+                        const u32 w = *src;
+                        *src = 0;
+                        const int32_t lo16 = (int32_t)(short)(w & 0xffffu);
+                        const int32_t hi16 = (int32_t)(short)((w - (u32)lo16) >> 16);
+                        uint2 *dst = reinterpret_cast<uint2 *>(seg + (size_t)(row ? 3 : 1) * HN + 2 * k);
+                        uint2 v = make_uint2((u32)lo16, (u32)hi16);
+                        if (add) {
+                            const uint2 o = *dst;
+                            v.x += o.x;
+                            v.y += o.y;
+                        }
+                        *dst = v;
+                    }
+                } else {
+#pragma nounroll
+                    for (u32 i = gt; i < (DO_MLEN ? 3u : 2u) * 1024u; i += NT) {
+                        // LDS rows GF, GR, EE -> segment rows 1, 3, 5
+                        const u32 r = i >> 10, k = i & 1023u;
+                        const u32 w = hGF[i];
+                        hGF[i] = 0;
+                        u32 *dst = seg + (size_t)(2 * r + 1) * 1024 + k;
+                        *dst = add ? *dst + w : w;
                     }
                 }
-                __syncthreads();
-                if (tid < (round == 0 ? 4u : 2u))
-                    seg[4 * 1024 + round * 4 + tid] = misc[4 * tid] + misc[4 * tid + 1] + misc[4 * tid + 2] + misc[4 * tid + 3];
-                __syncthreads();
             }
-            cntF = 0;
-            cntR = 0;
-            cntB = 0;
-            cnt0 = 0;
-            cntM = 0;
-            cntU = 0;
+            accF = 0;
+            accR = 0;
+            seg_written = true;
+            if (leaving) {
+                // scalars: |F|, |R|, Bf, R0, popcount(M), runs -> row 4 of the segment
+                u32 v[6] = {cntF, cntR, cntB, cnt0, cntM, cntU};
+#pragma unroll
+                for (u32 k = 0; k < 6; k++)
+                    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+                if ((gt & 63u) == 0) {
+#pragma unroll
+                    for (u32 k = 0; k < 6; k++)
+                        if (k < 4 || DO_MLEN) atomicAdd(&xch[8 + k], v[k]);
+                }
+                __syncthreads();
+                if (gt < 6) {
+                    seg[4 * HN + gt] = xch[8 + gt];
+                    xch[8 + gt] = 0;
+                }
+                cntF = 0;
+                cntR = 0;
+                cntB = 0;
+                cnt0 = 0;
+                cntM = 0;
+                cntU = 0;
+                seg_written = false;
+            }
         }
         ji = jn;
         cur_tile0 = pj.tile0;
@@ -638,9 +777,9 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         g = gnext;
     }
 #ifdef EV_STAMPS
-    if ((tid_ & 63) == 0) {
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(slab + (size_t)(gridDim.x + njobs) * EV_SEG_ROWS * 1024);
-        for (int i = 0; i < EV_NSTAMP; i++) dbg[((size_t)blockIdx.x * 4 + wave) * EV_NSTAMP + i] = stamp_acc[i];
+    if ((gt & 63) == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(slab + (size_t)(gridDim.x + njobs) * EV_SEG_ROWS * HN);
+        for (int i = 0; i < EV_NSTAMP; i++) dbg[((size_t)blockIdx.x * 4 * NSG + (gt >> 6)) * EV_NSTAMP + i] = stamp_acc[i];
     }
 #endif
 }
@@ -664,14 +803,15 @@ struct EvTailPlan {
 __global__ void __launch_bounds__(EV_TAIL_THREADS)
 k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailPlan plan, const u32 *__restrict__ slab_cc,
               const u32 *__restrict__ slab_ac, const u32 *__restrict__ n_flagged, u32 S, u32 out_stride, u32 has_m, u32 do_ncc,
-              u32 max_lag, u32 lagcap, int32_t c, u32 fused)
+              u32 max_lag, u32 lagcap, int32_t c, u32 fused, u32 rowlen, u32 slow_path)
 {
     __shared__ long long part[256];
     __shared__ long long tot[2];
     const u32 job = blockIdx.x, tid = threadIdx.x;
     const SpJobDev &jb = jobs.j[job];
     // blockIdx.y: 0 prefix sums (+ slow path: fsum, rsum), 1 autocorrelation, 2 / 3 slow path only: ncc + read counts / cc
-    const bool flagged = n_flagged[blockIdx.y == 1 ? 1 : 0] != 0;   // [0]: tiles flagged for k_cc_sparse, [1]: for k_autocorr_edges
+    // (slow_path == 0: max_shift > 1023, the window kernel runs in shift chunks behind this kernel and a gated reduce adds its sums)
+    const bool flagged = slow_path && n_flagged[blockIdx.y == 1 ? 1 : 0] != 0;   // [0]: tiles flagged for k_cc_sparse, [1]: for k_autocorr_edges
     if ((blockIdx.y >= 2 && !flagged) || (blockIdx.y == 1 && !fused)) return;
     if (blockIdx.y == 1) {
         if (flagged) {
@@ -701,7 +841,7 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
     if (has_m && blockIdx.y == 0) {
         long long bf = 0, r0 = 0;
         for (u32 w = jb.wg_first + tid; w <= jb.wg_last; w += EV_TAIL_THREADS) {
-            const u32 *sc = slab + (size_t)(w + job) * EV_SEG_ROWS * 1024 + 4 * 1024;
+            const u32 *sc = slab + ((size_t)(w + job) * EV_SEG_ROWS + 4) * rowlen;
             bf += sc[2];
             r0 += sc[3];
         }

@@ -378,11 +378,18 @@ __device__ __forceinline__ void tile_fetch_job(TileRegs &tr, TileRegsX &tx, cons
                                                const unsigned char *__restrict__ flags = nullptr)
 {
     // behind the event kernel only the tiles it flagged as dense are processed: the others read as empty
-    if (!CH && flags && !flags[jb.flag0 + local_tile]) {
+    if (flags && !flags[jb.flag0 + local_tile]) {
         tr.f = make_uint4(0, 0, 0, 0);
         tr.r = tr.f;
         tr.m = tr.f;
         tr.h = tr.f;
+        if (CH) {
+            tx.rw = tr.f;
+            tx.mw = tr.f;
+            tx.md = tr.f;
+            tx.hw = tr.f;
+            tx.hd = tr.f;
+        }
         return;
     }
     // edge tiles (or unaligned vectors) take the guarded loader
@@ -737,7 +744,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             // the unflagged tiles of this chromosome are skipped (pj is still the job of tile g here); the first tile of every
             // chromosome in this workgroup's range is visited whatever its flag, so that its slab segment gets written.
             gnext = g + 1;
-            if (!CH && tile_flags) {
+            if (tile_flags) {
                 const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
                 while (gnext < lim && !tile_flags[pj.flag0 + gnext - pj.tile0]) gnext++;
             }
@@ -1042,9 +1049,11 @@ struct ReduceSpec {
     u32 keep_scalar2;   // scalar [2] (popcount(M)) belongs to the autocorrelation pass, which may run concurrently
     u32 nzero;          // rows of the result block this batch does not produce: written as zeros (chunk 0 only)
     u32 zero_row[5];
+    u32 rowlen;         // u32 per slab row (0: 1024; the event kernel beyond 1023 shifts: its histogram length)
 };
 
-#define RS_NBX 32u   // chunks of 32 elements per row (1024 shifts); a block takes the chunks blockIdx.x, + gridDim.x, ...
+#define RS_NBX 32u   // chunks of 32 elements per row of 1024 shifts (rowlen / 32 in general); a block takes the chunks blockIdx.x, + gridDim.x, ...
+__device__ __forceinline__ u32 rs_rowlen(const ReduceSpec &rs) { return rs.rowlen ? rs.rowlen : 1024u; }
 __device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ slab, const SpJobTable &jobs, u32 seg_rows,
                                                       const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r, u32 bx,
                                                       u64 (*part)[32])   // part[blockDim.x / 32][32]
@@ -1056,11 +1065,12 @@ __device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ sl
     const SpJobDev &jb = jobs.j[job];
     const u32 e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const u32 i = bx * 32 + e;
+    const u32 rowlen = rs_rowlen(rs);
     if (r >= rs.nrows) {   // a row this batch leaves empty
         if ((jb.flags & 1u) && g == 0 && !rs.accumulate) {
             u64 *dst = rs.use_out2 ? jb.out2 + rs.zero_row[r - rs.nrows] : jb.out + (size_t)rs.zero_row[r - rs.nrows] * rs.out_stride;
             const u32 cnt = rs.use_out2 ? (rs.n_override ? rs.n_override : jb.d_n) : rs.out_stride;
-            for (u32 k = i; k < cnt; k += RS_NBX * 32) dst[k] = 0;
+            for (u32 k = i; k < cnt; k += rowlen) dst[k] = 0;
         }
         return;
     }
@@ -1069,8 +1079,8 @@ __device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ sl
     const u32 n = scalar ? 2u : (rs.n_override ? rs.n_override : jb.d_n);
     u64 sum = 0;
     if (i < n && live) {
-        const size_t stride = (size_t)seg_rows * 1024;
-        const u32 *p = slab + (size_t)rs.src_row[r] * 1024 + (scalar ? rs.scalar_off : 0u) + i;
+        const size_t stride = (size_t)seg_rows * rowlen;
+        const u32 *p = slab + (size_t)rs.src_row[r] * rowlen + (scalar ? rs.scalar_off : 0u) + i;
         if (rs.is_signed[r])
             for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += ng) sum += (u64)(long long)(int32_t)p[(size_t)(w + job) * stride];
         else
@@ -1088,7 +1098,7 @@ __device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ sl
         }
     } else if (scalar) {
         u64 *dst = jb.out + (size_t)rs.dst_row[r] * rs.out_stride;
-        for (u32 k = i; k < rs.out_stride; k += RS_NBX * 32) {   // [0],[1] sums, [3] path, everything else zero
+        for (u32 k = i; k < rs.out_stride; k += rowlen) {   // [0],[1] sums, [3] path, everything else zero
             if (k == 2 && rs.keep_scalar2) continue;
             if (rs.accumulate) {
                 if (k < 2) dst[k] += t;
@@ -1106,7 +1116,7 @@ __device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab
                                                     const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r)
 {
     __shared__ u64 part[32][32];   // (blocks of 256 or 1024 threads)
-    for (u32 bx = blockIdx.x; bx < RS_NBX; bx += gridDim.x) {   // (uniform over the block)
+    for (u32 bx = blockIdx.x; bx < rs_rowlen(rs) / 32; bx += gridDim.x) {   // (uniform over the block)
         reduce_segments_chunk(slab, jobs, seg_rows, rs, gate, r, bx, part);
         __syncthreads();
     }
@@ -1912,6 +1922,181 @@ int pmx_events_can_fuse_mlen(uint32_t max_shift, uint32_t max_lag)
     return events_enabled() && fuse && max_shift <= 1023 && max_lag <= 1023;   // one histogram row of 1024 lags
 }
 
+// ---- the event kernel beyond 1023 shifts (BIG instantiations) ----
+struct EvBigPlan {
+    u32 hn, lo, nsg, lds_bytes, wg_per_cu;
+};
+
+static bool events_big_enabled()
+{
+    // PMX_CC_EVENTS_BIG=0 in the environment keeps max_shift > 1023 on the window kernel in shift chunks (A/B, tests)
+    static const bool on = [] {
+        const char *e = getenv("PMX_CC_EVENTS_BIG");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// Geometry of a BIG launch: histogram length, staged M below a tile, and the number of sub-groups per workgroup that puts
+// the most wavefronts on a CU (16 at 128 VGPRs; ties go to the smaller workgroup: more independent phase groups).
+// PMX_EV_NSG=1|2|4 in the environment forces the sub-group count (A/B).
+template <bool HAS_M>
+static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p)
+{
+    typedef EvLds<HAS_M, true> L;
+    const u32 hn = (max_shift + 1 + 127) / 128 * 128;
+    const u32 lo = ((2 * max_shift + 31) / 32 + 3) / 4 * 4;
+    static const int forced = [] {
+        const char *e = getenv("PMX_EV_NSG");
+        return e ? atoi(e) : 0;
+    }();
+    const u32 lds_cu = 160u * 1024u;
+    u32 best_waves = 0;
+    for (u32 nsg = 1; nsg <= 4; nsg *= 2) {
+        if (forced && (u32)forced != nsg) continue;
+        const u32 bytes = L::total(hn, lo, nsg) * 4 + 16;   // + the static stub
+        if (bytes > lds_cu) continue;
+        u32 per_cu = lds_cu / (bytes + 256);                // (allocation granularity)
+        if (per_cu * nsg > 4) per_cu = 4 / nsg;
+        if (per_cu < 1) continue;
+        const u32 waves = per_cu * nsg * 4;
+        if (waves > best_waves) {
+            best_waves = waves;
+            p->hn = hn;
+            p->lo = lo;
+            p->nsg = nsg;
+            p->lds_bytes = bytes - 16;
+            p->wg_per_cu = per_cu;
+        }
+    }
+    return best_waves != 0;
+}
+
+template <bool HAS_M, bool DO_NCC, u32 NSG>
+static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTable &tab, u32 n, u32 total, u32 tpw, u32 nwg, u32 c,
+                         u32 max_shift, u32 nhr, unsigned char *d_flags, u32 *d_nflagged)
+{
+    auto kern = k_cc_events<HAS_M, DO_NCC, false, NSG, true>;
+    static bool attr_set = false;   // (a context is single-threaded; the attribute is per process and device function)
+    if (!attr_set) {
+        PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 64));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256 * NSG), pl.lds_bytes, ctx->stream, tab, n, total, tpw, c, max_shift, nhr, 0u,
+                       pl.hn, pl.lo, ctx->d_slab, d_flags, d_flags, d_nflagged);
+    PMX_CHECK_LAUNCH("k_cc_events (max_shift > 1023)");
+    return PMX_OK;
+}
+
+// max_shift in [1024, EV_MAX_SHIFT]: the event kernel over every chromosome (one pass over the vectors whatever the
+// shift range), then -- for the tiles it flagged as dense only -- the window kernel in chunks of 1024 shifts, whose sums a
+// gated reduce adds to the rows.  The mappable-length pass is not fused here (the caller runs k_autocorr_pairs).
+static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift, uint32_t read_len,
+                                bool do_ncc, uint32_t out_stride, const ReduceSpec &rs, u32 nr, u32 nz)
+{
+    const bool has_m = jobs[0].d_M != nullptr;
+    const u32 c = read_len - 1;
+    EvBigPlan pl;
+    if (!(has_m ? ev_big_plan<true>(max_shift, &pl) : ev_big_plan<false>(max_shift, &pl))) {
+        pmx_set_error("k_cc_events: no launch geometry for max_shift %u", max_shift);
+        return PMX_ERR_INVALID;
+    }
+    std::vector<uint32_t> flag0(njobs);
+    uint64_t total_flags = 0;
+    for (uint32_t i = 0; i < njobs; i++) {
+        flag0[i] = (uint32_t)total_flags;
+        total_flags += (jobs[i].nbits + SP_TB - 1) / SP_TB + EV_NQ;   // padding: an event tile flags EV_NQ window tiles
+    }
+    const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
+    int rc = pmx_ensure_flags_cc(ctx, flag_bytes + 16);
+    if (rc) return rc;
+    unsigned char *d_flags = ctx->d_flags_cc;
+    u32 *d_nflagged = (u32 *)(ctx->d_flags_cc + flag_bytes);
+    PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, flag_bytes + 16, ctx->stream));
+
+    ReduceSpec rs_ev = rs;
+    for (u32 i = 0; i < nr; i++)
+        if (rs.dst_row[i] == PMX_ROW_MSCC_FSUM || rs.dst_row[i] == PMX_ROW_MSCC_RSUM) rs_ev.is_signed[i] = 1;
+    rs_ev.rowlen = pl.hn;
+    const u32 nhr = (max_shift + 1 + 127) / 128;   // quads of R above a tile that hold partners of its forward reads
+    for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS) {
+        const uint32_t n = njobs - lo < SP_MAXJOBS ? njobs - lo : SP_MAXJOBS;
+        std::vector<VJob> ev(n);
+        for (uint32_t i = 0; i < n; i++) {
+            ev[i].job = &jobs[lo + i];
+            ev[i].d_off = 0;
+            ev[i].d_n = max_shift + 1;
+            ev[i].flag0 = flag0[lo + i];
+        }
+        SpJobTable tab;
+        memset(&tab, 0, sizeof tab);
+        uint32_t total, tpw, nwg;
+        plan_launch(ctx, ev.data(), n, false, pl.wg_per_cu, &tab, &total, &tpw, &nwg, EV_TB);
+        rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * EV_SEG_ROWS * pl.hn + (size_t)nwg * 4 * pl.nsg * 12 * 2 + 64);
+        if (rc) return rc;
+        pmx_timed_launch tl;
+        rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_EVENTS, &tl);
+        if (rc) return rc;
+#define EVB(HM, NC)                                                                                                         \
+    (pl.nsg == 1   ? ev_big_launch<HM, NC, 1>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged)     \
+     : pl.nsg == 2 ? ev_big_launch<HM, NC, 2>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged)     \
+                   : ev_big_launch<HM, NC, 4>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged))
+        rc = has_m ? (do_ncc ? EVB(true, true) : EVB(true, false)) : EVB(false, true);
+#undef EVB
+        if (rc) return rc;
+        rc = pmx_prof_end(ctx, &tl);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream,
+                           (const u32 *)ctx->d_slab, tab, (u32)EV_SEG_ROWS, rs_ev, (const u32 *)nullptr);
+        PMX_CHECK_LAUNCH("k_reduce_segments");
+        if (has_m) {
+            EvTailPlan tp;
+            memset(&tp, 0, sizeof tp);
+            hipLaunchKernelGGL(k_events_tail, dim3(n, 1), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
+                               (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)d_nflagged, max_shift, out_stride, 1u,
+                               do_ncc ? 1u : 0u, 0u, 1024u, (int32_t)c, 0u, pl.hn, 0u);
+            PMX_CHECK_LAUNCH("k_events_tail");
+        }
+    }
+    // the flagged tiles: window kernel per (chromosome, chunk of 1024 shifts); nothing flagged: every launch returns at once
+    std::vector<VJob> vjobs;
+    expand_chunks(jobs, njobs, max_shift + 1, vjobs, flag0.data());
+    ReduceSpec rs_w = rs;
+    rs_w.accumulate = 1;
+    for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS) {
+        const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS ? vjobs.size() - lo : SP_MAXJOBS);
+        SpJobTable tabW;
+        memset(&tabW, 0, sizeof tabW);
+        uint32_t total, tpw, nwg;
+        plan_launch(ctx, &vjobs[lo], n, false, has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC, &tabW, &total, &tpw, &nwg);
+        rc = pmx_ensure_slab_fb(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
+        if (rc) return rc;
+        pmx_timed_launch tl;
+        rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, true);
+        if (rc) return rc;
+#define SP_LAUNCH(HM, NC)                                                                                              \
+    hipLaunchKernelGGL((k_cc_sparse<HM, NC, true>), dim3(nwg), dim3(256), 0, ctx->stream, tabW, n, total, tpw, (int32_t)c, 5u, \
+                       ctx->d_slab_fb, (const unsigned char *)d_flags, (const u32 *)d_nflagged)
+        if (has_m && do_ncc) SP_LAUNCH(true, true);
+        else if (has_m) SP_LAUNCH(true, false);
+        else SP_LAUNCH(false, true);
+#undef SP_LAUNCH
+        PMX_CHECK_LAUNCH("k_cc_sparse");
+        rc = pmx_prof_end(ctx, &tl);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab_fb, tabW,
+                           (u32)SP_SEG_ROWS, rs_w, (const u32 *)d_nflagged);
+        PMX_CHECK_LAUNCH("k_reduce_segments");
+    }
+    return PMX_OK;
+}
+
+int pmx_events_take_big(uint32_t max_shift)
+{
+    return max_shift > 1023 && max_shift <= EV_MAX_SHIFT && events_enabled() && events_big_enabled();
+}
+
 int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
                                uint32_t read_len, bool do_ncc, uint32_t out_stride, bool zero_mlen,
                                uint32_t fused_lag, pmx_fused_mlen *fused)
@@ -1921,8 +2106,6 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     const bool has_m = jobs[0].d_M != nullptr;
     if (!has_m && !do_ncc) return PMX_OK;
     const bool chunked = max_shift > 1023;
-    std::vector<VJob> vjobs;
-    expand_chunks(jobs, njobs, max_shift + 1, vjobs);
     const int32_t c = (int32_t)read_len - 1;
     const u32 lgG = chunked ? 5u : lg_slot_lanes(max_shift + 1);
 
@@ -1948,6 +2131,12 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     rs.out_stride = out_stride;
     rs.use_out2 = 0;
     rs.keep_scalar2 = (has_m && !zero_mlen) ? 1 : 0;
+
+    if (!ctx->window_only && pmx_events_take_big(max_shift))
+        return launch_cc_events_big(ctx, jobs, njobs, max_shift, read_len, do_ncc, out_stride, rs, nr, nz);
+
+    std::vector<VJob> vjobs;
+    expand_chunks(jobs, njobs, max_shift + 1, vjobs);
 
     // Pass 1 (sparse tiles): the event kernel over every chromosome; tiles whose lists would overflow are flagged.
     const bool use_events = events_enabled() && !ctx->window_only && !chunked;
@@ -1988,8 +2177,8 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             if (rc) return rc;
             const u32 nhr = (max_shift + 1 + 127) / 128;   // quads of R above a tile that hold partners of its forward reads
 #define EV_LAUNCH(HM, NC, ML)                                                                                          \
-    hipLaunchKernelGGL((k_cc_events<HM, NC, ML>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, (u32)c,     \
-                       max_shift, nhr, fused_lag, ctx->d_slab, d_flags, d_flags_ac, d_nflagged)
+    hipLaunchKernelGGL((k_cc_events<HM, NC, ML, 1, false>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, (u32)c, \
+                       max_shift, nhr, fused_lag, 1024u, (u32)EV_LO, ctx->d_slab, d_flags, d_flags_ac, d_nflagged)
             if (has_m && do_ncc && fuse_mlen) EV_LAUNCH(true, true, true);
             else if (has_m && do_ncc) EV_LAUNCH(true, true, false);
             else if (has_m && fuse_mlen) EV_LAUNCH(true, false, true);
@@ -2091,7 +2280,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         }
         hipLaunchKernelGGL(k_events_tail, dim3(n, 4), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
                            (const u32 *)ctx->d_slab_fb, (const u32 *)ctx->d_slab_ac, (const u32 *)d_nflagged, max_shift, out_stride,
-                           has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c, fuse_mlen ? 1u : 0u);
+                           has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c, fuse_mlen ? 1u : 0u, 1024u, 1u);
         PMX_CHECK_LAUNCH("k_events_tail");
     }
     return PMX_OK;

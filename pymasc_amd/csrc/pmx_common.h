@@ -114,6 +114,8 @@ struct pmx_fused_mlen {
 int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len);
 // the event kernel can also take the edge pairs of the mappable-length pass for this geometry (and is not disabled)
 int pmx_events_can_fuse_mlen(uint32_t max_shift, uint32_t max_lag);
+// the event kernel (not the window kernel in shift chunks) takes this max_shift > 1023
+int pmx_events_take_big(uint32_t max_shift);
 uint32_t pmx_sparse_max_jobs(void);
 // Writes rows NCC_CCBINS / MSCC_FSUM / MSCC_CCBINS / MSCC_RSUM and the scalar row of every job's result block
 // (rows the batch does not produce are written as zeros, MLEN included when there is no mappability).
