@@ -55,16 +55,18 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(ctx, vecs, S, L, with_m, sample_bp, threads):
+def cpu_baseline(ctx, vecs, S, L, with_m, sample_bp, threads, budget_s=14.0):
     """Times the oracle (C restatement of the reference's per-shift full-vector passes) on host cores:
-    one chromosome slice per thread, like `pymasc -p <threads>`.  kind = "port"."""
+    one chromosome slice per thread, like `pymasc -p <threads>` (threads = the cores this process
+    may run on).  The sample is bounded by wall-clock: a short calibration slice on one thread sets the slice length so
+    that the threaded run takes about `budget_s` seconds.  kind = "port"."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import model as oracle
     oracle.lib()
-    slices = []
-    for i in range(threads):
+
+    def make_slice(i, bp):
         v = vecs[i % len(vecs)]
-        nb = int(min(v.length, sample_bp)) + L + S + 100
+        nb = int(min(v.length, bp)) + L + S + 100
         nw = (nb + 63) // 64
         F = ctx.bits_download(v.F.data_ptr(), nb)[:nw].copy()
         R = ctx.bits_download(v.R.data_ptr(), nb)[:nw].copy()
@@ -76,23 +78,55 @@ def cpu_baseline(ctx, vecs, S, L, with_m, sample_bp, threads):
             R[-1] &= mask
             if M is not None:
                 M[-1] &= mask
-        slices.append((F, R, M, nb, nb - (L + S + 100)))
+        return (F, R, M, nb, nb - (L + S + 100))
+
+    # calibration: one small slice alone on one core (also the 1-thread figure SURVEY 8d asks for)
+    s0 = make_slice(0, min(sample_bp, 8e6))
+    t1 = time.perf_counter()
+    oracle.calc_correlation(s0[0], s0[1], s0[2], s0[3], S, L)
+    dt1 = time.perf_counter() - t1
+    one_thread = (S + 1) * s0[4] / dt1
+    # all threads run one slice each at the same time: the wall time is one slice's (memory bandwidth permitting,
+    # assume half the single-thread rate under load)
+    slice_bp = min(sample_bp, max(1e6, 0.5 * one_thread / (S + 1) * budget_s))
+    slices = [make_slice(i, slice_bp) for i in range(threads)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=threads) as ex:
         list(ex.map(lambda s: oracle.calc_correlation(s[0], s[1], s[2], s[3], S, L), slices))
     dt = time.perf_counter() - t0
     work = (S + 1) * sum(s[4] for s in slices)
-    # one slice alone on one core (SURVEY 8d asks for the 1-thread figure as well)
-    t1 = time.perf_counter()
-    s0 = slices[0]
-    oracle.calc_correlation(s0[0], s0[1], s0[2], s0[3], S, L)
-    dt1 = time.perf_counter() - t1
     return {"value": work / dt, "unit": "shifts*bp/s", "cores": threads, "kind": "port", "sampled": True,
-            "cpu_model": cpu_model(),
-            "one_thread_value": (S + 1) * s0[4] / dt1,
+            "cpu_model": cpu_model(), "nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+            "cgroup_cpu_quota": usable_cores()[1],
+            "compiler": "gcc " + " ".join(oracle.ORACLE_CFLAGS) + " oracle/cc_oracle.c",
+            "one_thread_value": one_thread,
             "sample": f"SAMPLE, not the whole genome: {threads} slices x {slices[0][4] / 1e6:.1f} Mbp of the same synthetic chromosomes, "
-                      f"{'NCC+MSCC' if with_m else 'NCC'}, max_shift={S}, one slice per thread, {dt:.1f}s wall",
+                      f"{'NCC+MSCC' if with_m else 'NCC'}, max_shift={S}, one slice per thread on the {threads} cores this "
+                      f"process may use (nproc {os.cpu_count()}), {dt:.1f}s wall",
             "seconds": dt}
+
+
+def usable_cores():
+    """Cores this process may use: its affinity mask, cut by the cgroup's CPU quota where one is set (a GPU box hands a
+    job a share of the host: threads beyond the quota only time-slice)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
 
 
 def cpu_model():
@@ -387,7 +421,8 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+        cores, quota = usable_cores()
+        threads = args.cpu_threads or cores    # `-p <ncores>` = every core this process may use
         result["cpu_baseline"] = cpu_baseline(ctx, vecs, S, L, with_m, args.cpu_sample_mbp * 1e6, threads)
         result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
     else:

@@ -160,6 +160,10 @@ const char *pmx_kernel_name(int kernel_id);
  * output staging) and the LDS of every CU (bit 8) with `pattern`, so that a kernel reading memory it has not written
  * fails deterministically.  No effect on results. */
 int pmx_debug_poison(pmx_ctx *ctx, uint32_t pattern, uint32_t mask);
+/* Caps the number of persistent workgroups of every later launch (0: no cap), so that a small test input gives each
+ * workgroup many tiles: the paths that depend on a workgroup's tile count (histogram flushes before a 16-bit cell can
+ * overflow, job changes inside a range) are then checked against the oracle at sizes it finishes.  No effect on results. */
+int pmx_debug_set_max_workgroups(pmx_ctx *ctx, uint32_t n);
 /* Copies `bytes` from byte offset `off` of the event / window kernels' slab to host memory (phase stamps of the
  * diagnostic builds -DEV_STAMPS / -DSP_STAMPS). */
 int pmx_debug_read_slab(pmx_ctx *ctx, uint64_t off, void *dst, uint64_t bytes);

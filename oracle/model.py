@@ -40,10 +40,13 @@ class OracleReadUnsortedError(IndexError):
     """Restates PyMaSC/core/exceptions.py:4 (ReadUnsortedError(IndexError))."""
 
 
+ORACLE_CFLAGS = ["-O3", "-mpopcnt", "-fPIC", "-shared"]     # reported by bench.py's cpu_baseline
+
+
 def build_oracle_lib(force: bool = False) -> str:
     src = os.path.join(_HERE, "cc_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O3", "-mpopcnt", "-fPIC", "-shared", "-o", _LIB_PATH, src])
+        subprocess.check_call(["gcc", *ORACLE_CFLAGS, "-o", _LIB_PATH, src])
     return _LIB_PATH
 
 

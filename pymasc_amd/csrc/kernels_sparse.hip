@@ -1874,6 +1874,7 @@ static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr,
         t += (u32)nt;
     }
     uint64_t want = (uint64_t)ctx->num_cus * wg_per_cu;
+    if (ctx->debug_max_wg && want > ctx->debug_max_wg) want = ctx->debug_max_wg;   // (tests: pmx_debug_set_max_workgroups)
     if (want > t) want = t;
     if (want < 1) want = 1;
     const uint32_t tpw = (uint32_t)((t + want - 1) / want);

@@ -67,6 +67,7 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->profiling = 0;
     ctx->window_only = false;
+    ctx->debug_max_wg = 0;
     ctx->d_scratch = nullptr;
     ctx->scratch_words = 0;
     ctx->d_slab = nullptr;
@@ -424,6 +425,13 @@ int pmx_debug_poison(pmx_ctx *ctx, uint32_t pattern, uint32_t mask)
         PMX_CHECK_LAUNCH("k_debug_poison_lds");
     }
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+int pmx_debug_set_max_workgroups(pmx_ctx *ctx, uint32_t n)
+{
+    REQUIRE(ctx, "pmx_debug_set_max_workgroups: ctx is NULL");
+    ctx->debug_max_wg = n;
     return PMX_OK;
 }
 

@@ -46,7 +46,7 @@ EXPORTS = [
     "pmx_bits_count",
     "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
     "pmx_ctx_set_profiling", "pmx_ctx_reset_kernel_times", "pmx_ctx_kernel_time", "pmx_kernel_name",
-    "pmx_debug_poison", "pmx_debug_read_slab",
+    "pmx_debug_poison", "pmx_debug_read_slab", "pmx_debug_set_max_workgroups",
 ]
 
 
@@ -98,6 +98,7 @@ def load_library(path: Optional[str] = None):
     L.pmx_kernel_name.argtypes = [i32]
     L.pmx_debug_poison.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32]
     L.pmx_debug_read_slab.argtypes = [vp, u64, vp, u64]
+    L.pmx_debug_set_max_workgroups.argtypes = [vp, ctypes.c_uint32]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("pmx_version",):
@@ -260,6 +261,10 @@ class Context:
         """Diagnostic: fill the context's scratch buffers (mask bits 0-7) and the LDS of every CU (bit 8) with a byte /
         dword pattern, so that a kernel reading memory it has not written fails deterministically (tests, fuzz)."""
         _check(self._L, self._L.pmx_debug_poison(self._h, int(pattern) & 0xffffffff, int(mask)))
+
+    def debug_set_max_workgroups(self, n: int) -> None:
+        """Diagnostic: cap the persistent workgroups of later launches (0: off), see include/pymasc_amd.h."""
+        _check(self._L, self._L.pmx_debug_set_max_workgroups(self._h, int(n)))
 
     def kernel_name(self, kernel_id: int) -> str:
         return self._L.pmx_kernel_name(int(kernel_id)).decode()

@@ -28,6 +28,8 @@ def draw_case(rng):
     S = int(rng.choice([3, 4, 31, 32, 33, 63, 64, 100, 300, 511, 512, 1000, 1023, 1024, 1025, 2047, 2048, 3000, 5000]))
     if kind == 0:
         S = int(rng.integers(3, 6000))
+    if kind == 3:
+        S = int(rng.integers(1024, 8193))       # the event kernel's range beyond 1023 shifts, and the first shift past it
     L = int(rng.choice([1, 2, 20, 36, 50, 100, 151, 250, 1000, 1024, 1025, 1500]))
     if kind == 1:
         L = int(rng.integers(1, 1025))
