@@ -47,7 +47,14 @@ def parse():
     ap.add_argument("--mode", choices=["both", "ncc"], default="both",
                     help="both = NCC + MaSC with mappability (config 4); ncc = naive CC only (config 2 shape)")
     ap.add_argument("--path", choices=["auto", "dense", "sparse"], default="auto")
+    ap.add_argument("--track", choices=["synthetic", "fixture"], default="synthetic",
+                    help="mappability track: synthetic = BASELINE.md's geometric runs (mean 2000 on / 500 off); fixture = run "
+                         "and gap lengths sampled from the reference's test track hg19_36mer-test.bedGraph (860 run edges "
+                         "per 64 Kbit, 23 %% mappable: the only real-track statistics available offline), tiled to the genome")
     ap.add_argument("--chroms", type=int, default=24, help="use only the first K hg38 chromosomes (debug)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="one rank only: initialise a 1-rank process group and run the exchange through its collectives "
+                         "(RCCL all_gather_into_tensor + all_reduce on the second stream) instead of the local shortcut")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mbp", type=float, default=128.0, help="bp per CPU-baseline slice, in Mbp")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -139,20 +146,45 @@ def cpu_model():
     return "unknown"
 
 
-def pipe_utilisation(kernel, default_workload):
-    """Measured VALU-issue / LDS-pipe utilisation of the dominant kernel from the committed PMC summary
-    (tools/tools_pmc_summary.py -> profiles/r2_pmc_summary.json: rocprofv3 --pmc passes of this same command).
-    Only valid for the workload it was collected on."""
-    if not default_workload:
-        return None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_summary.json")))
-        k = prof["kernels"][kernel.split("+")[0]]
-        return {"valu_issue": k["valu_issue_util"], "lds_pipe": k["lds_pipe_util"],
-                "wave_cycles_issuing": k.get("wave_cycles_issuing"), "wave_cycles_waiting": k.get("wave_cycles_waiting"),
-                "source": "profiles/r2_pmc_summary.json (" + prof.get("how", "rocprofv3 --pmc") + ")"}
-    except Exception:
-        return None
+PROFILE_ROUND = "r3"
+
+
+def committed_profile(name, workload_tag):
+    """A counter summary under profiles/ (tools/tools_r3_profile.sh), or (None, reason).  The summaries name the build
+    (pmx_build_id: hash of pymasc_amd/csrc + the header) and the bench workload they were measured on; they are quoted only
+    for that build and that workload, so a kernel edit cannot leave stale HBM bytes or pipe utilisation in the line."""
+    from pymasc_amd import ffi
+    import glob
+    why = f"no profiles/{PROFILE_ROUND}_{name}*.json"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}*.json"))):
+        rel = os.path.relpath(path, ROOT)
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if prof.get("workload") != workload_tag:
+            if why.startswith("no "):
+                why = f"no profiles/{PROFILE_ROUND}_{name}*.json for workload '{workload_tag}'"
+            continue
+        if prof.get("build_id") != ffi.build_id():
+            why = f"{rel} was measured on build {prof.get('build_id')}, the loaded library is build {ffi.build_id()}"
+            continue
+        return prof, rel
+    return None, why
+
+
+def pipe_utilisation(kernel, workload_tag):
+    """Measured VALU-issue / LDS-pipe utilisation of the dominant kernel (rocprofv3 --pmc passes of this same command)."""
+    prof, why = committed_profile("pmc_summary", workload_tag)
+    if prof is None:
+        return {"valu_issue": None, "lds_pipe": None, "source": None, "reason": why}
+    k = prof["kernels"].get(kernel.split("+")[0])
+    if not k:
+        return {"valu_issue": None, "lds_pipe": None, "source": None, "reason": f"{why} holds no entry for {kernel}"}
+    return {"valu_issue": k["valu_issue_util"], "lds_pipe": k["lds_pipe_util"],
+            "lds_bank_conflict_frac": k.get("lds_bank_conflict_frac"),
+            "wave_cycles_issuing": k.get("wave_cycles_issuing"), "wave_cycles_waiting": k.get("wave_cycles_waiting"),
+            "source": why + " (" + prof.get("how", "rocprofv3 --pmc") + ")", "build_id": prof.get("build_id")}
 
 
 def main():
@@ -161,7 +193,9 @@ def main():
     if launch.needs_spawn(args.gpus):
         # `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything touches the GPU
         # (fresh child processes, the reference's `-p N`: handler/calc.py:163-192); rank 0 prints the JSON line
-        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        # (a rank that hangs in a collective must not hang the launcher for ever: a generous limit, exit code 124)
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                    timeout=float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "1500"))))
 
     import torch
     import torch.distributed as dist
@@ -186,6 +220,10 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    elif args.force_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": device} if backend == "nccl" else {}))
 
     stress = args.workload == "stress"
     strong = stress or args.scaling == "strong"
@@ -221,7 +259,7 @@ def main():
         s, i = jobs[j]
         name, length = chroms[i]
         vecs.append(synth.make_chromosome(ctx, device, f"{name}.s{s}", length, S, L, 0xC0FFEE + i + 1000 * s,
-                                          density=args.density, with_m=with_m, keep_host=e2e))
+                                          density=args.density, with_m=with_m, keep_host=e2e, track=args.track))
     t_gen = time.perf_counter() - t_gen
     total_bp = sum(costs)
 
@@ -238,9 +276,10 @@ def main():
     nstep = [0]
 
     # the hint the calculator gives from the read counts it holds (pymasc_amd/calculator.py: DENSE_READS_PER_BP)
-    from pymasc_amd.calculator import DENSE_READS_PER_BP
+    from pymasc_amd.calculator import DENSE_READS_PER_BP, DENSE_RUNS_PER_BP
     dense_reads = bool(vecs) and max(max(v.n_forward, v.n_reverse) / max(v.length, 1) for v in vecs) > DENSE_READS_PER_BP
-    step_flags = flags | (ffi.PMX_FLAG_WINDOW_ONLY if dense_reads and args.path == "auto" else 0)
+    dense_runs = bool(vecs) and with_m and max(v.n_runs / max(v.length, 1) for v in vecs) > DENSE_RUNS_PER_BP
+    step_flags = flags | (ffi.PMX_FLAG_WINDOW_ONLY if (dense_reads or dense_runs) and args.path == "auto" else 0)
 
     def step():
         # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev) on tstream, then the exchange
@@ -257,7 +296,7 @@ def main():
             if world > 1 and backend != "nccl":
                 out = sharding.exchange_results(d_rows[b].cpu(), assignment, len(jobs))
             else:
-                out = sharding.exchange_results(d_rows[b], assignment, len(jobs))
+                out = sharding.exchange_results(d_rows[b], assignment, len(jobs), force_collectives=args.force_collectives)
             ev_free[b].record(xstream)
         return out
 
@@ -315,21 +354,22 @@ def main():
     kernel_ms_per_step = {ctx.kernel_name(k): round(ktimes[k][0] / args.steps, 4) for k in ktimes if ktimes[k][1]}
 
     # HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
-    # rocprofv3 passes of this same command: tools_profile.sh -> profiles/r2_traffic.json); only valid for the
-    # default single-GPU workload it was collected on
-    default_workload = (world == 1 and not stress and args.chroms == 24 and args.density == 0.005 and S == 1000
-                        and L == 36 and with_m and args.path == "auto")
+    # rocprofv3 passes of this same command: tools/tools_r3_profile.sh -> profiles/r3_traffic*.json).  Quoted only when
+    # the summary was measured on THIS build of the library and on this workload.
+    workload_tag = (f"{args.workload}/{args.mode}/S{S}/L{L}/rho{args.density}/chroms{len(chroms)}/path{args.path}/"
+                    f"track{args.track}/gpus{world}")
     traffic, traffic_src = None, None
-    try:
-        if default_workload:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
-            key = {ffi.PMX_KERNEL_CC_SPARSE: "k_cc_sparse", ffi.PMX_KERNEL_AUTOCORR: "k_autocorr_pairs",
-                   ffi.PMX_KERNEL_CC_EVENTS: "k_cc_events"}.get(dom)
-            if key:
-                traffic = prof["mode_both"][key]["hbm_bytes"]
-                traffic_src = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-    except Exception:
-        traffic, traffic_src = None, None
+    prof, why = committed_profile("traffic", workload_tag)
+    if prof is not None:
+        key = {ffi.PMX_KERNEL_CC_SPARSE: "k_cc_sparse", ffi.PMX_KERNEL_AUTOCORR: "k_autocorr_pairs",
+               ffi.PMX_KERNEL_CC_EVENTS: "k_cc_events"}.get(dom)
+        if key in prof.get("kernels", {}):
+            traffic = prof["kernels"][key]["hbm_bytes"]
+            traffic_src = why + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; build " + prof["build_id"] + ")"
+        else:
+            traffic_src = f"{why} holds no entry for {key}"
+    else:
+        traffic_src = why
 
     work_per_step = (S + 1) * total_bp
     value = work_per_step * args.steps / elapsed
@@ -388,14 +428,19 @@ def main():
                          + ("+mappability" if with_m else "") + f" bit-vectors, {len(chroms)} chromosomes x "
                          f"{nsamples} genome(s), {total_bp / 1e9:.3f} Gbp total, max_shift={S}, read_len={L}, "
                          f"read density {args.density}/strand, "
+                         + ("" if args.track == "synthetic" or not with_m else
+                            "mappability runs and gaps sampled from the reference's test track hg19_36mer-test.bedGraph "
+                            "(860 run edges per 64 Kbit, 23 % mappable), ")
                          + ("NCC+MSCC" if with_m else "NCC only")
                          + ("" if stress else
                             "; stands in for ENCFF000VPI.bam (configs 2-3), which is not available offline")),
             "mode": args.mode,
             "kernel_path": args.path,
             "parallelism": f"chromosome jobs of {nsamples} genome(s) LPT-sharded over {world} GPU(s), one process per "
-                           "GPU; all-gather rows + all-reduce totals on a second stream",
+                           "GPU; all-gather rows + all-reduce totals on a second stream"
+                           + (" (1-rank RCCL group, collectives forced)" if args.force_collectives and world == 1 else ""),
             "inputs_resident_in_hbm": True,
+            "workload_tag": workload_tag,
         },
         "roofline": {
             "bound": "hbm",
@@ -410,7 +455,8 @@ def main():
             "launches": dom_n,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
         },
-        "pipe_utilisation": pipe_utilisation(ctx.kernel_name(dom), default_workload),
+        "pipe_utilisation": pipe_utilisation(ctx.kernel_name(dom), workload_tag),
+        "build_id": ffi.build_id(),
         # HIP-event durations per step.  k_cc_events takes the sparse tiles (and the run-edge pairs of the mappable-length
         # pass); k_cc_sparse / k_autocorr_pairs+edges are the window kernels, which only see the tiles it flagged as dense
         # (none on this workload: their figure is an empty launch) -- or everything when max_shift > 1023
@@ -431,7 +477,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     ctx.close()
-    if world > 1:
+    if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 
 

@@ -77,6 +77,9 @@ typedef struct pmx_ctx pmx_ctx;
 /* ---- library / context ------------------------------------------------------------------- */
 const char *pmx_last_error(void);
 int pmx_version(void);
+/* sha256 (16 hex digits) of the sources this library was built from (pymasc_amd/build.py: source_hash): the profile
+ * summaries under profiles/ name the build they were measured on, bench.py quotes them only for that build. */
+const char *pmx_build_id(void);
 int pmx_device_count(int *n);
 
 /* One context per worker process / per GPU (replaces nothing in the reference: it owns the HIP

@@ -17,6 +17,19 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources libpymasc_hip.so is built from.  build() compiles it into the library
+    (pmx_build_id), and the profile summaries under profiles/ carry the hash of the build they were measured on, so that
+    bench.py only quotes counters that belong to the library it loaded."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "pymasc_amd.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -33,7 +46,7 @@ def build(force=False, verbose=False, extra_flags=()):
     # default "Iterative" strategy serialises over the active lanes with a scalar loop (~2k cycles per atomic).
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP",
-           "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB] + sources()
+           "-Wall", "-Wno-unused-function", '-DPMX_SRC_SHA16="%s"' % source_hash(), *extra_flags, "-o", LIB] + sources()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

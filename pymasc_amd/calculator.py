@@ -167,7 +167,7 @@ class CCHipCalculator:
         self._fwd.n = 0
         self._rev.n = 0
 
-    def _check_pos(self, chrom: str, pos: int):
+    def _check_pos(self, chrom: str, pos: int, bit: Optional[int] = None, what: str = ""):
         if chrom != self._chr:
             if self._chr != "":
                 if chrom in self._solved_chr:
@@ -177,19 +177,29 @@ class CCHipCalculator:
                 self._buff_flashed = False
             self._chr = chrom
             self._init_buff()
+            self._cur_nbits = self.ref2genomelen[chrom] + self._array_extend_size   # mscc.pyx:165-167
             self._logging_info("Loading {} reads to bit array...".format(chrom))
+        if bit is not None:
+            self._check_bit(chrom, bit, what)
         if pos < self._last_pos:
             raise ReadUnsortedError
         self._last_pos = pos
 
+    def _check_bit(self, chrom: str, bit: int, what: str):
+        """The reference sets bit_array[bit] unchecked (bitarray.pyx:72-79: undefined beyond the array); here a read whose
+        bit falls outside the chromosome's vector is refused when it is fed, before anything is queued for the GPU."""
+        if bit < 0 or bit >= self._cur_nbits:
+            raise IndexError("{} read beyond the bit array of {} (position {}, {} bits)".format(
+                what, chrom, bit, self._cur_nbits))
+
     def feed_forward_read(self, chrom: str, pos: int, readlen: int) -> None:
         """1-based 5' position of a forward read (mscc.pyx:370-393)."""
-        self._check_pos(chrom, pos)
+        self._check_pos(chrom, pos, pos, "forward")
         self._fwd.append(pos, readlen)
 
     def feed_reverse_read(self, chrom: str, pos: int, readlen: int) -> None:
         """1-based leftmost position of a reverse read; its bit is pos + readlen - 1 (mscc.pyx:397-418)."""
-        self._check_pos(chrom, pos)
+        self._check_pos(chrom, pos, pos + readlen - 1, "reverse")
         self._rev.append(pos, readlen)
 
     def feed_reads(self, chrom: str, pos: np.ndarray, readlen: np.ndarray, is_reverse: np.ndarray) -> None:
@@ -203,8 +213,15 @@ class CCHipCalculator:
         self._check_pos(chrom, int(pos[0]))
         if pos.size > 1 and (np.diff(pos) < 0).any():
             raise ReadUnsortedError
+        fpos, rbit = pos[~is_reverse], pos[is_reverse] + readlen[is_reverse] - 1
+        if fpos.size:
+            self._check_bit(chrom, int(fpos.min()), "forward")
+            self._check_bit(chrom, int(fpos.max()), "forward")
+        if rbit.size:
+            self._check_bit(chrom, int(rbit.min()), "reverse")
+            self._check_bit(chrom, int(rbit.max()), "reverse")
         self._last_pos = int(pos[-1])
-        self._fwd.extend(pos[~is_reverse], readlen[~is_reverse])
+        self._fwd.extend(fpos, readlen[~is_reverse])
         self._rev.extend(pos[is_reverse], readlen[is_reverse])
 
     # ---- per-chromosome calculation ---------------------------------------------------------------

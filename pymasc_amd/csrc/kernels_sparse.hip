@@ -2352,6 +2352,14 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
             pmx_timed_launch tl;
             rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
             if (rc) return rc;
+            if (lds_bytes > 64 * 1024) {   // (max_lag above ~7870: the histograms alone pass 64 KB)
+                static bool attr_set = false;
+                if (!attr_set) {
+                    PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_autocorr_pairs),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                    attr_set = true;
+                }
+            }
             hipLaunchKernelGGL(k_autocorr_pairs, dim3(nwg), dim3(256), lds_bytes, ctx->stream, tab, n, total, tpw, max_lag, nl,
                                nh, ctx->d_slab2, d_flags, d_nflagged);
             PMX_CHECK_LAUNCH("k_autocorr_pairs");

@@ -31,6 +31,10 @@ extern "C" {
 
 const char *pmx_last_error(void) { return g_err; }
 int pmx_version(void) { return 100; }
+#ifndef PMX_SRC_SHA16
+#define PMX_SRC_SHA16 "unknown"
+#endif
+const char *pmx_build_id(void) { return PMX_SRC_SHA16; }
 
 int pmx_device_count(int *n)
 {
@@ -760,6 +764,8 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             }
             continue;
         }
+        bool forked = false;
+        rc = PMX_OK;
         if (do_mlen && !fork) {
             rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
             if (rc) return rc;
@@ -769,17 +775,30 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             hipStream_t main_stream = ctx->stream;
             ctx->stream = ctx->aux_stream;       // the launchers enqueue on ctx->stream (a context is single-threaded)
             rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
-            hipError_t er = rc ? hipSuccess : hipEventRecord(ctx->ev_join, ctx->aux_stream);
             ctx->stream = main_stream;
-            if (rc) return rc;
-            if (er != hipSuccess) {
-                pmx_set_error("hipEventRecord(ev_join) failed: %s", hipGetErrorString(er));
+            forked = true;
+        }
+        // Whatever was queued on the auxiliary stream (possibly a partial chain after an error) writes the context's
+        // scratch: the caller's stream waits for it on EVERY exit from here on, so that no later call can race with it.
+        auto join = [&]() -> hipError_t {
+            hipError_t er = hipEventRecord(ctx->ev_join, ctx->aux_stream);
+            if (er == hipSuccess) er = hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+            if (er != hipSuccess) (void)hipStreamSynchronize(ctx->aux_stream);
+            return er;
+        };
+        if (rc) {
+            if (forked) (void)join();
+            return rc;
+        }
+        rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, !do_mlen);
+        if (forked) {
+            const hipError_t er = join();
+            if (!rc && er != hipSuccess) {
+                pmx_set_error("join of the mappable-length pass failed: %s", hipGetErrorString(er));
                 return PMX_ERR_HIP;
             }
         }
-        rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, !do_mlen);
         if (rc) return rc;
-        if (do_mlen && fork) PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join
     }
     return PMX_OK;
 }

@@ -39,7 +39,7 @@ PMX_KERNEL_COUNT = 4
 
 # every symbol include/pymasc_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "pmx_last_error", "pmx_version", "pmx_device_count",
+    "pmx_last_error", "pmx_version", "pmx_build_id", "pmx_device_count",
     "pmx_ctx_create", "pmx_ctx_destroy", "pmx_ctx_sync",
     "pmx_bits_alloc", "pmx_bits_free", "pmx_bits_clear", "pmx_bits_upload", "pmx_bits_download",
     "pmx_bits_set_positions", "pmx_bits_set_positions_dev", "pmx_bits_set_regions", "pmx_bits_set_regions_dev",
@@ -71,6 +71,8 @@ def load_library(path: Optional[str] = None):
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
     L.pmx_last_error.restype = ctypes.c_char_p
     L.pmx_last_error.argtypes = []
+    L.pmx_build_id.argtypes = []
+    L.pmx_build_id.restype = ctypes.c_char_p
     L.pmx_version.restype = i32
     L.pmx_device_count.argtypes = [ctypes.POINTER(i32)]
     L.pmx_ctx_create.argtypes = [i32, vp, ctypes.POINTER(vp)]
@@ -106,6 +108,11 @@ def load_library(path: Optional[str] = None):
     if path is None:
         _lib = L
     return L
+
+
+def build_id() -> str:
+    """Source hash compiled into the loaded library (include/pymasc_amd.h: pmx_build_id)."""
+    return load_library().pmx_build_id().decode()
 
 
 def _check(L, rc: int):

@@ -51,29 +51,41 @@ def spawn_ranks(argv: Sequence[str], nranks: int, extra_env: Optional[dict] = No
     t0 = time.monotonic()
     rc = 0
     live = set(range(nranks))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = code
-                print(f"[launch] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
-        if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
-            if rc == 0:
-                rc = 124
-                print(f"[launch] timeout after {timeout:.0f}s; stopping all ranks", file=sys.stderr)
-            for r in live:
-                procs[r].terminate()          # exact PIDs we started, never a pattern
-            deadline = time.monotonic() + 10
-            for r in live:
-                try:
-                    procs[r].wait(max(0.1, deadline - time.monotonic()))
-                except subprocess.TimeoutExpired:
-                    procs[r].kill()
-                    procs[r].wait()
-            break
-        if live:
-            time.sleep(poll)
+
+    def stop(ranks):
+        """terminate, then kill, exactly the processes started above (PIDs, never a pattern)"""
+        for r in ranks:
+            if procs[r].poll() is None:
+                procs[r].terminate()
+        deadline = time.monotonic() + 10
+        for r in ranks:
+            try:
+                procs[r].wait(max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"[launch] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+            if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
+                if rc == 0:
+                    rc = 124
+                    print(f"[launch] timeout after {timeout:.0f}s; stopping all ranks", file=sys.stderr)
+                stop(sorted(live))
+                live.clear()
+                break
+            if live:
+                time.sleep(poll)
+    finally:
+        # KeyboardInterrupt or any other exception in the loop above: no rank may outlive the launcher holding a GPU and
+        # the rendezvous port
+        stop([r for r in range(nranks) if procs[r].poll() is None])
     return rc

@@ -53,16 +53,18 @@ def _owner_index(assignment: List[List[int]], njobs: int, device) -> Tuple[torch
 
 
 def exchange_results(local_rows: torch.Tensor, assignment: List[List[int]], njobs: int,
-                     group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                     group=None, force_collectives: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """local_rows: int64 [max_slots, nrows, stride], this rank's jobs in slot order (unused slots zero).
 
     Returns (rows[njobs, nrows, stride] in job order on every rank, totals[nrows, stride] = sum over
-    all jobs, computed by all-reduce so it can be cross-checked against rows.sum(0))."""
+    all jobs, computed by all-reduce so it can be cross-checked against rows.sum(0)).
+    force_collectives: run the all-gather / all-reduce even in a group of one rank (the one-GPU boxes' way to put the
+    RCCL code path under test and to time its fixed cost)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     max_slots = max(len(a) for a in assignment)
     assert local_rows.shape[0] == max_slots
     totals = local_rows.sum(dim=0)
-    if world == 1:
+    if world == 1 and not (force_collectives and dist.is_initialized()):
         gathered = local_rows.unsqueeze(0)
     else:
         flat = torch.empty((world * max_slots,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype,

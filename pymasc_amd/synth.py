@@ -32,6 +32,35 @@ def stress_genome(n_chroms: int = 200, total_bp: float = 1e10, seed: int = 0xBAD
     return [(f"s{i}", int(l)) for i, l in enumerate(lens.tolist())]
 
 
+_FIXTURE_RUNS = None
+
+
+def fixture_run_lengths(path: Optional[str] = None):
+    """Empirical run statistics of the only real mappability track available offline: the reference's test fixture
+    `hg19_36mer-test.bedGraph` (committed under tests/golden/; 985 mappable runs -- maximal stretches of value >= 1, the
+    filter of reader/bigwig.pyx:174-175 -- over 149 kb of chr1: mean run 35 bp, mean gap 117 bp, 23 % mappable, 860 run
+    edges per 64 Kbit).  Returns (run lengths, gap lengths) as int64 numpy arrays."""
+    global _FIXTURE_RUNS
+    if _FIXTURE_RUNS is None:
+        import os
+        import numpy as np
+        path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                    "hg19_36mer-test.bedGraph")
+        runs = []
+        for line in open(path):
+            f = line.split()
+            if len(f) < 4 or float(f[3]) < 1.0:
+                continue
+            b, e = int(f[1]), int(f[2])
+            if runs and runs[-1][1] == b:
+                runs[-1][1] = e
+            else:
+                runs.append([b, e])
+        r = np.asarray(runs, dtype=np.int64)
+        _FIXTURE_RUNS = (r[:, 1] - r[:, 0], r[1:, 0] - r[:-1, 1])
+    return _FIXTURE_RUNS
+
+
 @dataclass
 class ChromVectors:
     name: str
@@ -42,6 +71,7 @@ class ChromVectors:
     M: Optional[torch.Tensor]
     n_forward: int
     n_reverse: int
+    n_runs: int = 0          # mappable runs of M (the calculator's PMX_FLAG_WINDOW_ONLY hint looks at runs per bp)
     # host copies of what the vectors were built from (keep_host=True): read positions and set(first, last) intervals
     h_fpos: Optional["numpy.ndarray"] = None
     h_rpos: Optional["numpy.ndarray"] = None
@@ -55,7 +85,11 @@ def nwords(nbits: int) -> int:
 
 def make_chromosome(ctx, device, name: str, length: int, max_shift: int, read_len: int, seed: int,
                     density: float = 0.005, with_m: bool = True, peak_frac: float = 0.3, peak_shift: int = 180,
-                    mean_on: float = 2000.0, mean_off: float = 500.0, keep_host: bool = False) -> ChromVectors:
+                    mean_on: float = 2000.0, mean_off: float = 500.0, keep_host: bool = False,
+                    track: str = "synthetic") -> ChromVectors:
+    """track = "synthetic": BASELINE.md's geometric runs (mean_on / mean_off); "fixture": run and gap lengths drawn
+    independently from the empirical distribution of the reference's test track (fixture_run_lengths), tiled to the
+    chromosome's length -- the statistics of a real 36-mer track's worst stretch everywhere."""
     g = torch.Generator(device=device).manual_seed(seed)
     nbits = length + read_len + max_shift + 100
     nw = nwords(nbits)
@@ -76,11 +110,19 @@ def make_chromosome(ctx, device, name: str, length: int, max_shift: int, read_le
     M = None
     if with_m:
         M = torch.zeros(nw, dtype=torch.int64, device=device)
-        nruns = int(length / (mean_on + mean_off) * 1.3) + 16
-        on = torch.empty(nruns, device=device, dtype=torch.float64).exponential_(1.0 / mean_on, generator=g)
-        off = torch.empty(nruns, device=device, dtype=torch.float64).exponential_(1.0 / mean_off, generator=g)
-        on = on.floor().to(torch.int64) + 1
-        off = off.floor().to(torch.int64) + 1
+        if track == "fixture":
+            e_on, e_off = fixture_run_lengths()
+            nruns = int(length / (float(e_on.mean()) + float(e_off.mean())) * 1.1) + 64
+            t_on = torch.from_numpy(e_on).to(device)
+            t_off = torch.from_numpy(e_off).to(device)
+            on = t_on[torch.randint(0, t_on.numel(), (nruns,), generator=g, device=device)]
+            off = t_off[torch.randint(0, t_off.numel(), (nruns,), generator=g, device=device)]
+        else:
+            nruns = int(length / (mean_on + mean_off) * 1.3) + 16
+            on = torch.empty(nruns, device=device, dtype=torch.float64).exponential_(1.0 / mean_on, generator=g)
+            off = torch.empty(nruns, device=device, dtype=torch.float64).exponential_(1.0 / mean_off, generator=g)
+            on = on.floor().to(torch.int64) + 1
+            off = off.floor().to(torch.int64) + 1
         ends = torch.cumsum(on + off, 0)          # exclusive end of each on-run, 0-based like BigWig
         begins = ends - on
         keep = begins < length
@@ -91,7 +133,8 @@ def make_chromosome(ctx, device, name: str, length: int, max_shift: int, read_le
         if keep_host:
             host.update(h_first=first.cpu().numpy(), h_last=last.cpu().numpy())
     ctx.sync()
-    return ChromVectors(name, length, nbits, F, R, M, int(fpos.numel()), int(rpos.numel()), **host)
+    return ChromVectors(name, length, nbits, F, R, M, int(fpos.numel()), int(rpos.numel()),
+                        n_runs=int(first.numel()) if with_m else 0, **host)
 
 
 def make_genome(ctx, device, chroms, max_shift: int, read_len: int, seed_base: int = 0xC0FFEE,

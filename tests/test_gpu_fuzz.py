@@ -34,3 +34,30 @@ def test_randomized_geometry(seed):
                        f"full={full} f={flags}")
                 assert fz.compare(out, ref, S, with_m, False, tag), tag
             done += 1
+
+
+def test_randomized_geometry_with_every_buffer_poisoned():
+    """One more seed of the same sweep with pmx_debug_poison before EVERY call: scratch buffers, slabs, flag arrays and the
+    LDS of every CU hold a pattern, so a kernel that reads anything it has not written differs from the oracle here."""
+    rng = np.random.default_rng(15)
+    prng = np.random.default_rng(1515)
+    done = 0
+    with ffi.Context(0) as ctx:
+        while done < 50:
+            S, L, clen, fd, rd, with_m, mean_on, mean_off = fz.draw_case(rng)
+            if (S + 1) * (clen + S + L + 100) > 2e8:
+                continue
+            case_seed = int(rng.integers(0, 2**31))
+            full = fz.draw_full_range(rng)
+            nbits, F, R, M = synth.make_case(case_seed, clen, S, L, fd, rd, with_m, mean_on=mean_on, mean_off=mean_off,
+                                             full_range=full)
+            ref = oracle.calc_correlation(F, R, M, nbits, S, L)
+            for flags in (0, ffi.PMX_FLAG_FORCE_SPARSE):
+                if flags == ffi.PMX_FLAG_FORCE_SPARSE and L > 1024:
+                    continue
+                ctx.debug_poison(int(prng.choice([0, 0xffffffff, 0x80808080, 0x7fffffff, 0x00010001, int(prng.integers(0, 2**32))])))
+                out = ctx.calc_correlation(F, R, M, nbits, S, L, flags)
+                tag = (f"seed={case_seed} S={S} L={L} clen={clen} fd={fd} rd={rd} m={with_m}/{mean_on}/{mean_off} "
+                       f"full={full} f={flags} poisoned")
+                assert fz.compare(out, ref, S, with_m, False, tag), tag
+            done += 1

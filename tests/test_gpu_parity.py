@@ -178,6 +178,20 @@ def test_mappable_len_readless(ctx, flags, max_shift):
     np.testing.assert_array_equal(out.astype(np.int64), ref)
 
 
+@pytest.mark.parametrize("max_lag", [7900, 8191, 8192])
+def test_mappable_len_at_the_largest_pair_pass_lags(ctx, max_lag):
+    """The pair pass keeps 2 x (max_lag + 1) histogram words in LDS: 64 KB is passed at ~7870 lags, 8191 is its last lag
+    (8192: the window kernel in lag chunks takes over); with reads (calc_correlation) and without (mappable_len)."""
+    L = 36
+    nbits, F, R, M = synth.make_case(max_lag, 400000, max_lag, L, 0.003, 0.003, True, mean_on=2500, mean_off=600)
+    ref = oracle.mappable_len_readless(M, nbits, max_lag)
+    np.testing.assert_array_equal(ctx.mappable_len(M, nbits, max_lag, 0).astype(np.int64), ref)
+    S = max_lag + L - 1        # lags |L - 1 - d| up to max_lag
+    if S <= 65535:
+        nb2, F2, R2, M2 = synth.make_case(max_lag + 1, 150000, S, L, 0.003, 0.003, True, mean_on=2500, mean_off=600)
+        check_block(ctx.calc_correlation(F2, R2, M2, nb2, S, L, 0), oracle.calc_correlation(F2, R2, M2, nb2, S, L), S, True)
+
+
 def test_empty_vectors(ctx):
     nbits = 10000
     z = np.zeros(synth.nwords(nbits), dtype=np.uint64)

@@ -131,6 +131,26 @@ def test_unsorted_reads_raise():
     assert issubclass(ReadUnsortedError, IndexError)
 
 
+def test_a_read_beyond_the_vector_is_refused_when_it_is_fed():
+    """nbits = chromosome length + read_len + max_shift + 100 (mscc.pyx:165-167); the reference sets the bit unchecked.
+    The error comes at feed time, before anything of the chromosome is queued, and leaves the calculator usable."""
+    S, L, G = 50, 36, 5000
+    nbits = G + L + S + 100
+    calc = CCHipCalculator(S, L, ["a", "b"], [G, G], context=FakeContext())
+    calc.feed_forward_read("a", 100, 36)
+    calc.feed_reverse_read("a", nbits - 36, 36)          # reverse bit = pos + readlen - 1 = nbits - 1: the last bit, fine
+    with pytest.raises(IndexError):
+        calc.feed_reverse_read("a", nbits - 35, 36)
+    calc.feed_forward_read("a", nbits - 1, 36)           # last bit of the vector
+    with pytest.raises(IndexError):
+        calc.feed_forward_read("a", nbits, 36)
+    with pytest.raises(IndexError):
+        calc.feed_reads("b", np.array([10, nbits + 5]), np.array([36, 36]), np.array([False, False]))
+    calc.feed_forward_read("b", 20, 36)
+    calc.finishup_calculation()
+    assert calc.get_result("a").chrom.forward_sum == 2 and calc.get_result("b").chrom.forward_sum == 1
+
+
 def test_get_result_unknown_chrom_is_keyerror():
     calc = CCHipCalculator(50, 36, ["a"], [5000], context=FakeContext())
     with pytest.raises(KeyError):

@@ -53,12 +53,39 @@ def test_a_failing_rank_ends_the_run():
 def test_bench_gpus_n_spawns_ranks_before_touching_the_gpu():
     """No GPU here: both ranks of `bench.py --gpus 2` must start (fresh processes with RANK / WORLD_SIZE set) and fail
     loudly; the parent never imports torch.cuda itself and returns their exit code."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, timeout=500, env=env)
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is visible: the ranks would run the benchmark")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=500, env=env)
     assert p.returncode != 0
     assert p.stderr.count("no GPU visible") >= 1 and "[launch] rank" in p.stderr
     assert p.stdout.strip() == ""
+
+
+def test_an_exception_in_the_launcher_leaves_no_rank_behind(monkeypatch):
+    """KeyboardInterrupt (or any exception) while waiting: every rank process is terminated before it propagates."""
+    from pymasc_amd import launch
+    started = []
+    real_popen = subprocess.Popen
+
+    def recording_popen(*a, **k):
+        p = real_popen(*a, **k)
+        started.append(p)
+        return p
+
+    def interrupt(_seconds):
+        raise KeyboardInterrupt
+
+    monkeypatch.setattr(launch.subprocess, "Popen", recording_popen)
+    monkeypatch.setattr(launch.time, "sleep", interrupt)
+    with pytest.raises(KeyboardInterrupt):
+        launch.spawn_ranks([sys.executable, "-c", "import time; time.sleep(120)"], 2)
+    assert len(started) == 2 and all(p.poll() is not None for p in started)
+
+
+def test_a_hanging_rank_hits_the_timeout():
+    from pymasc_amd import launch
+    rc = launch.spawn_ranks([sys.executable, "-c", "import time; time.sleep(120)"], 2, timeout=1.0)
+    assert rc == 124
