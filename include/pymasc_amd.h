@@ -114,6 +114,62 @@ int pmx_bits_set_regions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits,
 /* bit_array_num_bits_set (bitarray.pyx:101-107) */
 int pmx_bits_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, uint64_t *h_count);
 
+/* ---- stream-ordered feeding --------------------------------------------------------------------------
+ * The calls above that take host arrays synchronise (they hand an error back); a genome fed through them costs one
+ * round trip per vector.  The calls below only ENQUEUE -- copies, builder kernels and the reference's per-read rules run
+ * on the context's stream, errors are recorded on the device and read later -- so the vectors of chromosome k are built
+ * while the host decodes chromosome k + 1 and nothing waits until the results are fetched.
+ * Host arrays: pageable memory may be reused as soon as a call returns (HIP stages it); pinned memory (pmx_host_alloc)
+ * is copied asynchronously and must stay untouched until the stream has passed the call (pmx_ctx_sync, or any
+ * synchronising call). */
+int pmx_host_alloc(pmx_ctx *ctx, uint64_t bytes, void **h);   /* page-locked host memory */
+int pmx_host_free(pmx_ctx *ctx, void *h);
+
+/* Feed state of ONE chromosome: PMX_FEED_WORDS uint64 in device memory, cleared (pmx_bits_clear) when the chromosome
+ * starts (CCBitArrayCalculator._init_buff, mscc.pyx:161-171), downloaded with pmx_bits_download when its sums are needed. */
+#define PMX_FEED_FORWARD_LEN_SUM     0   /* _forward_read_len_sum of the chromosome                 mscc.pyx:392       */
+#define PMX_FEED_REVERSE_LEN_SUM     1   /* _reverse_read_len_sum                                   mscc.pyx:418       */
+#define PMX_FEED_FORWARD_KEPT        2   /* forward reads that were not duplicates (= forward bits set by the feed)    */
+#define PMX_FEED_REVERSE_KEPT        3   /* reverse reads that found their bit clear                                   */
+#define PMX_FEED_FIRST_UNSORTED      4   /* 0, or PMX_FEED_ERR_BASE - index of the first read (counted over all calls since
+                                            the clear) below its predecessor: ReadUnsortedError, mscc.pyx:362-363     */
+#define PMX_FEED_FIRST_OUT_OF_RANGE  5   /* 0, or PMX_FEED_ERR_BASE - index of the first read / interval whose bit(s) fall
+                                            outside [0, nbits) (dropped / clipped; the reference writes unchecked)    */
+#define PMX_FEED_LAST_POS            6   /* _last_pos                                               mscc.pyx:365       */
+#define PMX_FEED_LAST_FORWARD_POS    7   /* _last_forward_pos                                       mscc.pyx:390       */
+#define PMX_FEED_READS               8   /* reads fed since the clear                                                  */
+#define PMX_FEED_MAX_REVERSE_LEN     9   /* longest reverse read seen (look-back bound of the reverse rule)            */
+#define PMX_FEED_CHUNK_FORWARD_POS  10   /* internal: 1 + last forward position of the call in progress                */
+#define PMX_FEED_WORDS              16
+#define PMX_FEED_ERR_BASE (1ull << 62)
+/* feed_forward_read / feed_reverse_read (mscc.pyx:370-418) for a run of n reads of one chromosome in FILE ORDER:
+ * h_pos[i] = 1-based leftmost position, h_readlen[i] = query length, h_is_reverse[i] != 0 for the reverse strand
+ * (forward bit: pos; reverse bit: pos + readlen - 1).  pos_bytes / len_bytes: 4 (int32) or 8 (int64).  Applies the
+ * reference's rules in file order across calls: a forward read at the position of the previous forward read is a
+ * duplicate; a reverse read counts only if its bit was clear; read-length sums over the reads that count.
+ * `reads_before` = reads fed to this chromosome by earlier calls since its state was cleared.  Asynchronous. */
+int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *h_pos, uint32_t pos_bytes,
+                   const void *h_readlen, uint32_t len_bytes, const uint8_t *h_is_reverse, uint64_t n,
+                   uint64_t reads_before, uint64_t *d_state);
+/* _load_mappability's loop (mscc.pyx:343-344): set(h_first[i] + first_offset, h_last[i]) for n intervals, ends inclusive
+ * (BigWig (begin, end) pairs: first_offset = 1).  width_bytes: 4 (uint32) or 8 (int64).  An interval outside [0, nbits) is
+ * clipped and recorded in d_state[PMX_FEED_FIRST_OUT_OF_RANGE] (d_state may be NULL).  Asynchronous. */
+int pmx_bits_set_regions_async(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
+                               uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state);
+/* A batch of chromosomes from bit positions and intervals in host memory -> cleared and rebuilt vectors, ONE call, no
+ * synchronisation: for callers that hold bit positions already (any of d_F / d_R / d_M may be NULL).  Range errors of the
+ * whole batch are reported by pmx_bits_build_status, which synchronises. */
+typedef struct pmx_build_job {
+    uint64_t *d_F, *d_R, *d_M;
+    uint64_t nbits;
+    const void *h_fpos, *h_rpos;        /* bit positions, pos_bytes wide */
+    uint64_t n_f, n_r;
+    const void *h_first, *h_last;       /* set(first, last), inclusive, pos_bytes wide */
+    uint64_t n_iv;
+} pmx_build_job;
+int pmx_bits_build_batch(pmx_ctx *ctx, uint32_t njobs, const pmx_build_job *jobs, uint32_t pos_bytes);
+int pmx_bits_build_status(pmx_ctx *ctx);   /* PMX_OK, or PMX_ERR_INVALID naming the first job with a position outside its vector */
+
 /* ---- the hot path ------------------------------------------------------------------------ */
 /* CCBitArrayCalculator._calc_correlation for one chromosome (mscc.pyx:217-325), inputs resident in
  * HBM.  d_M may be NULL (no mappability: rows 1-4 left zero).  d_out: PMX_NROWS * (max_shift+1)
@@ -140,6 +196,10 @@ int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint
                          uint32_t flags, uint64_t *d_out);
 int pmx_mappable_len(pmx_ctx *ctx, const uint64_t *h_M, uint64_t nbits, uint32_t max_shift,
                      uint32_t flags, uint64_t *h_out);
+/* The same for a batch of read-less chromosomes in one pass of the kernels (finishup_calculation walks every
+ * reference, mscc.pyx:436-439: 86 in the reference's test BAM): d_M, nbits, d_out are HOST arrays of njobs entries. */
+int pmx_mappable_len_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_M, const uint64_t *nbits,
+                               uint32_t max_shift, uint32_t flags, uint64_t *const *d_out);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* on = 1: every launch of a hot-path kernel that does work is bracketed by HIP events; on = 2: also the window-kernel

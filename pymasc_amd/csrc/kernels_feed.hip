@@ -1,0 +1,254 @@
+// Stream-ordered feeding (gfx950): the bulk counterparts of CCBitArrayCalculator.feed_forward_read / feed_reverse_read
+// (PyMaSC/core/bitarray/mscc.pyx:370-418) and of _load_mappability's set(begin + 1, end) loop (mscc.pyx:327-349).
+//
+// The reference takes one Python call per read: sortedness check (mscc.pyx:362-366), forward duplicate rule ("same
+// position as the previous forward read", :388-392), reverse rule ("the bit is already set", :416-418), read-length sums,
+// bit set.  Here a RUN of reads of one chromosome arrives as arrays in file order (position, read length, strand) and
+// three small kernels apply the same rules on the device, so that the host never walks the reads:
+//   k_feed_maxlen   longest reverse read of the chunk (bounds the look-back of the reverse rule)
+//   k_feed_reads    per read: sortedness against its predecessor, range check, duplicate rules, the two read-length
+//                   sums; sets the FORWARD bits.  Reads R as earlier chunks left it and never writes it, so "already set"
+//                   means exactly what it means in the reference: set by an earlier read in file order -- an earlier chunk
+//                   (the vector) or an earlier read of this chunk (look-back over the reads whose position allows the
+//                   same bit: pos_j >= bit - maxlen + 1).
+//   k_feed_finish   sets the REVERSE bits of the chunk and hands the chunk's last position / last forward position on to
+//                   the next chunk (the reference's _last_pos / _last_forward_pos).
+// Nothing is returned to the host here: sums, counts and the first offending read (unsorted / out of range) stay in the
+// chromosome's feed state in device memory (include/pymasc_amd.h: PMX_FEED_*) until the caller downloads it.
+#include "pmx_common.h"
+
+#define FEED_ERR_BASE (1ull << 62)   // error words hold FEED_ERR_BASE - index (atomicMax keeps the FIRST index); 0 = none
+
+template <typename T>
+__device__ __forceinline__ int64_t feed_ld(const T *p, uint64_t i) { return (int64_t)p[i]; }
+
+template <typename LT>
+__global__ void __launch_bounds__(256) k_feed_maxlen(const LT *__restrict__ rlen, const unsigned char *__restrict__ rev, uint64_t n,
+                                                     u64 *__restrict__ state)
+{
+    u64 m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t l = feed_ld(rlen, i);
+        if (rev[i] && l > 0 && (u64)l > m) m = (u64)l;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_down(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&state[PMX_FEED_MAX_REVERSE_LEN], m);
+}
+
+template <typename PT, typename LT>
+__global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, const LT *__restrict__ rlen,
+                                                    const unsigned char *__restrict__ rev, uint64_t n, uint64_t base, uint64_t nbits,
+                                                    u64 *__restrict__ F, const u64 *__restrict__ R, u64 *__restrict__ state)
+{
+    const int64_t prev_last = base ? (int64_t)state[PMX_FEED_LAST_POS] : 0;            // _last_pos (0 at a chromosome's start)
+    const int64_t prev_fwd = (int64_t)state[PMX_FEED_LAST_FORWARD_POS];                 // _last_forward_pos (0 likewise)
+    const int64_t maxlen = (int64_t)state[PMX_FEED_MAX_REVERSE_LEN];
+    u64 fsum = 0, rsum = 0, nf = 0, nr = 0, maxf = 0, e_sort = 0, e_range = 0;
+    bool any_f = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t p = feed_ld(pos, i), l = feed_ld(rlen, i);
+        const bool rv = rev[i] != 0;
+        const int64_t before = i ? feed_ld(pos, i - 1) : prev_last;
+        if (p < before) {                                                               // mscc.pyx:362-363
+            const u64 code = FEED_ERR_BASE - (base + i);
+            e_sort = code > e_sort ? code : e_sort;
+        }
+        const int64_t bit = rv ? p + l - 1 : p;
+        if (bit < 0 || (uint64_t)bit >= nbits) {
+            const u64 code = FEED_ERR_BASE - (base + i);
+            e_range = code > e_range ? code : e_range;
+            continue;
+        }
+        if (!rv) {
+            // duplicate: an earlier forward read at this position (sorted input: such reads are the ones right before it)
+            bool dup = p == prev_fwd;
+            for (uint64_t j = i; !dup && j > 0 && feed_ld(pos, j - 1) == p; j--) dup = rev[j - 1] == 0;
+            any_f = true;
+            if ((u64)p > maxf) maxf = (u64)p;
+            if (!dup) {
+                fsum += (u64)l;
+                nf++;
+                atomicOr(&F[bit >> 6], 1ull << (bit & 63));
+            }
+        } else {
+            bool set = (R[bit >> 6] >> (bit & 63)) & 1ull;                              // by an earlier chunk
+            const int64_t lowest = bit - maxlen + 1;                                    // by an earlier read of this chunk
+            for (uint64_t j = i; !set && j > 0; j--) {
+                const int64_t pj = feed_ld(pos, j - 1);
+                if (pj < lowest) break;
+                set = rev[j - 1] != 0 && pj + feed_ld(rlen, j - 1) - 1 == bit;
+            }
+            if (!set) {
+                rsum += (u64)l;
+                nr++;
+            }
+        }
+    }
+    // wave sums / maxima, one atomic per wave and word
+    for (int off = 32; off > 0; off >>= 1) {
+        fsum += __shfl_down(fsum, off, 64);
+        rsum += __shfl_down(rsum, off, 64);
+        nf += __shfl_down(nf, off, 64);
+        nr += __shfl_down(nr, off, 64);
+        const u64 a = __shfl_down(maxf, off, 64), b = __shfl_down(e_sort, off, 64), c = __shfl_down(e_range, off, 64);
+        maxf = a > maxf ? a : maxf;
+        e_sort = b > e_sort ? b : e_sort;
+        e_range = c > e_range ? c : e_range;
+    }
+    const bool wave_any_f = __ballot(any_f) != 0;
+    if ((threadIdx.x & 63) == 0) {
+        if (fsum) atomicAdd(&state[PMX_FEED_FORWARD_LEN_SUM], fsum);
+        if (rsum) atomicAdd(&state[PMX_FEED_REVERSE_LEN_SUM], rsum);
+        if (nf) atomicAdd(&state[PMX_FEED_FORWARD_KEPT], nf);
+        if (nr) atomicAdd(&state[PMX_FEED_REVERSE_KEPT], nr);
+        if (wave_any_f) atomicMax(&state[PMX_FEED_CHUNK_FORWARD_POS], maxf + 1);        // (+1: 0 = no forward read in the chunk)
+        if (e_sort) atomicMax(&state[PMX_FEED_FIRST_UNSORTED], e_sort);
+        if (e_range) atomicMax(&state[PMX_FEED_FIRST_OUT_OF_RANGE], e_range);
+    }
+}
+
+template <typename PT, typename LT>
+__global__ void __launch_bounds__(256) k_feed_finish(const PT *__restrict__ pos, const LT *__restrict__ rlen,
+                                                     const unsigned char *__restrict__ rev, uint64_t n, uint64_t nbits,
+                                                     u64 *__restrict__ R, u64 *__restrict__ state)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!rev[i]) continue;
+        const int64_t bit = feed_ld(pos, i) + feed_ld(rlen, i) - 1;
+        if (bit >= 0 && (uint64_t)bit < nbits) atomicOr(&R[bit >> 6], 1ull << (bit & 63));   // mscc.pyx:416-417
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t last = feed_ld(pos, n - 1);
+        state[PMX_FEED_LAST_POS] = last < 0 ? 0 : (u64)last;
+        const u64 cf = state[PMX_FEED_CHUNK_FORWARD_POS];
+        if (cf) state[PMX_FEED_LAST_FORWARD_POS] = cf - 1;
+        state[PMX_FEED_CHUNK_FORWARD_POS] = 0;
+        state[PMX_FEED_READS] += n;
+    }
+}
+
+// bitarray.set(first + offset, last), inclusive (bitarray.pyx:88-95; the mappability loader calls set(begin + 1, end),
+// mscc.pyx:343-344: offset = 1 for BigWig (begin, end) pairs).  One wavefront per interval as in k_set_regions; an
+// interval outside [0, nbits) is clipped and its index recorded in err (FEED_ERR_BASE - index, atomicMax).
+template <typename T>
+__global__ void __launch_bounds__(256) k_set_regions_t(u64 *__restrict__ words, uint64_t nbits, const T *__restrict__ from,
+                                                       const T *__restrict__ to, uint64_t n, int64_t offset, u64 *__restrict__ err)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < n; i += nwaves) {
+        int64_t a = (int64_t)from[i] + offset, b = (int64_t)to[i];
+        if (b < a) continue;
+        if (a < 0 || b >= (int64_t)nbits) {
+            if (err && lane == 0) atomicMax(err, FEED_ERR_BASE - i);
+            if (a < 0) a = 0;
+            if (b >= (int64_t)nbits) b = (int64_t)nbits - 1;
+            if (b < a) continue;
+        }
+        const uint64_t wa = (uint64_t)a >> 6, wb = (uint64_t)b >> 6;
+        const u64 lo_mask = ~0ull << (a & 63);
+        const u64 hi_mask = ~0ull >> (63 - (b & 63));
+        if (wa == wb) {
+            if (lane == 0) atomicOr(&words[wa], lo_mask & hi_mask);
+            continue;
+        }
+        if (lane == 0) atomicOr(&words[wa], lo_mask);
+        if (lane == 1) atomicOr(&words[wb], hi_mask);
+        for (uint64_t w = wa + 1 + lane; w < wb; w += 64) words[w] = ~0ull;
+    }
+}
+
+// bitarray[pos] = 1 for positions of either width; out-of-range positions are dropped and recorded in err
+template <typename T>
+__global__ void __launch_bounds__(256) k_set_positions_t(u64 *__restrict__ words, uint64_t nbits, const T *__restrict__ pos,
+                                                         uint64_t n, u64 *__restrict__ err)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t p = (int64_t)pos[i];
+        if (p >= 0 && (uint64_t)p < nbits)
+            atomicOr(&words[p >> 6], 1ull << (p & 63));
+        else if (err)
+            atomicMax(err, FEED_ERR_BASE - i);
+    }
+}
+
+static int feed_grid(pmx_ctx *ctx, uint64_t items, int per_block)
+{
+    uint64_t blocks = (items + per_block - 1) / per_block;
+    const uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <typename PT, typename LT>
+static int launch_feed(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *d_pos, const void *d_len,
+                       const unsigned char *d_rev, uint64_t n, uint64_t base, u64 *d_state)
+{
+    const int g = feed_grid(ctx, n, 256);
+    hipLaunchKernelGGL(k_feed_maxlen<LT>, dim3(g), dim3(256), 0, ctx->stream, (const LT *)d_len, d_rev, n, d_state);
+    PMX_CHECK_LAUNCH("k_feed_maxlen");
+    hipLaunchKernelGGL((k_feed_reads<PT, LT>), dim3(g), dim3(256), 0, ctx->stream, (const PT *)d_pos, (const LT *)d_len, d_rev, n,
+                       base, nbits, (u64 *)d_F, (const u64 *)d_R, d_state);
+    PMX_CHECK_LAUNCH("k_feed_reads");
+    hipLaunchKernelGGL((k_feed_finish<PT, LT>), dim3(g), dim3(256), 0, ctx->stream, (const PT *)d_pos, (const LT *)d_len, d_rev, n,
+                       nbits, (u64 *)d_R, d_state);
+    PMX_CHECK_LAUNCH("k_feed_finish");
+    return PMX_OK;
+}
+
+int pmx_launch_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *d_pos, uint32_t pos_bytes,
+                          const void *d_len, uint32_t len_bytes, const unsigned char *d_rev, uint64_t n, uint64_t base,
+                          uint64_t *d_state)
+{
+    if (n == 0) return PMX_OK;
+    u64 *st = (u64 *)d_state;
+    if (pos_bytes == 4 && len_bytes == 4) return launch_feed<int32_t, int32_t>(ctx, d_F, d_R, nbits, d_pos, d_len, d_rev, n, base, st);
+    if (pos_bytes == 4 && len_bytes == 8) return launch_feed<int32_t, int64_t>(ctx, d_F, d_R, nbits, d_pos, d_len, d_rev, n, base, st);
+    if (pos_bytes == 8 && len_bytes == 4) return launch_feed<int64_t, int32_t>(ctx, d_F, d_R, nbits, d_pos, d_len, d_rev, n, base, st);
+    if (pos_bytes == 8 && len_bytes == 8) return launch_feed<int64_t, int64_t>(ctx, d_F, d_R, nbits, d_pos, d_len, d_rev, n, base, st);
+    pmx_set_error("pmx_feed_reads: positions and read lengths must be 4 or 8 bytes wide (int32 / int64)");
+    return PMX_ERR_INVALID;
+}
+
+int pmx_launch_set_regions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to, uint32_t width,
+                             uint64_t n, int64_t offset, uint64_t *d_err)
+{
+    if (n == 0) return PMX_OK;
+    const int g = feed_grid(ctx, n, 4);
+    if (width == 4)
+        hipLaunchKernelGGL(k_set_regions_t<uint32_t>, dim3(g), dim3(256), 0, ctx->stream, (u64 *)d_words, nbits, (const uint32_t *)d_from,
+                           (const uint32_t *)d_to, n, offset, (u64 *)d_err);
+    else if (width == 8)
+        hipLaunchKernelGGL(k_set_regions_t<int64_t>, dim3(g), dim3(256), 0, ctx->stream, (u64 *)d_words, nbits, (const int64_t *)d_from,
+                           (const int64_t *)d_to, n, offset, (u64 *)d_err);
+    else {
+        pmx_set_error("set_regions: interval ends must be 4 (uint32) or 8 (int64) bytes wide");
+        return PMX_ERR_INVALID;
+    }
+    PMX_CHECK_LAUNCH("k_set_regions_t");
+    return PMX_OK;
+}
+
+int pmx_launch_set_positions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_pos, uint32_t width, uint64_t n,
+                               uint64_t *d_err)
+{
+    if (n == 0) return PMX_OK;
+    const int g = feed_grid(ctx, n, 256);
+    if (width == 4)
+        hipLaunchKernelGGL(k_set_positions_t<uint32_t>, dim3(g), dim3(256), 0, ctx->stream, (u64 *)d_words, nbits, (const uint32_t *)d_pos, n,
+                           (u64 *)d_err);
+    else if (width == 8)
+        hipLaunchKernelGGL(k_set_positions_t<int64_t>, dim3(g), dim3(256), 0, ctx->stream, (u64 *)d_words, nbits, (const int64_t *)d_pos, n,
+                           (u64 *)d_err);
+    else {
+        pmx_set_error("set_positions: positions must be 4 (uint32) or 8 (int64) bytes wide");
+        return PMX_ERR_INVALID;
+    }
+    PMX_CHECK_LAUNCH("k_set_positions_t");
+    return PMX_OK;
+}

@@ -97,6 +97,18 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
         ctx->d_stage[i] = nullptr;
         ctx->stage_words[i] = 0;
     }
+    for (int i = 0; i < PMX_FEED_SLOTS; i++) {
+        ctx->d_feed[i] = nullptr;
+        ctx->feed_words[i] = 0;
+        ctx->feed_done[i] = nullptr;
+        ctx->feed_used[i] = false;
+    }
+    ctx->feed_next = 0;
+    ctx->copy_stream = nullptr;
+    ctx->feed_copied = nullptr;
+    ctx->d_build_err = nullptr;
+    ctx->build_err_cap = 0;
+    ctx->build_err_jobs = 0;
     for (int i = 0; i < PMX_KERNEL_COUNT_; i++) {
         ctx->total_ms[i] = 0;
         ctx->launches[i] = 0;
@@ -113,7 +125,10 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
         }
         ctx->own_stream = true;
     }
-    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+    bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->feed_copied, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < PMX_FEED_SLOTS; i++) ok = hipEventCreateWithFlags(&ctx->feed_done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok || hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         pmx_set_error("pmx_ctx_create: cannot create the auxiliary stream / events");
@@ -138,6 +153,14 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (int i = 0; i < PMX_FEED_SLOTS; i++) {
+        if (ctx->d_feed[i]) (void)hipFree(ctx->d_feed[i]);
+        if (ctx->feed_done[i]) (void)hipEventDestroy(ctx->feed_done[i]);
+    }
+    if (ctx->feed_copied) (void)hipEventDestroy(ctx->feed_copied);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->d_build_err) (void)hipFree(ctx->d_build_err);
     for (auto &tl : ctx->timed) {
         (void)hipEventDestroy(tl.start);
         (void)hipEventDestroy(tl.stop);
@@ -590,6 +613,204 @@ int pmx_bits_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, uint64
     return PMX_OK;
 }
 
+// ---- stream-ordered feeding ------------------------------------------------------------------------
+
+int pmx_host_alloc(pmx_ctx *ctx, uint64_t bytes, void **h)
+{
+    REQUIRE(ctx && h, "pmx_host_alloc: NULL argument");
+    (void)hipSetDevice(ctx->device);
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pmx_set_error("pmx_host_alloc: hipHostMalloc of %llu bytes failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+        return PMX_ERR_NOMEM;
+    }
+    *h = p;
+    return PMX_OK;
+}
+
+int pmx_host_free(pmx_ctx *ctx, void *h)
+{
+    REQUIRE(ctx, "pmx_host_free: ctx is NULL");
+    if (!h) return PMX_OK;
+    (void)hipSetDevice(ctx->device);
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->copy_stream));
+    PMX_HIP(hipHostFree(h));
+    return PMX_OK;
+}
+
+}   // extern "C"
+
+// A staging slot of the feeders: device memory the copy stream fills while the kernels of the previous call still run on
+// the context's stream.  A slot is taken again only after the event behind its last consumer has passed.
+static int feed_acquire(pmx_ctx *ctx, size_t bytes, unsigned char **d, uint32_t *slot_out)
+{
+    const uint32_t slot = ctx->feed_next;
+    ctx->feed_next = (slot + 1) % PMX_FEED_SLOTS;
+    if (ctx->feed_used[slot]) PMX_HIP(hipEventSynchronize(ctx->feed_done[slot]));
+    const size_t words = (bytes + 7) / 8 + 8;
+    if (ctx->feed_words[slot] < words) {
+        if (ctx->d_feed[slot]) PMX_HIP(hipFree(ctx->d_feed[slot]));
+        ctx->d_feed[slot] = nullptr;
+        ctx->feed_words[slot] = 0;
+        const size_t want = words + words / 4;
+        PMX_HIP(hipMalloc((void **)&ctx->d_feed[slot], want * sizeof(uint64_t)));
+        ctx->feed_words[slot] = want;
+    }
+    *d = (unsigned char *)ctx->d_feed[slot];
+    *slot_out = slot;
+    return PMX_OK;
+}
+
+// copies queued on the copy stream -> visible to the kernels queued on the context's stream after this
+static int feed_publish(pmx_ctx *ctx)
+{
+    PMX_HIP(hipEventRecord(ctx->feed_copied, ctx->copy_stream));
+    PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->feed_copied, 0));
+    return PMX_OK;
+}
+
+static int feed_release(pmx_ctx *ctx, uint32_t slot)
+{
+    PMX_HIP(hipEventRecord(ctx->feed_done[slot], ctx->stream));
+    ctx->feed_used[slot] = true;
+    return PMX_OK;
+}
+
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+extern "C" {
+
+int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *h_pos, uint32_t pos_bytes,
+                   const void *h_readlen, uint32_t len_bytes, const uint8_t *h_is_reverse, uint64_t n,
+                   uint64_t reads_before, uint64_t *d_state)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    REQUIRE(ctx && d_F && d_R && d_state, "pmx_feed_reads: NULL argument");
+    REQUIRE(n == 0 || (h_pos && h_readlen && h_is_reverse), "pmx_feed_reads: NULL read arrays");
+    REQUIRE((pos_bytes == 4 || pos_bytes == 8) && (len_bytes == 4 || len_bytes == 8),
+            "pmx_feed_reads: positions and read lengths must be 4 or 8 bytes wide");
+    REQUIRE(nbits >= 1 && nbits < (1ull << 40), "pmx_feed_reads: nbits must be in [1, 2^40)");
+    if (n == 0) return PMX_OK;
+    const size_t o_len = align16((size_t)n * pos_bytes), o_rev = o_len + align16((size_t)n * len_bytes);
+    unsigned char *d = nullptr;
+    uint32_t slot = 0;
+    int rc = feed_acquire(ctx, o_rev + n, &d, &slot);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(d, h_pos, (size_t)n * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    PMX_HIP(hipMemcpyAsync(d + o_len, h_readlen, (size_t)n * len_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    PMX_HIP(hipMemcpyAsync(d + o_rev, h_is_reverse, (size_t)n, hipMemcpyHostToDevice, ctx->copy_stream));
+    rc = feed_publish(ctx);
+    if (rc) return rc;
+    rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d, pos_bytes, d + o_len, len_bytes, d + o_rev, n, reads_before, d_state);
+    if (rc) return rc;
+    return feed_release(ctx, slot);
+}
+
+int pmx_bits_set_regions_async(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
+                               uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    REQUIRE(ctx && d_words && ((h_first && h_last) || n == 0), "pmx_bits_set_regions_async: NULL argument");
+    REQUIRE(width_bytes == 4 || width_bytes == 8, "pmx_bits_set_regions_async: interval ends must be 4 or 8 bytes wide");
+    if (n == 0) return PMX_OK;
+    const size_t o_last = align16((size_t)n * width_bytes);
+    unsigned char *d = nullptr;
+    uint32_t slot = 0;
+    int rc = feed_acquire(ctx, 2 * o_last, &d, &slot);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(d, h_first, (size_t)n * width_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    PMX_HIP(hipMemcpyAsync(d + o_last, h_last, (size_t)n * width_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    rc = feed_publish(ctx);
+    if (rc) return rc;
+    rc = pmx_launch_set_regions_w(ctx, d_words, nbits, d, d + o_last, width_bytes, n, first_offset,
+                                  d_state ? d_state + PMX_FEED_FIRST_OUT_OF_RANGE : nullptr);
+    if (rc) return rc;
+    return feed_release(ctx, slot);
+}
+
+int pmx_bits_build_batch(pmx_ctx *ctx, uint32_t njobs, const pmx_build_job *jobs, uint32_t pos_bytes)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    REQUIRE(ctx && (jobs || njobs == 0), "pmx_bits_build_batch: NULL argument");
+    REQUIRE(pos_bytes == 4 || pos_bytes == 8, "pmx_bits_build_batch: positions must be 4 or 8 bytes wide");
+    if (njobs == 0) return PMX_OK;
+    // one error word per job of the batches since the last status call
+    const size_t need = (size_t)ctx->build_err_jobs + njobs;
+    if (ctx->build_err_cap < need) {
+        u64 *grown = nullptr;
+        const size_t cap = need * 2 + 64;
+        PMX_HIP(hipMalloc((void **)&grown, cap * sizeof(u64)));
+        PMX_HIP(hipMemsetAsync(grown, 0, cap * sizeof(u64), ctx->stream));
+        if (ctx->d_build_err) {
+            if (ctx->build_err_jobs)
+                PMX_HIP(hipMemcpyAsync(grown, ctx->d_build_err, ctx->build_err_jobs * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+            PMX_HIP(hipStreamSynchronize(ctx->stream));
+            PMX_HIP(hipFree(ctx->d_build_err));
+        }
+        ctx->d_build_err = grown;
+        ctx->build_err_cap = cap;
+    }
+    for (uint32_t i = 0; i < njobs; i++) {
+        const pmx_build_job &jb = jobs[i];
+        REQUIRE(jb.nbits >= 1 && jb.nbits < (1ull << 40), "pmx_bits_build_batch: nbits must be in [1, 2^40)");
+        REQUIRE((jb.n_f == 0 || (jb.d_F && jb.h_fpos)) && (jb.n_r == 0 || (jb.d_R && jb.h_rpos)) &&
+                    (jb.n_iv == 0 || (jb.d_M && jb.h_first && jb.h_last)),
+                "pmx_bits_build_batch: a job has entries but no vector / array for them");
+        const size_t nw = (size_t)words_for(jb.nbits) * sizeof(uint64_t);
+        if (jb.d_F) PMX_HIP(hipMemsetAsync(jb.d_F, 0, nw, ctx->stream));
+        if (jb.d_R) PMX_HIP(hipMemsetAsync(jb.d_R, 0, nw, ctx->stream));
+        if (jb.d_M) PMX_HIP(hipMemsetAsync(jb.d_M, 0, nw, ctx->stream));
+        const size_t o_r = align16((size_t)jb.n_f * pos_bytes), o_a = o_r + align16((size_t)jb.n_r * pos_bytes),
+                     o_b = o_a + align16((size_t)jb.n_iv * pos_bytes), total = o_b + align16((size_t)jb.n_iv * pos_bytes);
+        if (total == 0) continue;
+        unsigned char *d = nullptr;
+        uint32_t slot = 0;
+        int rc = feed_acquire(ctx, total, &d, &slot);
+        if (rc) return rc;
+        if (jb.n_f) PMX_HIP(hipMemcpyAsync(d, jb.h_fpos, (size_t)jb.n_f * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        if (jb.n_r) PMX_HIP(hipMemcpyAsync(d + o_r, jb.h_rpos, (size_t)jb.n_r * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        if (jb.n_iv) {
+            PMX_HIP(hipMemcpyAsync(d + o_a, jb.h_first, (size_t)jb.n_iv * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+            PMX_HIP(hipMemcpyAsync(d + o_b, jb.h_last, (size_t)jb.n_iv * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        }
+        rc = feed_publish(ctx);
+        if (rc) return rc;
+        uint64_t *err = (uint64_t *)(ctx->d_build_err + ctx->build_err_jobs + i);
+        if (jb.n_f) rc = pmx_launch_set_positions_w(ctx, jb.d_F, jb.nbits, d, pos_bytes, jb.n_f, err);
+        if (!rc && jb.n_r) rc = pmx_launch_set_positions_w(ctx, jb.d_R, jb.nbits, d + o_r, pos_bytes, jb.n_r, err);
+        if (!rc && jb.n_iv) rc = pmx_launch_set_regions_w(ctx, jb.d_M, jb.nbits, d + o_a, d + o_b, pos_bytes, jb.n_iv, 0, err);
+        if (rc) return rc;
+        rc = feed_release(ctx, slot);
+        if (rc) return rc;
+    }
+    ctx->build_err_jobs += njobs;
+    return PMX_OK;
+}
+
+int pmx_bits_build_status(pmx_ctx *ctx)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    REQUIRE(ctx, "pmx_bits_build_status: ctx is NULL");
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t n = ctx->build_err_jobs;
+    if (n == 0) return PMX_OK;
+    std::vector<u64> err(n);
+    PMX_HIP(hipMemcpy(err.data(), ctx->d_build_err, n * sizeof(u64), hipMemcpyDeviceToHost));
+    PMX_HIP(hipMemsetAsync(ctx->d_build_err, 0, n * sizeof(u64), ctx->stream));
+    ctx->build_err_jobs = 0;
+    for (size_t i = 0; i < n; i++)
+        if (err[i]) {
+            pmx_set_error("pmx_bits_build_batch: job %llu of the batches since the last status call has a position or interval "
+                          "outside its vector (first at index %llu of its array)",
+                          (unsigned long long)i, (unsigned long long)(PMX_FEED_ERR_BASE - err[i]));
+            return PMX_ERR_INVALID;
+        }
+    return PMX_OK;
+}
+
 // ---- hot path -------------------------------------------------------------------------------------
 
 static int check_shift_args(uint64_t nbits, uint32_t max_shift, const char *who)
@@ -622,6 +843,47 @@ int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint
     }
     PMX_HIP(hipMemsetAsync(d_out, 0, ((size_t)max_shift + 1) * sizeof(u64), ctx->stream));
     return pmx_launch_autocorr_dense(ctx, d_M, nbits, max_shift, (u64 *)d_out);
+}
+
+int pmx_mappable_len_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_M, const uint64_t *nbits,
+                               uint32_t max_shift, uint32_t flags, uint64_t *const *d_out)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    REQUIRE(ctx && (njobs == 0 || (d_M && nbits && d_out)), "pmx_mappable_len_batch_dev: NULL argument");
+    REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
+            "pmx_mappable_len_batch_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
+    if (njobs == 0) return PMX_OK;
+    for (uint32_t i = 0; i < njobs; i++) {
+        REQUIRE(d_M[i] && d_out[i], "pmx_mappable_len_batch_dev: NULL vector or output in the batch");
+        int rc = check_shift_args(nbits[i], max_shift, "pmx_mappable_len_batch_dev");
+        if (rc) return rc;
+    }
+    if ((flags & PMX_FLAG_FORCE_DENSE) || !pmx_sparse_supported(max_shift > 3 ? max_shift : 3, 1)) {
+        for (uint32_t i = 0; i < njobs; i++) {
+            int rc = pmx_mappable_len_dev(ctx, d_M[i], nbits[i], max_shift, flags, d_out[i]);
+            if (rc) return rc;
+        }
+        return PMX_OK;
+    }
+    const uint32_t chunk = pmx_sparse_max_jobs();
+    const size_t ac_words = pmx_autocorr_scratch_words(max_shift);
+    pmx_job jobs[64];
+    for (uint32_t lo = 0; lo < njobs; lo += chunk) {
+        const uint32_t n = njobs - lo < chunk ? njobs - lo : chunk;
+        int rc = pmx_ensure_scratch(ctx, (size_t)n * ac_words);
+        if (rc) return rc;
+        for (uint32_t i = 0; i < n; i++) {
+            jobs[i].d_F = nullptr;
+            jobs[i].d_R = nullptr;
+            jobs[i].d_M = d_M[lo + i];
+            jobs[i].nbits = nbits[lo + i];
+            jobs[i].d_out = d_out[lo + i];
+            jobs[i].d_out2 = (uint64_t *)(ctx->d_scratch + (size_t)i * ac_words);
+        }
+        rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_shift, 0, 1, max_shift, max_shift + 1);
+        if (rc) return rc;
+    }
+    return PMX_OK;
 }
 
 // one chromosome through the dense kernels (atomics into a zeroed block)

@@ -38,6 +38,8 @@ struct pmx_timed_launch {
     hipEvent_t start, stop;
 };
 
+#define PMX_FEED_SLOTS 3
+
 struct pmx_ctx {
     int device;
     hipStream_t stream;          // the stream launches are enqueued on (the caller's, or our own)
@@ -74,6 +76,17 @@ struct pmx_ctx {
     // staging for the host-pointer entry points
     uint64_t *d_stage[3];
     size_t stage_words[3];
+    // staging of the stream-ordered feeders (pmx_feed_reads, pmx_bits_set_regions_async, pmx_bits_build_batch): a ring of
+    // FEED_SLOTS buffers; a slot is reused once the event recorded behind its consumer kernels has passed
+    uint64_t *d_feed[PMX_FEED_SLOTS];
+    size_t feed_words[PMX_FEED_SLOTS];
+    hipEvent_t feed_done[PMX_FEED_SLOTS];
+    bool feed_used[PMX_FEED_SLOTS];
+    uint32_t feed_next;
+    hipStream_t copy_stream;     // H2D copies of the feeders run here, one slot ahead of the kernels on `stream`
+    hipEvent_t feed_copied;
+    u64 *d_build_err;            // pmx_bits_build_batch: one range-error word per job since the last pmx_bits_build_status
+    size_t build_err_cap, build_err_jobs;
     u64 *d_out_stage;
     size_t out_stage_words;
     // result blocks of max_shift < 3 are computed 4 columns wide here and narrowed into the caller's blocks
@@ -93,6 +106,15 @@ int pmx_launch_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, co
 int pmx_launch_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const int64_t *d_from,
                            const int64_t *d_to, uint64_t n);
 int pmx_launch_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, u64 *d_count /* += */);
+
+// stream-ordered feeding (kernels_feed.hip): device arrays in, nothing read back
+int pmx_launch_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *d_pos, uint32_t pos_bytes,
+                          const void *d_len, uint32_t len_bytes, const unsigned char *d_rev, uint64_t n, uint64_t base,
+                          uint64_t *d_state);
+int pmx_launch_set_regions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to, uint32_t width,
+                             uint64_t n, int64_t offset, uint64_t *d_err);
+int pmx_launch_set_positions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_pos, uint32_t width, uint64_t n,
+                               uint64_t *d_err);
 
 // dense cross-correlation (kernels_dense.hip)
 // rows NCC_CCBINS / MSCC_FSUM / MSCC_RSUM / MSCC_CCBINS of d_out (stride = out_stride) are overwritten (per-workgroup

@@ -28,6 +28,11 @@ PMX_FLAG_FORCE_DENSE = 2
 PMX_FLAG_FORCE_SPARSE = 4
 PMX_FLAG_SKIP_MLEN = 8
 
+# feed state words (include/pymasc_amd.h: PMX_FEED_*)
+PMX_FEED_FORWARD_LEN_SUM, PMX_FEED_REVERSE_LEN_SUM, PMX_FEED_FORWARD_KEPT, PMX_FEED_REVERSE_KEPT = 0, 1, 2, 3
+PMX_FEED_FIRST_UNSORTED, PMX_FEED_FIRST_OUT_OF_RANGE, PMX_FEED_LAST_POS, PMX_FEED_LAST_FORWARD_POS = 4, 5, 6, 7
+PMX_FEED_READS, PMX_FEED_MAX_REVERSE_LEN, PMX_FEED_CHUNK_FORWARD_POS, PMX_FEED_WORDS = 8, 9, 10, 16
+PMX_FEED_ERR_BASE = 1 << 62
 PMX_PATH_DENSE = 1
 PMX_PATH_SPARSE = 2
 
@@ -44,7 +49,10 @@ EXPORTS = [
     "pmx_bits_alloc", "pmx_bits_free", "pmx_bits_clear", "pmx_bits_upload", "pmx_bits_download",
     "pmx_bits_set_positions", "pmx_bits_set_positions_dev", "pmx_bits_set_regions", "pmx_bits_set_regions_dev",
     "pmx_bits_count",
+    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_bits_set_regions_async", "pmx_bits_build_batch",
+    "pmx_bits_build_status",
     "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
+    "pmx_mappable_len_batch_dev",
     "pmx_ctx_set_profiling", "pmx_ctx_reset_kernel_times", "pmx_ctx_kernel_time", "pmx_kernel_name",
     "pmx_debug_poison", "pmx_debug_read_slab", "pmx_debug_set_max_workgroups",
 ]
@@ -88,6 +96,13 @@ def load_library(path: Optional[str] = None):
     L.pmx_bits_set_regions.argtypes = [vp, vp, u64, vp, vp, u64]
     L.pmx_bits_set_regions_dev.argtypes = [vp, vp, u64, vp, vp, u64]
     L.pmx_bits_count.argtypes = [vp, vp, u64, ctypes.POINTER(u64)]
+    L.pmx_host_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
+    L.pmx_host_free.argtypes = [vp, vp]
+    L.pmx_feed_reads.argtypes = [vp, vp, vp, u64, vp, u32, vp, u32, vp, u64, u64, vp]
+    L.pmx_bits_set_regions_async.argtypes = [vp, vp, u64, vp, vp, u32, u64, ctypes.c_int64, vp]
+    L.pmx_bits_build_batch.argtypes = [vp, u32, vp, u32]
+    L.pmx_bits_build_status.argtypes = [vp]
+    L.pmx_mappable_len_batch_dev.argtypes = [vp, u32, vp, vp, u32, u32, vp]
     L.pmx_cc_dev.argtypes = [vp, vp, vp, vp, u64, u32, u32, u32, vp]
     L.pmx_cc_batch_dev.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, vp]
     L.pmx_calc_correlation.argtypes = [vp, vp, vp, vp, u64, u32, u32, u32, vp]
@@ -146,6 +161,9 @@ class Context:
     # -- lifecycle
     def close(self):
         if getattr(self, "_h", None):
+            for p in list(getattr(self, "_pinned", {}).values()):
+                self._L.pmx_host_free(self._h, ctypes.c_void_p(p))
+            self._pinned = {}
             self._L.pmx_ctx_destroy(self._h)
             self._h = None
 
@@ -210,6 +228,102 @@ class Context:
         out = ctypes.c_uint64()
         _check(self._L, self._L.pmx_bits_count(self._h, ctypes.c_void_p(d_words), int(nbits), ctypes.byref(out)))
         return int(out.value)
+
+    # -- stream-ordered feeding (nothing below synchronises)
+    def host_array(self, n: int, dtype) -> np.ndarray:
+        """A numpy array over page-locked host memory (pmx_host_alloc): copies from it run asynchronously.  The memory is
+        released with the context (or host_free(array))."""
+        dt = np.dtype(dtype)
+        nbytes = max(int(n) * dt.itemsize, 1)
+        p = ctypes.c_void_p()
+        _check(self._L, self._L.pmx_host_alloc(self._h, nbytes, ctypes.byref(p)))
+        buf = (ctypes.c_char * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt, count=int(n))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            _check(self._L, self._L.pmx_host_free(self._h, ctypes.c_void_p(p)))
+
+    @staticmethod
+    def _int_array(a: np.ndarray, what: str) -> np.ndarray:
+        a = np.asarray(a)
+        if a.dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+            a = a.astype(np.int64)
+        return np.ascontiguousarray(a)
+
+    def feed_reads(self, d_F: int, d_R: int, nbits: int, pos: np.ndarray, readlen: np.ndarray, is_reverse: np.ndarray,
+                   reads_before: int, d_state: int):
+        """pmx_feed_reads: a run of reads of one chromosome in file order (int32 / int64 arrays, strand as bool / uint8).
+        Returns the arrays actually handed over: keep them alive until the next synchronising call."""
+        pos = self._int_array(pos, "pos")
+        readlen = self._int_array(readlen, "readlen")
+        rev = np.ascontiguousarray(is_reverse)
+        if rev.dtype != np.uint8:
+            rev = rev.view(np.uint8) if rev.dtype == np.bool_ else rev.astype(np.uint8)
+        assert pos.size == readlen.size == rev.size
+        _check(self._L, self._L.pmx_feed_reads(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R), int(nbits), pos.ctypes.data,
+                                               pos.dtype.itemsize, readlen.ctypes.data, readlen.dtype.itemsize, rev.ctypes.data,
+                                               pos.size, int(reads_before), ctypes.c_void_p(d_state)))
+        return pos, readlen, rev
+
+    def bits_set_regions_async(self, d_words: int, nbits: int, first: np.ndarray, last: np.ndarray, first_offset: int = 0,
+                               d_state: Optional[int] = None):
+        """set(first + first_offset, last) per interval, no synchronisation (uint32 or int64 arrays)."""
+        first, last = np.asarray(first), np.asarray(last)
+        if first.dtype != last.dtype or first.dtype not in (np.dtype(np.uint32), np.dtype(np.int64)):
+            first, last = first.astype(np.int64), last.astype(np.int64)
+        first, last = np.ascontiguousarray(first), np.ascontiguousarray(last)
+        assert first.size == last.size
+        _check(self._L, self._L.pmx_bits_set_regions_async(self._h, ctypes.c_void_p(d_words), int(nbits), first.ctypes.data,
+                                                           last.ctypes.data, first.dtype.itemsize, first.size, int(first_offset),
+                                                           ctypes.c_void_p(d_state) if d_state else None))
+        return first, last
+
+    class _BuildJob(ctypes.Structure):
+        _fields_ = [("d_F", ctypes.c_void_p), ("d_R", ctypes.c_void_p), ("d_M", ctypes.c_void_p), ("nbits", ctypes.c_uint64),
+                    ("h_fpos", ctypes.c_void_p), ("h_rpos", ctypes.c_void_p), ("n_f", ctypes.c_uint64), ("n_r", ctypes.c_uint64),
+                    ("h_first", ctypes.c_void_p), ("h_last", ctypes.c_void_p), ("n_iv", ctypes.c_uint64)]
+
+    def bits_build_batch(self, jobs, pos_dtype=np.int64):
+        """pmx_bits_build_batch.  jobs: iterable of (d_F, d_R, d_M, nbits, fpos, rpos, first, last) -- vectors as device
+        pointers (or None), arrays of dtype `pos_dtype` (uint32 / int64) or None.  One call, no synchronisation; errors are
+        reported by build_status()."""
+        dt = np.dtype(pos_dtype)
+        assert dt in (np.dtype(np.uint32), np.dtype(np.int64))
+        jobs = list(jobs)
+        arr = (self._BuildJob * max(len(jobs), 1))()
+        keep = []
+        for k, (d_F, d_R, d_M, nbits, fpos, rpos, first, last) in enumerate(jobs):
+            def a(x):
+                if x is None:
+                    return None, 0
+                x = np.ascontiguousarray(x, dtype=dt)
+                keep.append(x)
+                return x.ctypes.data, x.size
+            j = arr[k]
+            j.d_F, j.d_R, j.d_M, j.nbits = d_F, d_R, d_M, int(nbits)
+            j.h_fpos, j.n_f = a(fpos)
+            j.h_rpos, j.n_r = a(rpos)
+            j.h_first, n1 = a(first)
+            j.h_last, n2 = a(last)
+            assert n1 == n2
+            j.n_iv = n1
+        _check(self._L, self._L.pmx_bits_build_batch(self._h, len(jobs), ctypes.cast(arr, ctypes.c_void_p), dt.itemsize))
+        return keep
+
+    def bits_build_status(self):
+        _check(self._L, self._L.pmx_bits_build_status(self._h))
+
+    def mappable_len_batch_dev(self, d_M, nbits, max_shift: int, flags: int, d_out):
+        n = len(d_M)
+        vpa = ctypes.c_void_p * n
+        _check(self._L, self._L.pmx_mappable_len_batch_dev(self._h, n, ctypes.cast(vpa(*d_M), ctypes.c_void_p),
+                                                           ctypes.cast((ctypes.c_uint64 * n)(*[int(x) for x in nbits]), ctypes.c_void_p),
+                                                           int(max_shift), int(flags), ctypes.cast(vpa(*d_out), ctypes.c_void_p)))
 
     # -- hot path
     def cc_dev(self, d_F: int, d_R: int, d_M: Optional[int], nbits: int, max_shift: int, read_len: int,

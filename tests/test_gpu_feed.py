@@ -1,0 +1,184 @@
+"""GPU parity of the stream-ordered feeders against the oracle's restatement of the reference's per-read rules
+(feed_forward_read / feed_reverse_read, mscc.pyx:370-418; _load_mappability, mscc.pyx:327-349): bit-exact vectors,
+read-length sums, kept-read counts and the first offending read, for one chunk and for chunk boundaries anywhere."""
+import numpy as np
+import pytest
+
+from oracle import model as oracle
+from pymasc_amd import ffi
+from . import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ffi.Context(0)
+    yield c
+    c.close()
+
+
+def make_reads(rng, n, glen, dup_frac=0.3, lens=(36,), sort=True):
+    """Sorted reads with plenty of duplicates: repeated positions on both strands, variable read lengths so that
+    different (pos, len) pairs hit the same reverse bit."""
+    base = rng.integers(1, glen, size=n)
+    pick = rng.random(n) < dup_frac
+    base[pick] = rng.choice(base[~pick] if (~pick).any() else base, size=int(pick.sum()))
+    pos = np.sort(base) if sort else base
+    rlen = rng.choice(np.asarray(lens), size=n)
+    rev = rng.random(n) < 0.5
+    return pos.astype(np.int64), rlen.astype(np.int64), rev
+
+
+def reference_feed(pos, rlen, rev, S, L, glen):
+    oc = oracle.OracleCalculator(S, L, ["c"], [glen])
+    for p, l, r in zip(pos.tolist(), rlen.tolist(), rev.tolist()):
+        (oc.feed_reverse_read if r else oc.feed_forward_read)("c", p, l)
+    return oc._F, oc._R, oc._f_rls, oc._r_rls, oc._nbits
+
+
+def device_feed(ctx, pos, rlen, rev, nbits, cuts, pdt, ldt):
+    d_F, d_R = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits)
+    d_st = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    keep = []
+    fed = 0
+    for a, b in zip([0] + cuts, cuts + [pos.size]):
+        if b > a:
+            keep.append(ctx.feed_reads(d_F, d_R, nbits, pos[a:b].astype(pdt), rlen[a:b].astype(ldt), rev[a:b], fed, d_st))
+            fed += b - a
+    F, R = ctx.bits_download(d_F, nbits), ctx.bits_download(d_R, nbits)
+    st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+    for d in (d_F, d_R, d_st):
+        ctx.bits_free(d)
+    return F, R, st
+
+
+@pytest.mark.parametrize("pdt,ldt", [(np.int32, np.int32), (np.int64, np.int64), (np.int32, np.int64), (np.int64, np.int32)])
+@pytest.mark.parametrize("nchunks", [1, 2, 7])
+def test_feed_reads_matches_the_reference_rules(ctx, nchunks, pdt, ldt):
+    S, L, glen = 300, 36, 200000
+    rng = np.random.default_rng(100 * nchunks + np.dtype(pdt).itemsize + np.dtype(ldt).itemsize)
+    pos, rlen, rev = make_reads(rng, 30000, glen, lens=(20, 36, 36, 36, 50, 101))
+    pos[:3] = 0                                          # position 0: the reference's _last_forward_pos starts at 0 (a duplicate)
+    pos.sort()
+    wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
+    cuts = sorted(rng.choice(np.arange(1, pos.size), size=nchunks - 1, replace=False).tolist()) if nchunks > 1 else []
+    F, R, st = device_feed(ctx, pos, rlen, rev, nbits, cuts, pdt, ldt)
+    np.testing.assert_array_equal(F, wF)
+    np.testing.assert_array_equal(R, wR)
+    assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+    popc = lambda w: int(oracle.lib().pmo_count(oracle._p(np.ascontiguousarray(w)), w.size))
+    assert int(st[ffi.PMX_FEED_FORWARD_KEPT]) == popc(wF) and int(st[ffi.PMX_FEED_REVERSE_KEPT]) == popc(wR)
+    assert int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0 and int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 0
+    assert int(st[ffi.PMX_FEED_READS]) == pos.size and int(st[ffi.PMX_FEED_LAST_POS]) == int(pos[-1])
+
+
+def test_chunk_boundaries_inside_runs_of_equal_positions(ctx):
+    """Every cut falls inside a run of reads at one position (both strands, several lengths): the duplicate rules must see
+    the reads of the previous chunk -- forward through the carried last forward position, reverse through the vector."""
+    S, L, glen = 100, 36, 5000
+    rng = np.random.default_rng(7)
+    pos = np.sort(rng.integers(1, 60, size=4000)).astype(np.int64) * 50      # 60 positions x ~66 reads
+    rlen = rng.choice(np.asarray([30, 36, 36, 40]), size=pos.size).astype(np.int64)
+    rev = rng.random(pos.size) < 0.5
+    wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
+    cuts = list(range(13, pos.size, 97))
+    F, R, st = device_feed(ctx, pos, rlen, rev, nbits, cuts, np.int32, np.int32)
+    np.testing.assert_array_equal(F, wF)
+    np.testing.assert_array_equal(R, wR)
+    assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+
+
+def test_first_unsorted_and_first_out_of_range_read_are_recorded(ctx):
+    S, L, glen = 100, 36, 50000
+    nbits = glen + L + S + 100
+    rng = np.random.default_rng(3)
+    pos, rlen, rev = make_reads(rng, 5000, glen)
+    bad_sort = 3210
+    pos[bad_sort] = pos[bad_sort - 1] - 1                # below its predecessor (mscc.pyx:362-363)
+    pos[bad_sort + 1:] = np.maximum(pos[bad_sort + 1:], pos[bad_sort - 1])
+    F, R, st = device_feed(ctx, pos, rlen, rev, nbits, [1000, bad_sort], np.int64, np.int64)
+    assert ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == bad_sort
+    pos, rlen, rev = make_reads(rng, 5000, glen)
+    pos[-2:] = nbits + 5
+    rev[-2:] = False
+    F, R, st = device_feed(ctx, pos, rlen, rev, nbits, [2500], np.int64, np.int64)
+    assert ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == pos.size - 2
+    assert int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0
+
+
+@pytest.mark.parametrize("dt,offset", [(np.uint32, 1), (np.int64, 1), (np.int64, 0)])
+def test_set_regions_async_matches_oracle(ctx, dt, offset):
+    rng = np.random.default_rng(11)
+    nbits = 300000
+    starts = np.sort(rng.integers(0, nbits - 3000, size=900))
+    ends = starts + rng.integers(1, 2500, size=900)
+    d = ctx.bits_alloc(nbits)
+    d_st = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    keep = ctx.bits_set_regions_async(d, nbits, starts.astype(dt), ends.astype(dt), offset, d_st)
+    got = ctx.bits_download(d, nbits)
+    iv = [(int(s) + offset - 1, int(e)) for s, e in zip(starts, ends)]     # bits_from_intervals sets (b + 1 .. e)
+    np.testing.assert_array_equal(got, oracle.bits_from_intervals(iv, nbits))
+    assert int(ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 0
+    # an interval beyond the vector is clipped and recorded
+    ctx.bits_clear(d, nbits)
+    keep = ctx.bits_set_regions_async(d, nbits, np.array([10, nbits - 5], dtype=dt), np.array([20, nbits + 50], dtype=dt), 0, d_st)
+    got = ctx.bits_download(d, nbits)
+    assert ffi.PMX_FEED_ERR_BASE - int(ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 1
+    assert (int(got[(nbits - 1) >> 6]) >> ((nbits - 1) & 63)) & 1
+    ctx.bits_free(d)
+    ctx.bits_free(d_st)
+    del keep
+
+
+@pytest.mark.parametrize("dt", [np.uint32, np.int64])
+def test_build_batch_matches_oracle_and_reports_range_errors(ctx, dt):
+    rng = np.random.default_rng(21)
+    jobs, want, ptrs = [], [], []
+    for k, nbits in enumerate([70001, 65536, 300, 123457]):
+        fpos = np.sort(rng.integers(0, nbits, size=nbits // 50))
+        rpos = np.sort(rng.integers(0, nbits, size=nbits // 40))
+        starts = np.sort(rng.integers(0, max(nbits - 400, 1), size=max(nbits // 500, 1)))
+        ends = np.minimum(starts + rng.integers(0, 300, size=starts.size), nbits - 1)
+        dF, dR, dM = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits), ctx.bits_alloc(nbits)
+        ctx.bits_set_positions(dF, nbits, np.arange(0, nbits, 7))       # stale content: the batch call clears
+        jobs.append((dF, dR, dM if k != 2 else None, nbits, fpos, rpos, starts if k != 2 else None, ends if k != 2 else None))
+        ptrs.append((dF, dR, dM))
+        want.append((oracle.bits_from_positions(fpos, nbits), oracle.bits_from_positions(rpos, nbits),
+                     oracle.bits_from_intervals([(int(s) - 1, int(e)) for s, e in zip(starts, ends)], nbits) if k != 2 else None, nbits))
+    keep = ctx.bits_build_batch(jobs, dt)
+    ctx.bits_build_status()
+    for (dF, dR, dM), (wF, wR, wM, nbits) in zip(ptrs, want):
+        np.testing.assert_array_equal(ctx.bits_download(dF, nbits), wF)
+        np.testing.assert_array_equal(ctx.bits_download(dR, nbits), wR)
+        if wM is not None:
+            np.testing.assert_array_equal(ctx.bits_download(dM, nbits), wM)
+    # a position beyond its vector: reported by the status call, naming the job
+    bad = list(jobs[1])
+    bad[4] = np.array([5, 65536], dtype=np.int64)
+    keep = ctx.bits_build_batch([jobs[0], tuple(bad)], dt)
+    with pytest.raises(ffi.PmxError) as e:
+        ctx.bits_build_status()
+    assert "job 1" in str(e.value)
+    ctx.bits_build_status()                               # cleared by the report
+    for tri in ptrs:
+        for d in tri:
+            ctx.bits_free(d)
+    del keep
+
+
+@pytest.mark.parametrize("max_shift", [300, 2000])
+def test_mappable_len_batch_matches_oracle(ctx, max_shift):
+    rng = np.random.default_rng(5 + max_shift)
+    sizes = [40000, 900, 200003, 65536] + [3000 + 517 * i for i in range(36)]     # more jobs than one job table
+    Ms = [synth.run_bits(rng, n, 300, 80, 0, n) for n in sizes]
+    dM = [ctx.bits_alloc(n) for n in sizes]
+    dO = [ctx.bits_alloc((max_shift + 1) * 64) for _ in sizes]
+    for d, M, n in zip(dM, Ms, sizes):
+        ctx.bits_upload(d, M, n)
+    ctx.mappable_len_batch_dev(dM, sizes, max_shift, 0, dO)
+    for d, M, n in zip(dO, Ms, sizes):
+        got = ctx.bits_download(d, (max_shift + 1) * 64)
+        np.testing.assert_array_equal(got.astype(np.int64), oracle.mappable_len_readless(M, n, max_shift).astype(np.int64))
+    for d in dM + dO:
+        ctx.bits_free(d)
