@@ -374,25 +374,39 @@ def main():
     work_per_step = (S + 1) * total_bp
     value = work_per_step * args.steps / elapsed
 
-    # ---- end to end: reads + intervals in HOST memory -> pmx_bits_set_positions / _regions (H2D + builder
-    # kernels) -> the same kernels -> rows back in host memory.  Never `value`; reported beside it.
+    # ---- end to end: reads + intervals in HOST memory -> vectors -> the same kernels -> rows back in host
+    # memory.  Never `value`; reported beside it.  Two legs:
+    #   end_to_end            bit positions / intervals (uint32, page-locked host arrays) -> pmx_bits_build_batch (ONE
+    #                         stream-ordered call per genome, copies one chromosome ahead of the builder kernels, range check
+    #                         deferred) -> pmx_cc_batch_dev -> exchange -> rows
+    #   end_to_end_calculator the drop-in boundary itself: CCHipCalculator.feed_reads per chromosome (reads in file order:
+    #                         int32 position + uint16 read length + strand, page-locked) -> finishup_calculation ->
+    #                         get_whole_result (the reference's result objects), rows compared with the resident-vector run
     end_to_end = None
+    calc_leg = None
     if e2e:
+        def pinned(a, dt):
+            out = ctx.host_array(a.size, dt)
+            out[:] = a
+            return out
+        host = []
+        for v in vecs:
+            host.append((pinned(v.h_fpos, np.uint32), pinned(v.h_rpos, np.uint32),
+                         pinned(v.h_first, np.uint32) if with_m else None, pinned(v.h_last, np.uint32) if with_m else None))
+        build_jobs = [(v.F.data_ptr(), v.R.data_ptr(), v.M.data_ptr() if with_m else None, v.nbits, h[0], h[1], h[2], h[3])
+                      for v, h in zip(vecs, host)]
+
         def e2e_step():
-            for v in vecs:
-                ctx.bits_clear(v.F.data_ptr(), v.nbits)
-                ctx.bits_clear(v.R.data_ptr(), v.nbits)
-                ctx.bits_set_positions(v.F.data_ptr(), v.nbits, v.h_fpos)
-                ctx.bits_set_positions(v.R.data_ptr(), v.nbits, v.h_rpos)
-                if with_m:
-                    ctx.bits_clear(v.M.data_ptr(), v.nbits)
-                    ctx.bits_set_regions(v.M.data_ptr(), v.nbits, v.h_first, v.h_last)
+            keep = ctx.bits_build_batch(build_jobs, np.uint32)
             rws, _tot = step()
             xstream.synchronize()
-            return rws.cpu()
+            out = rws.cpu()
+            ctx.bits_build_status()              # the deferred range check of the whole genome (one read-back)
+            del keep
+            return out
         e2e_step()
         fence()
-        n_e2e = 3
+        n_e2e = 5
         t1 = time.perf_counter()
         for _ in range(n_e2e):
             host_rows = e2e_step()
@@ -403,11 +417,91 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         assert torch.equal(host_rows, rows.cpu()), "end-to-end rows differ from the resident-vector rows"
-        h2d = sum(v.h_fpos.nbytes + v.h_rpos.nbytes + (v.h_first.nbytes + v.h_last.nbytes if with_m else 0) for v in vecs)
+        h2d = sum(h[0].nbytes + h[1].nbytes + ((h[2].nbytes + h[3].nbytes) if with_m else 0) for h in host)
         end_to_end = {"value": work_per_step / dt, "unit": "shifts*bp/s", "ms_per_step": dt * 1e3, "steps": n_e2e,
                       "h2d_bytes_this_rank": h2d, "d2h_bytes": int(host_rows.numel() * 8),
-                      "what": "positions + intervals in host memory -> pmx_bits_set_positions/_regions (H2D copy + "
-                              "builder kernels) -> k_cc_events (+ window kernels for dense tiles) -> exchange -> rows in host memory"}
+                      "what": "uint32 bit positions + intervals in page-locked host memory -> pmx_bits_build_batch (one "
+                              "stream-ordered call per genome: H2D copies one chromosome ahead of the builder kernels, deferred "
+                              "range check) -> k_cc_events (+ window kernels for dense tiles) -> exchange -> rows in host memory"}
+
+        if world == 1:
+            # ---- the calculator leg.  Reads in file order per chromosome: forward reads at their bit, reverse reads at
+            # bit - len + 1 with len = read_len (shorter at the chromosome's first bases), merged by position (stable).
+            from pymasc_amd.calculator import CCHipCalculator
+
+            class TrackFeeder:       # what CCHipCalculator asks of a BigWig reader (pymasc_amd/bigwig.py: fetch_arrays)
+                def __init__(self, tracks):
+                    self.tracks = tracks
+
+                def fetch_arrays(self, _threshold, chrom):
+                    return self.tracks[chrom]
+
+            reads, tracks = {}, {}
+            for v, h in zip(vecs, host):
+                fb, rb = np.unique(v.h_fpos), np.unique(v.h_rpos)
+                rl = np.minimum(L, rb).astype(np.int64)
+                pos = np.concatenate([fb, rb - rl + 1])
+                ln = np.concatenate([np.full(fb.size, L, dtype=np.int64), rl])
+                rv = np.concatenate([np.zeros(fb.size, dtype=np.uint8), np.ones(rb.size, dtype=np.uint8)])
+                order = np.argsort(pos, kind="stable")
+                # a run of reads of one length passes that length as a scalar (what a reader of single-end ChIP-seq data sees)
+                uniform = bool((ln == L).all())
+                reads[v.name] = (pinned(pos[order], np.int32), L if uniform else pinned(ln[order], np.uint16),
+                                 pinned(rv[order], np.uint8))
+                if with_m:      # BigWig (begin, end): set(begin + 1, end)
+                    tracks[v.name] = (pinned(v.h_first - 1, np.uint32), h[3], None)
+            names = [v.name for v in vecs]
+            lens = [v.length for v in vecs]
+
+            def calc_step():
+                calc = CCHipCalculator(S, L, names, lens, bwfeeder=TrackFeeder(tracks) if with_m else None, context=ctx)
+                for v in vecs:
+                    calc.feed_reads(v.name, *reads[v.name])
+                calc.finishup_calculation()
+                whole = calc.get_whole_result()
+                calc.close()
+                return whole
+            calc_step()
+            fence()
+            if os.environ.get("BENCH_CALC_PROFILE"):      # where the host time of the calculator leg goes (stderr)
+                import cProfile
+                import pstats
+                pr = cProfile.Profile()
+                pr.enable()
+                calc_step()
+                fence()
+                pr.disable()
+                pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
+            t1 = time.perf_counter()
+            for _ in range(n_e2e):
+                whole = calc_step()
+            fence()
+            dtc = (time.perf_counter() - t1) / n_e2e
+            # rows equal to the resident-vector run (job order = this rank's slot order at one rank)
+            hr = rows.cpu().numpy()
+            for slot, j in enumerate(mine):
+                name = vecs[slot].name
+                assert whole.chroms[name].ccbins == hr[j, ffi.PMX_ROW_NCC_CCBINS].tolist(), "calculator ncc differs"
+                assert whole.chroms[name].forward_sum == int(hr[j, ffi.PMX_ROW_SCALARS, 0])
+                if with_m:
+                    mc = whole.mappable_chroms[name]
+                    assert mc.ccbins == hr[j, ffi.PMX_ROW_MSCC_CCBINS].tolist(), "calculator mscc.ccbins differ"
+                    assert mc.forward_sum == hr[j, ffi.PMX_ROW_MSCC_FSUM].tolist() and mc.reverse_sum == hr[j, ffi.PMX_ROW_MSCC_RSUM].tolist()
+            nreads = sum(r[0].size for r in reads.values())
+            calc_leg = {"value": work_per_step / dtc, "unit": "shifts*bp/s", "ms_per_step": dtc * 1e3, "steps": n_e2e,
+                        "reads": int(nreads), "reads_per_s": nreads / dtc,
+                        "h2d_bytes": int(sum(r[0].nbytes + getattr(r[1], "nbytes", 0) + r[2].nbytes for r in reads.values())
+                                         + sum(t[0].nbytes + t[1].nbytes for t in tracks.values())),
+                        "what": "CCHipCalculator (the class handler/factory.py constructs): feed_reads(chrom, int32 pos, read "
+                                "length (one int per chromosome where all reads have it, else uint16), uint8 strand; page-locked "
+                                "arrays in file order) per chromosome -> pmx_feed_reads "
+                                "(duplicate rules + read-length sums + bit set on the device) -> finishup_calculation (one batched "
+                                "pmx_cc_batch_dev, one synchronisation, one copy back) -> get_whole_result (the reference's result "
+                                "objects, cc curves computed); rows equal to the resident-vector run"}
+        for h in host:
+            for a in h:
+                if a is not None:
+                    ctx.host_free(a)
 
     result = {
         "metric": "shifts*genome-bp/sec (whole node), hg38 max_shift=1000; HBM-BW fraction",
@@ -463,6 +557,7 @@ def main():
         "kernel_ms_per_step": kernel_ms_per_step,
         "value_end_to_end": end_to_end["value"] if end_to_end else None,
         "end_to_end": end_to_end,
+        "end_to_end_calculator": calc_leg,
         "gen_seconds": round(t_gen, 2),
     }
 

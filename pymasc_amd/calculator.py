@@ -6,20 +6,25 @@ same exceptions (ReadUnsortedError / KeyError) and value-equal result objects, s
 ``PyMaSC/handler/factory.py:224-258`` can construct it instead of the Cython class.
 
 What is different underneath (MI355X-first, not a translation):
-* reads are not written into a host bit array one Python call at a time; positions are appended to
-  host arrays and, when the chromosome ends, uploaded once and scattered into HBM bit-vectors by a
-  HIP kernel (``pmx_bits_set_positions``); mappability intervals go through ``pmx_bits_set_regions``;
-* the (max_shift+1)-iteration loop of full-vector passes (mscc.pyx:288-317) is ONE call,
-  ``pmx_cc_dev``, whose kernels read each vector from HBM once;
-* read-length sums and duplicate rules (mscc.pyx:388-392, :416-418) are evaluated vectorised on the
-  host at flush time from the same position arrays.
+* nothing waits for the GPU until results are asked for.  Reads fed one by one are appended to host arrays; reads fed in
+  bulk (``feed_reads``) go straight to the device, where ``pmx_feed_reads`` applies the reference's per-read rules --
+  sortedness, the forward / reverse duplicate rules, read-length sums (mscc.pyx:362-366,388-392,416-418) -- and sets the
+  bits; mappability intervals go through ``pmx_bits_set_regions_async``.  The host never walks the reads;
+* every chromosome keeps HBM bit-vectors of its own (a pool on the context; 288 GB hold many genomes) and ``flush`` only
+  queues it: the (max_shift+1)-iteration loop of full-vector passes (mscc.pyx:288-317) of ALL chromosomes queued since
+  the last fetch is ONE batched call, ``pmx_cc_batch_dev``, whose kernels read each vector from HBM once; the lag pass
+  of the read-less references (mscc.pyx:207-215, one per reference in ``finishup_calculation``) is one batched call too;
+* ``get_result`` / ``finishup_calculation`` / ``get_whole_result`` (and the public result attributes) run what is
+  queued, synchronise ONCE, copy the result arena back in one piece and build the reference's result objects.  Errors
+  the device found inside a bulk chunk (``ReadUnsortedError``, ``IndexError``) are raised then; the per-read methods
+  raise them at once, like the reference.
 
 There is no CPU compute fallback: constructing the calculator without a visible GPU raises.
 """
 from __future__ import annotations
 
 import logging
-from typing import Any, Dict, List, Optional, Sequence
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -35,35 +40,43 @@ DENSE_READS_PER_BP = 0.0105      # reads of one strand per position above which 
 DENSE_RUNS_PER_BP = 0.0025       # mappable runs per position above which it is passed (the event kernel lists 384 edges per 64 Kbit)
 
 
-class _PosBuffer:
-    """Append-only (position, readlen) arrays; amortised O(1) per read, no Python list of ints."""
+class _ReadBuffer:
+    """Append-only (position, readlen, strand) arrays in file order for the per-read protocol methods; amortised O(1) per
+    read, no Python list of ints.  Handed to the device in one piece when the chromosome ends."""
 
-    __slots__ = ("pos", "rlen", "n")
+    __slots__ = ("pos", "rlen", "rev", "n")
 
     def __init__(self):
         self.pos = np.empty(_CHUNK, dtype=np.int64)
         self.rlen = np.empty(_CHUNK, dtype=np.int64)
+        self.rev = np.empty(_CHUNK, dtype=np.uint8)
         self.n = 0
 
-    def append(self, pos: int, rlen: int):
+    def append(self, pos: int, rlen: int, rev: int):
         if self.n == self.pos.size:
             self.pos = np.concatenate([self.pos, np.empty(self.pos.size, dtype=np.int64)])
             self.rlen = np.concatenate([self.rlen, np.empty(self.rlen.size, dtype=np.int64)])
+            self.rev = np.concatenate([self.rev, np.empty(self.rev.size, dtype=np.uint8)])
         self.pos[self.n] = pos
         self.rlen[self.n] = rlen
+        self.rev[self.n] = rev
         self.n += 1
 
-    def extend(self, pos: np.ndarray, rlen: np.ndarray):
-        k = pos.size
-        while self.n + k > self.pos.size:
-            self.pos = np.concatenate([self.pos, np.empty(self.pos.size, dtype=np.int64)])
-            self.rlen = np.concatenate([self.rlen, np.empty(self.rlen.size, dtype=np.int64)])
-        self.pos[self.n:self.n + k] = pos
-        self.rlen[self.n:self.n + k] = rlen
-        self.n += k
+    def take(self):
+        """The buffered reads as arrays of their own (the buffer is reused while the copy to the device may still run)."""
+        n, self.n = self.n, 0
+        return self.pos[:n].copy(), self.rlen[:n].copy(), self.rev[:n].copy()
 
-    def view(self):
-        return self.pos[:self.n], self.rlen[:self.n]
+
+class _Pending:
+    """One chromosome whose kernels are queued: where its rows / feed state will be, and what to build from them."""
+
+    __slots__ = ("chrom", "slot", "kind", "has_m", "known", "glen", "nreads", "vecs", "nbits", "flags")
+
+    def __init__(self, chrom, slot, kind, has_m=False, known=None, glen=0, nreads=0, vecs=(), nbits=0, flags=0):
+        self.chrom, self.slot, self.kind, self.has_m, self.known, self.glen, self.nreads = (
+            chrom, slot, kind, has_m, known, glen, nreads)
+        self.vecs, self.nbits, self.flags = vecs, nbits, flags     # [(device pointer, pool capacity)]: F, R[, M]
 
 
 class CCHipCalculator:
@@ -84,7 +97,7 @@ class CCHipCalculator:
         self.skip_ncc = bool(skip_ncc)
         self.logger_lock = logger_lock
         self._bwfeeder = bwfeeder
-        self._progress = progress_bar
+        self._progress = progress_bar       # accepted for the reference's constructor signature; not driven
         self._kernel_flags = int(kernel_flags)
         # the result block of the C ABI keeps four scalars in a row of max_shift + 1 words, so the kernels are run
         # with at least 3 shifts; shifts are independent, rows are cut back to max_shift + 1 below
@@ -93,37 +106,94 @@ class CCHipCalculator:
         # found here skip the autocorrelation pass
         self._known_mlen: Dict[str, Sequence[int]] = dict(chrom2mappable_len or {})
 
-        self.ref2ncc_result: Dict[str, NCCResult] = {}
-        self.ref2mscc_result: Dict[str, MSCCResult] = {}
-        self.forward_sum = self.reverse_sum = 0
-        self.forward_read_len_sum = self.reverse_read_len_sum = 0
+        self._ncc: Dict[str, NCCResult] = {}
+        self._mscc: Dict[str, MSCCResult] = {}
+        self._forward_sum = self._reverse_sum = 0
+        self._forward_read_len_sum = self._reverse_read_len_sum = 0
 
         self._chr = ""
         self._solved_chr: List[str] = []
         self._buff_flashed = False
         self._array_extend_size = self.read_len + self.max_shift + self.EXTRA_ALLOCATE_SIZE   # mscc.pyx:134
         self._last_pos = 0
-        self._fwd = _PosBuffer()
-        self._rev = _PosBuffer()
+        self._cur_nbits = 0
+        self._buf = _ReadBuffer()
+        self._fed = 0                 # reads of the current chromosome handed to the device so far
+        self._cur_slot = -1
+        self._cur_vecs: List[Tuple[int, int]] = []
 
         # the one and only compute back-end; raises ffi.PmxError when no GPU / no library
         self._ctx = context if context is not None else ffi.Context(device)
         self._own_ctx = context is None
-        self._dev_bits: Dict[str, List[int]] = {}     # name -> [device pointer, capacity in bits]
-        self._d_out = 0
-        self._d_out_words = 0
+        # Every chromosome gets bit-vectors of its own from the context's pool and keeps them until results are fetched:
+        # the cross-correlation of ALL chromosomes queued by then is ONE batched pass of the kernels (pmx_cc_batch_dev),
+        # not a launch chain per chromosome.  288 GB of HBM hold hundreds of genomes' worth of vectors; `max_resident_bytes`
+        # bounds what one calculator keeps before it runs the batch early.
+        self.max_resident_bytes = 64 << 30
+        self._resident_bytes = 0
+        # result arena: one slot per reference = a result block + a feed state, filled by the queued kernels and read
+        # back in ONE copy when results are asked for
+        self._slot_words = ffi.PMX_NROWS * (self._kshift + 1) + ffi.PMX_FEED_WORDS
+        self._arena = 0
+        self._arena_slots = 0
+        self._free_slots: List[int] = []
+        self._pending: List[_Pending] = []
+        self._readless: List[Tuple[str, int, Tuple[int, int]]] = []     # (chrom, slot, M vector) awaiting the batched lag pass
+        self._inflight: List[Any] = []                      # host arrays whose copies may still be running
+
+    # ---- the reference's public attributes, current as soon as they are read -------------------------------
+    @property
+    def ref2ncc_result(self) -> Dict[str, NCCResult]:
+        self._materialize()
+        return self._ncc
+
+    @property
+    def ref2mscc_result(self) -> Dict[str, MSCCResult]:
+        self._materialize()
+        return self._mscc
+
+    @property
+    def forward_sum(self) -> int:
+        self._materialize()
+        return self._forward_sum
+
+    @property
+    def reverse_sum(self) -> int:
+        self._materialize()
+        return self._reverse_sum
+
+    @property
+    def forward_read_len_sum(self) -> int:
+        self._materialize()
+        return self._forward_read_len_sum
+
+    @property
+    def reverse_read_len_sum(self) -> int:
+        self._materialize()
+        return self._reverse_read_len_sum
 
     # ---- plumbing ------------------------------------------------------------------------------
     def close(self):
         ctx = getattr(self, "_ctx", None)
         if ctx is None:
             return
-        for ptr, _cap in self._dev_bits.values():
-            ctx.bits_free(ptr)
-        self._dev_bits.clear()
-        if self._d_out:
-            ctx.bits_free(self._d_out)
-            self._d_out = 0
+        try:
+            ctx.sync()
+        except Exception:
+            pass
+        for p in self._pending:
+            for ptr, cap in p.vecs:
+                ctx.pool_free(ptr, cap)
+        self._pending = []
+        for v in getattr(self, "_cur_vecs", []):
+            ctx.pool_free(*v)
+        self._cur_vecs = []
+        for _c, _s, (d_m, cap) in self._readless:
+            ctx.pool_free(d_m, cap)
+        self._readless = []
+        if self._arena:
+            ctx.bits_free(self._arena)
+            self._arena = 0
         if self._own_ctx:
             ctx.close()
         self._ctx = None
@@ -141,31 +211,34 @@ class CCHipCalculator:
         if self.logger_lock:
             self.logger_lock.release()
 
-    def _device_vector(self, name: str, nbits: int) -> int:
-        """A zeroed HBM bit-vector of >= nbits, reused across chromosomes (grow-only)."""
-        slot = self._dev_bits.get(name)
-        if slot is None or slot[1] < nbits:
-            if slot is not None:
-                self._ctx.bits_free(slot[0])
-            cap = int(nbits * 1.25) + 4096 if slot is not None else int(nbits)
-            self._dev_bits[name] = slot = [self._ctx.bits_alloc(cap), cap]
-        else:
-            self._ctx.bits_clear(slot[0], slot[1])
-        return slot[0]
+    def _vector(self, nbits: int):
+        """(pointer, pool capacity) of a zeroed HBM bit-vector of >= nbits (the clear is queued on the stream)."""
+        ptr, cap = self._ctx.pool_alloc(nbits)
+        self._ctx.bits_clear(ptr, nbits)
+        self._resident_bytes += cap // 8
+        return ptr, cap
 
-    def _device_out(self, words: int) -> int:
-        if self._d_out_words < words:
-            if self._d_out:
-                self._ctx.bits_free(self._d_out)
-            self._d_out = self._ctx.bits_alloc(words * 64)
-            self._d_out_words = words
-        return self._d_out
+    def _new_slot(self) -> int:
+        """A cleared arena slot (result block + feed state)."""
+        if not self._arena:
+            self._arena_slots = len(self.references) + 2
+            self._arena = self._ctx.bits_alloc(self._arena_slots * self._slot_words * 64)
+            self._free_slots = list(range(self._arena_slots - 1, -1, -1))
+        if not self._free_slots:
+            self._materialize()                     # (gives the slots of everything fetched back)
+        return self._free_slots.pop()            # (cleared: a fresh arena is zero-filled, _materialize clears what it fetched)
+
+    def _slot_ptr(self, slot: int) -> int:
+        return self._arena + slot * self._slot_words * 8
+
+    def _state_ptr(self, slot: int) -> int:
+        return self._slot_ptr(slot) + ffi.PMX_NROWS * (self._kshift + 1) * 8
 
     # ---- feeding (mscc.pyx:351-418) --------------------------------------------------------------
     def _init_buff(self):
         self._last_pos = 0
-        self._fwd.n = 0
-        self._rev.n = 0
+        self._buf.n = 0
+        self._fed = 0
 
     def _check_pos(self, chrom: str, pos: int, bit: Optional[int] = None, what: str = ""):
         if chrom != self._chr:
@@ -178,6 +251,7 @@ class CCHipCalculator:
             self._chr = chrom
             self._init_buff()
             self._cur_nbits = self.ref2genomelen[chrom] + self._array_extend_size   # mscc.pyx:165-167
+            self._cur_slot = -1             # its vectors are cleared and its slot taken when the first reads go to the device
             self._logging_info("Loading {} reads to bit array...".format(chrom))
         if bit is not None:
             self._check_bit(chrom, bit, what)
@@ -195,105 +269,90 @@ class CCHipCalculator:
     def feed_forward_read(self, chrom: str, pos: int, readlen: int) -> None:
         """1-based 5' position of a forward read (mscc.pyx:370-393)."""
         self._check_pos(chrom, pos, pos, "forward")
-        self._fwd.append(pos, readlen)
+        self._buf.append(pos, readlen, 0)
 
     def feed_reverse_read(self, chrom: str, pos: int, readlen: int) -> None:
         """1-based leftmost position of a reverse read; its bit is pos + readlen - 1 (mscc.pyx:397-418)."""
         self._check_pos(chrom, pos, pos + readlen - 1, "reverse")
-        self._rev.append(pos, readlen)
+        self._buf.append(pos, readlen, 1)
+
+    def _start_chromosome_on_device(self):
+        if self._cur_slot < 0:
+            self._cur_slot = self._new_slot()
+            self._cur_vecs = [self._vector(self._cur_nbits), self._vector(self._cur_nbits)]
+            self._d_f, self._d_r = self._cur_vecs[0][0], self._cur_vecs[1][0]
+
+    def _to_device(self, pos: np.ndarray, readlen: np.ndarray, rev: np.ndarray):
+        """Queues a run of reads of the current chromosome: copy + the reference's duplicate rules + bit set on the device
+        (pmx_feed_reads).  Nothing is read back here."""
+        if pos.size == 0:
+            return
+        self._start_chromosome_on_device()
+        self._inflight.append(self._ctx.feed_reads(self._d_f, self._d_r, self._cur_nbits, pos, readlen, rev, self._fed,
+                                                   self._state_ptr(self._cur_slot)))
+        self._fed += int(pos.size)
 
     def feed_reads(self, chrom: str, pos: np.ndarray, readlen: np.ndarray, is_reverse: np.ndarray) -> None:
-        """Bulk variant of the two methods above for one chromosome: arrays in file order.
-        Not part of the reference protocol; it removes the per-read Python call for vectorised readers."""
-        pos = np.ascontiguousarray(pos, dtype=np.int64)
-        readlen = np.ascontiguousarray(readlen, dtype=np.int64)
-        is_reverse = np.asarray(is_reverse, dtype=bool)
+        """Bulk variant of the two methods above for one chromosome: arrays in file order (int32 or int64 positions,
+        uint16 / int32 / int64 read lengths or ONE int when every read of the chunk has that length, strand as bool / uint8).  Not part of the reference protocol; it removes the per-read Python call for
+        vectorised readers, and the host does not walk the reads at all: the order of the chunk against the reads fed
+        before is checked here (first position), everything else -- order inside the chunk, range, duplicates, read-length
+        sums -- by the device, so ReadUnsortedError / IndexError for a read inside the chunk are raised when the results
+        of the chromosome are fetched (flush + get_result, finishup_calculation), not by this call."""
+        pos = np.asarray(pos)
         if pos.size == 0:
             return
         self._check_pos(chrom, int(pos[0]))
-        if pos.size > 1 and (np.diff(pos) < 0).any():
-            raise ReadUnsortedError
-        fpos, rbit = pos[~is_reverse], pos[is_reverse] + readlen[is_reverse] - 1
-        if fpos.size:
-            self._check_bit(chrom, int(fpos.min()), "forward")
-            self._check_bit(chrom, int(fpos.max()), "forward")
-        if rbit.size:
-            self._check_bit(chrom, int(rbit.min()), "reverse")
-            self._check_bit(chrom, int(rbit.max()), "reverse")
-        self._last_pos = int(pos[-1])
-        self._fwd.extend(fpos, readlen[~is_reverse])
-        self._rev.extend(pos[is_reverse], readlen[is_reverse])
+        if self._buf.n:                              # reads fed one by one before this chunk go first
+            self._to_device(*self._buf.take())
+        self._to_device(pos, readlen if np.ndim(readlen) == 0 else np.asarray(readlen), np.asarray(is_reverse))
+        self._last_pos = max(self._last_pos, int(pos[-1]))
 
     # ---- per-chromosome calculation ---------------------------------------------------------------
-    def _load_mappability(self, chrom: str, nbits: int) -> Optional[int]:
-        """mscc.pyx:327-349 -> device vector, or None without a feeder; KeyError if the track is missing."""
+    def _load_mappability(self, chrom: str, nbits: int):
+        """mscc.pyx:327-349 -> (device vector, pool capacity), queued, not waited for; None without a feeder; KeyError if
+        the track is missing."""
         if not self._bwfeeder:
             return None
         bulk = getattr(self._bwfeeder, "fetch_arrays", None)
         if bulk is not None:          # pymasc_amd.bigwig.BigWigReader: arrays, no per-interval Python objects
-            begin, end, _v = bulk(self.MAPPABILITY_THRESHOLD, chrom)
-            first, last = begin.astype(np.int64) + 1, end.astype(np.int64)
+            first, last, _v = bulk(self.MAPPABILITY_THRESHOLD, chrom)
         else:
             iv = [(b, e) for b, e, _v in self._bwfeeder.fetch(self.MAPPABILITY_THRESHOLD, chrom)]
             arr = np.asarray(iv, dtype=np.int64).reshape(-1, 2)
-            first, last = arr[:, 0] + 1, arr[:, 1].copy()
+            first, last = arr[:, 0].copy(), arr[:, 1].copy()
         self._logging_info("Loading {} mappability to bit array...".format(chrom))
-        d_m = self._device_vector("M", nbits)
+        vec = self._vector(nbits)
         if first.size:
-            self._ctx.bits_set_regions(d_m, nbits, first, last)   # set(begin + 1, end), mscc.pyx:343-344
+            # set(begin + 1, end), mscc.pyx:343-344 (the + 1 is applied on the device; an end beyond the vector is clipped)
+            self._inflight.append(self._ctx.bits_set_regions_async(vec[0], nbits, first, last, 1, None))
         self._n_runs = int(first.size)   # two run edges per interval: the other density the event kernel's lists depend on
-        return d_m
+        return vec
 
     def _calc_correlation(self):
         chrom = self._chr
         S, L = self.max_shift, self.read_len
         glen = self.ref2genomelen[chrom]
         nbits = glen + self._array_extend_size
-
-        fpos, flen = self._fwd.view()
-        rpos, rlen = self._rev.view()
-        # forward: a read at the same position as the previous forward read is a duplicate (:388-392)
-        if fpos.size:
-            keep = np.empty(fpos.size, dtype=bool)
-            keep[0] = fpos[0] != 0
-            np.not_equal(fpos[1:], fpos[:-1], out=keep[1:])
-            f_read_len_sum = int(flen[keep].sum())
-            fbits = fpos[keep]
-        else:
-            f_read_len_sum, fbits = 0, fpos
-        # reverse: first read to hit a 3' position sets the bit and counts (:416-418)
-        if rpos.size:
-            p3 = rpos + rlen - 1
-            uniq, first = np.unique(p3, return_index=True)
-            r_read_len_sum = int(rlen[first].sum())
-            rbits = uniq
-        else:
-            r_read_len_sum, rbits = 0, rpos
-        self.forward_read_len_sum += f_read_len_sum
-        self.reverse_read_len_sum += r_read_len_sum
-
-        for arr, what in ((fbits, "forward"), (rbits, "reverse")):
-            if arr.size and (arr.min() < 0 or arr.max() >= nbits):
-                raise IndexError("{} read beyond the bit array of {} (position {}, {} bits)".format(
-                    what, chrom, int(arr.max()), nbits))
-
-        d_f = self._device_vector("F", nbits)
-        d_r = self._device_vector("R", nbits)
-        self._ctx.bits_set_positions(d_f, nbits, fbits)
-        self._ctx.bits_set_positions(d_r, nbits, rbits)
+        if self._buf.n:
+            self._to_device(*self._buf.take())
+        self._start_chromosome_on_device()          # (a chromosome whose reads were all refused still gets its rows)
+        slot = self._cur_slot
 
         try:
-            d_m = self._load_mappability(chrom, nbits)
+            m_vec = self._load_mappability(chrom, nbits)
         except KeyError as e:
             self._logging_info("Mappability for '{}' not found. "
                                "Skip calc mappability sensitive CC.".format(e.args[0] if e.args else chrom))
-            d_m = None
+            m_vec = None
+        d_m = m_vec[0] if m_vec is not None else None
 
         self._logging_info("Calculate cross-correlation for {}...".format(chrom))
         flags = self._kernel_flags | (ffi.PMX_FLAG_SKIP_NCC if self.skip_ncc else 0)
         # deep data: above ~1 % read starts per position and strand every tile overflows the event kernel's lists
-        # (EV_CAPF / EV_CAPR per 64 Kbit) -- say so instead of letting it find out (same integers either way)
-        if max(fbits.size, rbits.size) > DENSE_READS_PER_BP * max(glen, 1):
+        # (EV_CAPF / EV_CAPR per 64 Kbit) -- say so instead of letting it find out (same integers either way).  The
+        # strand split is not known on the host (the device walks the reads): half the reads fed stands for a strand.
+        if 0.5 * self._fed > DENSE_READS_PER_BP * max(glen, 1):
             flags |= ffi.PMX_FLAG_WINDOW_ONLY
         if d_m is not None and getattr(self, "_n_runs", 0) > DENSE_RUNS_PER_BP * max(glen, 1):
             flags |= ffi.PMX_FLAG_WINDOW_ONLY   # a track of short runs (> ~330 run edges per 64 Kbit on average)
@@ -303,67 +362,129 @@ class CCHipCalculator:
             known = None
         if known is not None:
             flags |= ffi.PMX_FLAG_SKIP_MLEN
-        KS = self._kshift
-        words = ffi.PMX_NROWS * (KS + 1)
-        d_out = self._device_out(words)
-        self._ctx.cc_dev(d_f, d_r, d_m, nbits, KS, L, flags, d_out)
-        out = self._ctx.bits_download(d_out, words * 64).reshape(ffi.PMX_NROWS, KS + 1)
-
-        if not self.skip_ncc:
-            fsum = int(out[ffi.PMX_ROW_SCALARS, 0])
-            rsum = int(out[ffi.PMX_ROW_SCALARS, 1])
-            self.forward_sum += fsum
-            self.reverse_sum += rsum
-            res = self.ref2ncc_result[chrom] = NCCResult(
-                max_shift=S, read_len=L, genomelen=glen, forward_sum=fsum, reverse_sum=rsum,
-                forward_read_len_sum=f_read_len_sum, reverse_read_len_sum=r_read_len_sum,
-                ccbins=[int(x) for x in out[ffi.PMX_ROW_NCC_CCBINS, :S + 1]])
-            res.calc_cc()
-        if d_m is not None:
-            by_shift = out[ffi.PMX_ROW_MLEN] if known is None else [known[abs(c - d)] for d in range(S + 1)]
-            # the reference stores mappable_len by LAG: d < L -> index L-1-d, L <= d < 2L-1 skipped
-            # (same value by symmetry), d >= 2L-1 appended (mscc.pyx:271,292-298)
-            mlen: List[Optional[int]] = [None] * L
-            for d in range(S + 1):
-                if d < L:
-                    mlen[L - d - 1] = int(by_shift[d])
-                elif d >= 2 * L - 1:
-                    mlen.append(int(by_shift[d]))
-            mres = self.ref2mscc_result[chrom] = MSCCResult(
-                max_shift=S, read_len=L, genomelen=glen,
-                forward_sum=[int(x) for x in out[ffi.PMX_ROW_MSCC_FSUM, :S + 1]],
-                reverse_sum=[int(x) for x in out[ffi.PMX_ROW_MSCC_RSUM, :S + 1]],
-                forward_read_len_sum=f_read_len_sum, reverse_read_len_sum=r_read_len_sum,
-                ccbins=[int(x) for x in out[ffi.PMX_ROW_MSCC_CCBINS, :S + 1]], mappable_len=mlen)
-            mres.calc_cc()
+        # queued for the batched pass (_run_cc): the vectors stay resident until then
+        vecs = self._cur_vecs + ([m_vec] if m_vec is not None else [])
+        self._cur_vecs = []
+        self._pending.append(_Pending(chrom, slot, "cc", has_m=d_m is not None, known=known, glen=glen, nreads=self._fed,
+                                      vecs=vecs, nbits=nbits, flags=flags))
+        self._cur_slot = -1
+        if self._resident_bytes > self.max_resident_bytes:
+            self._materialize()
 
     def _fill_result(self, chrom: str):
-        """Placeholders / read-less mappable_len (mscc.pyx:181-215)."""
+        """Placeholders / read-less mappable_len (mscc.pyx:181-215).  The lag pass of read-less chromosomes is queued for ONE
+        batched launch (finishup_calculation walks every reference: 86 in the reference's test BAM, mscc.pyx:436-439)."""
         self._chr = chrom
         S, L = self.max_shift, self.read_len
         glen = self.ref2genomelen[chrom]
-        if chrom not in self.ref2ncc_result:
-            self.ref2ncc_result[chrom] = EmptyNCCResult.create_empty(glen, S, L)
-        if not self._bwfeeder or chrom in self.ref2mscc_result:
+        queued = {p.chrom for p in self._pending}
+        if chrom not in self._ncc and not (chrom in queued and not self.skip_ncc):
+            self._ncc[chrom] = EmptyNCCResult.create_empty(glen, S, L)
+        has_mscc = chrom in self._mscc or any(p.chrom == chrom and (p.has_m or p.kind == "mlen") for p in self._pending)
+        if not self._bwfeeder or has_mscc:
             return
-        result = self.ref2mscc_result[chrom] = EmptyMSCCResult.create_empty(glen, S, L)
+        result = self._mscc[chrom] = EmptyMSCCResult.create_empty(glen, S, L)
         nbits = glen + self._array_extend_size
         known = self._known_mlen.get(chrom)
         if known is not None and len(known) > S:      # cached table long enough: no track load, no kernel
             result.mappable_len = tuple(int(x) for x in known[:S + 1])
             return
         try:
-            d_m = self._load_mappability(chrom, nbits)
-            if d_m is None:
+            m_vec = self._load_mappability(chrom, nbits)
+            if m_vec is None:
                 raise KeyError(chrom)
         except KeyError:
             return
         self._logging_info("Calc {} mappable length...".format(chrom))
-        KS = self._kshift
-        d_out = self._device_out(ffi.PMX_NROWS * (KS + 1))
-        self._ctx.mappable_len_dev(d_m, nbits, KS, self._kernel_flags, d_out)
-        out = self._ctx.bits_download(d_out, (KS + 1) * 64)
-        result.mappable_len = tuple(int(x) for x in out[:S + 1])
+        self._readless.append((chrom, self._new_slot(), m_vec))
+
+    def _run_cc(self):
+        """_calc_correlation's loop (mscc.pyx:288-317) for every chromosome queued since the last fetch: one batched pass per
+        group of chromosomes that share the kernel flags (normally one group)."""
+        groups: Dict[Tuple[int, bool], List[_Pending]] = {}
+        for p in self._pending:
+            if p.kind == "cc":
+                groups.setdefault((p.flags, p.has_m), []).append(p)
+        for (flags, has_m), ps in groups.items():
+            self._ctx.cc_batch_dev([p.vecs[0][0] for p in ps], [p.vecs[1][0] for p in ps],
+                                   [p.vecs[2][0] for p in ps] if has_m else None, [p.nbits for p in ps], self._kshift,
+                                   self.read_len, flags, [self._slot_ptr(p.slot) for p in ps])
+
+    def _run_readless(self):
+        if not self._readless:
+            return
+        nb = [self.ref2genomelen[c] + self._array_extend_size for c, _s, _m in self._readless]
+        self._ctx.mappable_len_batch_dev([m[0] for _c, _s, m in self._readless], nb, self._kshift, self._kernel_flags,
+                                         [self._slot_ptr(s) for _c, s, _m in self._readless])
+        for chrom, slot, m_vec in self._readless:
+            self._pending.append(_Pending(chrom, slot, "mlen", glen=self.ref2genomelen[chrom], vecs=[m_vec]))
+
+    def _materialize(self):
+        """Everything queued -> result objects: ONE synchronisation and ONE copy of the arena, then the deferred errors of
+        the chunks fed in bulk, then the reference's result classes."""
+        if not self._pending and not self._readless:
+            return
+        self._run_cc()
+        self._run_readless()
+        S, L, KS = self.max_shift, self.read_len, self._kshift
+        pending, self._pending = self._pending, []
+        readless, self._readless = self._readless, []
+        hi = max(p.slot for p in pending) + 1
+        raw = self._ctx.bits_download(self._arena, hi * self._slot_words * 64)     # synchronises
+        self._free_slots.extend(p.slot for p in pending)
+        self._ctx.bits_clear(self._arena, hi * self._slot_words * 64)      # one clear for every slot handed out again
+        self._inflight = []
+        for p in pending:                            # (the synchronising copy above is behind every kernel that read them)
+            for ptr, cap in p.vecs:
+                self._ctx.pool_free(ptr, cap)
+                self._resident_bytes -= cap // 8
+            p.vecs = ()
+        raw = raw.reshape(-1, self._slot_words)
+        nrow = ffi.PMX_NROWS * (KS + 1)
+        c = L - 1
+        error: Optional[BaseException] = None
+        for p in pending:
+            out = raw[p.slot, :nrow].reshape(ffi.PMX_NROWS, KS + 1)
+            st = raw[p.slot, nrow:]
+            if p.kind == "mlen":
+                self._mscc[p.chrom].mappable_len = tuple(out.reshape(-1)[:S + 1].tolist())
+                continue
+            # what the device found in the chunks fed in bulk: raised once everything fetched has been stored
+            if int(st[ffi.PMX_FEED_FIRST_UNSORTED]) and error is None:
+                error = ReadUnsortedError("read {} of {} is below its predecessor".format(
+                    ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_UNSORTED]), p.chrom))
+            if int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) and error is None:
+                error = IndexError("read {} of {} beyond its bit array ({} bits)".format(
+                    ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]), p.chrom, p.glen + self._array_extend_size))
+            f_rls, r_rls = int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]), int(st[ffi.PMX_FEED_REVERSE_LEN_SUM])
+            self._forward_read_len_sum += f_rls
+            self._reverse_read_len_sum += r_rls
+            if not self.skip_ncc:
+                fsum, rsum = int(out[ffi.PMX_ROW_SCALARS, 0]), int(out[ffi.PMX_ROW_SCALARS, 1])
+                self._forward_sum += fsum
+                self._reverse_sum += rsum
+                res = self._ncc[p.chrom] = NCCResult(
+                    max_shift=S, read_len=L, genomelen=p.glen, forward_sum=fsum, reverse_sum=rsum,
+                    forward_read_len_sum=f_rls, reverse_read_len_sum=r_rls,
+                    ccbins=out[ffi.PMX_ROW_NCC_CCBINS, :S + 1].tolist())
+                res.calc_cc()
+            if p.has_m:
+                by_shift = out[ffi.PMX_ROW_MLEN].tolist() if p.known is None else [int(p.known[abs(c - d)]) for d in range(S + 1)]
+                # the reference stores mappable_len by LAG: d < L -> index L-1-d, L <= d < 2L-1 skipped
+                # (same value by symmetry), d >= 2L-1 appended (mscc.pyx:271,292-298)
+                head = by_shift[:min(L, S + 1)][::-1]
+                mlen: List[Optional[int]] = [None] * (L - len(head)) + head
+                if S >= 2 * L - 1:
+                    mlen += by_shift[2 * L - 1:S + 1]
+                mres = self._mscc[p.chrom] = MSCCResult(
+                    max_shift=S, read_len=L, genomelen=p.glen,
+                    forward_sum=out[ffi.PMX_ROW_MSCC_FSUM, :S + 1].tolist(),
+                    reverse_sum=out[ffi.PMX_ROW_MSCC_RSUM, :S + 1].tolist(),
+                    forward_read_len_sum=f_rls, reverse_read_len_sum=r_rls,
+                    ccbins=out[ffi.PMX_ROW_MSCC_CCBINS, :S + 1].tolist(), mappable_len=mlen)
+                mres.calc_cc()
+        if error is not None:
+            raise error
 
     # ---- lifecycle (mscc.pyx:173-179, :420-483) -----------------------------------------------------
     def flush(self, chrom: Optional[str] = None) -> None:
@@ -377,24 +498,27 @@ class CCHipCalculator:
         self.flush(self._chr)
         for chrom in self.references:
             self._fill_result(chrom)
+        self._materialize()
 
     def get_result(self, chrom: str) -> BothChromResult:
-        if chrom not in self.ref2ncc_result and chrom not in self.ref2mscc_result:
+        self._materialize()
+        if chrom not in self._ncc and chrom not in self._mscc:
             raise KeyError(chrom)
-        return BothChromResult(chrom=self.ref2ncc_result.get(chrom), mappable_chrom=self.ref2mscc_result.get(chrom))
+        return BothChromResult(chrom=self._ncc.get(chrom), mappable_chrom=self._mscc.get(chrom))
 
     def get_whole_result(self):
-        if not self.ref2mscc_result:
-            assert self.ref2ncc_result, "No results available for either NCC or MSCC."
+        self._materialize()
+        if not self._mscc:
+            assert self._ncc, "No results available for either NCC or MSCC."
             return NCCGenomeWideResult(
-                genomelen=self.genomelen, forward_sum=self.forward_sum, reverse_sum=self.reverse_sum,
-                chroms=self.ref2ncc_result.copy(), forward_read_len_sum=self.forward_read_len_sum,
-                reverse_read_len_sum=self.reverse_read_len_sum)
-        if not self.ref2ncc_result:
+                genomelen=self.genomelen, forward_sum=self._forward_sum, reverse_sum=self._reverse_sum,
+                chroms=self._ncc.copy(), forward_read_len_sum=self._forward_read_len_sum,
+                reverse_read_len_sum=self._reverse_read_len_sum)
+        if not self._ncc:
             return MSCCGenomeWideResult(
-                genomelen=self.genomelen, chroms=self.ref2mscc_result.copy(),
-                forward_read_len_sum=self.forward_read_len_sum, reverse_read_len_sum=self.reverse_read_len_sum)
+                genomelen=self.genomelen, chroms=self._mscc.copy(),
+                forward_read_len_sum=self._forward_read_len_sum, reverse_read_len_sum=self._reverse_read_len_sum)
         return BothGenomeWideResult(
-            genomelen=self.genomelen, forward_sum=self.forward_sum, reverse_sum=self.reverse_sum,
-            chroms=self.ref2ncc_result.copy(), mappable_chroms=self.ref2mscc_result.copy(),
-            forward_read_len_sum=self.forward_read_len_sum, reverse_read_len_sum=self.reverse_read_len_sum)
+            genomelen=self.genomelen, forward_sum=self._forward_sum, reverse_sum=self._reverse_sum,
+            chroms=self._ncc.copy(), mappable_chroms=self._mscc.copy(),
+            forward_read_len_sum=self._forward_read_len_sum, reverse_read_len_sum=self._reverse_read_len_sum)

@@ -21,25 +21,35 @@
 
 template <typename T>
 __device__ __forceinline__ int64_t feed_ld(const T *p, uint64_t i) { return (int64_t)p[i]; }
+// read lengths: an array, or (null pointer) ONE length for every read of the run
+template <typename T>
+__device__ __forceinline__ int64_t feed_len(const T *p, int64_t uniform, uint64_t i) { return p ? (int64_t)p[i] : uniform; }
 
 template <typename LT>
-__global__ void __launch_bounds__(256) k_feed_maxlen(const LT *__restrict__ rlen, const unsigned char *__restrict__ rev, uint64_t n,
-                                                     u64 *__restrict__ state)
+__global__ void __launch_bounds__(256) k_feed_maxlen(const LT *__restrict__ rlen, int64_t ulen, const unsigned char *__restrict__ rev,
+                                                     uint64_t n, u64 *__restrict__ state)
 {
     u64 m = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t l = feed_ld(rlen, i);
+        const int64_t l = feed_len(rlen, ulen, i);
         if (rev[i] && l > 0 && (u64)l > m) m = (u64)l;
     }
     for (int off = 32; off > 0; off >>= 1) {
         const u64 o = __shfl_down(m, off, 64);
         m = o > m ? o : m;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&state[PMX_FEED_MAX_REVERSE_LEN], m);
+    // one atomic per BLOCK: thousands of waves adding to one address serialise in L2 (96 us for 8 K waves)
+    __shared__ u64 part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) m = part[w] > m ? part[w] : m;
+        if (m > state[PMX_FEED_MAX_REVERSE_LEN]) atomicMax(&state[PMX_FEED_MAX_REVERSE_LEN], m);
+    }
 }
 
 template <typename PT, typename LT>
-__global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, const LT *__restrict__ rlen,
+__global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, const LT *__restrict__ rlen, int64_t ulen,
                                                     const unsigned char *__restrict__ rev, uint64_t n, uint64_t base, uint64_t nbits,
                                                     u64 *__restrict__ F, const u64 *__restrict__ R, u64 *__restrict__ state)
 {
@@ -49,7 +59,7 @@ __global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, 
     u64 fsum = 0, rsum = 0, nf = 0, nr = 0, maxf = 0, e_sort = 0, e_range = 0;
     bool any_f = false;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t p = feed_ld(pos, i), l = feed_ld(rlen, i);
+        const int64_t p = feed_ld(pos, i), l = feed_len(rlen, ulen, i);
         const bool rv = rev[i] != 0;
         const int64_t before = i ? feed_ld(pos, i - 1) : prev_last;
         if (p < before) {                                                               // mscc.pyx:362-363
@@ -79,7 +89,7 @@ __global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, 
             for (uint64_t j = i; !set && j > 0; j--) {
                 const int64_t pj = feed_ld(pos, j - 1);
                 if (pj < lowest) break;
-                set = rev[j - 1] != 0 && pj + feed_ld(rlen, j - 1) - 1 == bit;
+                set = rev[j - 1] != 0 && pj + feed_len(rlen, ulen, j - 1) - 1 == bit;
             }
             if (!set) {
                 rsum += (u64)l;
@@ -98,26 +108,45 @@ __global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, 
         e_sort = b > e_sort ? b : e_sort;
         e_range = c > e_range ? c : e_range;
     }
+    // block sums / maxima through LDS, then one atomic per block and word (per-wave atomics on a handful of addresses took
+    // 0.3 ms per chromosome: they serialise in L2)
+    __shared__ u64 part[4][8];
+    const u32 wv = threadIdx.x >> 6;
     const bool wave_any_f = __ballot(any_f) != 0;
     if ((threadIdx.x & 63) == 0) {
-        if (fsum) atomicAdd(&state[PMX_FEED_FORWARD_LEN_SUM], fsum);
-        if (rsum) atomicAdd(&state[PMX_FEED_REVERSE_LEN_SUM], rsum);
-        if (nf) atomicAdd(&state[PMX_FEED_FORWARD_KEPT], nf);
-        if (nr) atomicAdd(&state[PMX_FEED_REVERSE_KEPT], nr);
-        if (wave_any_f) atomicMax(&state[PMX_FEED_CHUNK_FORWARD_POS], maxf + 1);        // (+1: 0 = no forward read in the chunk)
-        if (e_sort) atomicMax(&state[PMX_FEED_FIRST_UNSORTED], e_sort);
-        if (e_range) atomicMax(&state[PMX_FEED_FIRST_OUT_OF_RANGE], e_range);
+        part[wv][0] = fsum;
+        part[wv][1] = rsum;
+        part[wv][2] = nf;
+        part[wv][3] = nr;
+        part[wv][4] = wave_any_f ? maxf + 1 : 0;     // (+1: 0 = no forward read in the chunk)
+        part[wv][5] = e_sort;
+        part[wv][6] = e_range;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const u32 k = threadIdx.x;
+        u64 v = part[0][k];
+        for (int w = 1; w < 4; w++) v = k < 4 ? v + part[w][k] : (part[w][k] > v ? part[w][k] : v);
+        if (v) {
+            if (k == 0) atomicAdd(&state[PMX_FEED_FORWARD_LEN_SUM], v);
+            else if (k == 1) atomicAdd(&state[PMX_FEED_REVERSE_LEN_SUM], v);
+            else if (k == 2) atomicAdd(&state[PMX_FEED_FORWARD_KEPT], v);
+            else if (k == 3) atomicAdd(&state[PMX_FEED_REVERSE_KEPT], v);
+            else if (k == 4) atomicMax(&state[PMX_FEED_CHUNK_FORWARD_POS], v);
+            else if (k == 5) atomicMax(&state[PMX_FEED_FIRST_UNSORTED], v);
+            else atomicMax(&state[PMX_FEED_FIRST_OUT_OF_RANGE], v);
+        }
     }
 }
 
 template <typename PT, typename LT>
-__global__ void __launch_bounds__(256) k_feed_finish(const PT *__restrict__ pos, const LT *__restrict__ rlen,
+__global__ void __launch_bounds__(256) k_feed_finish(const PT *__restrict__ pos, const LT *__restrict__ rlen, int64_t ulen,
                                                      const unsigned char *__restrict__ rev, uint64_t n, uint64_t nbits,
                                                      u64 *__restrict__ R, u64 *__restrict__ state)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         if (!rev[i]) continue;
-        const int64_t bit = feed_ld(pos, i) + feed_ld(rlen, i) - 1;
+        const int64_t bit = feed_ld(pos, i) + feed_len(rlen, ulen, i) - 1;
         if (bit >= 0 && (uint64_t)bit < nbits) atomicOr(&R[bit >> 6], 1ull << (bit & 63));   // mscc.pyx:416-417
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -176,10 +205,10 @@ __global__ void __launch_bounds__(256) k_set_positions_t(u64 *__restrict__ words
     }
 }
 
-static int feed_grid(pmx_ctx *ctx, uint64_t items, int per_block)
+static int feed_grid(pmx_ctx *ctx, uint64_t items, int per_block, int per_cu = 8)
 {
     uint64_t blocks = (items + per_block - 1) / per_block;
-    const uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -187,31 +216,36 @@ static int feed_grid(pmx_ctx *ctx, uint64_t items, int per_block)
 
 template <typename PT, typename LT>
 static int launch_feed(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *d_pos, const void *d_len,
-                       const unsigned char *d_rev, uint64_t n, uint64_t base, u64 *d_state)
+                       int64_t ulen, const unsigned char *d_rev, uint64_t n, uint64_t base, u64 *d_state)
 {
-    const int g = feed_grid(ctx, n, 256);
-    hipLaunchKernelGGL(k_feed_maxlen<LT>, dim3(g), dim3(256), 0, ctx->stream, (const LT *)d_len, d_rev, n, d_state);
+    const int g = feed_grid(ctx, n, 1024, 4);   // (every block ends in a few atomics on the state words)
+    hipLaunchKernelGGL(k_feed_maxlen<LT>, dim3(g), dim3(256), 0, ctx->stream, (const LT *)d_len, ulen, d_rev, n, d_state);
     PMX_CHECK_LAUNCH("k_feed_maxlen");
-    hipLaunchKernelGGL((k_feed_reads<PT, LT>), dim3(g), dim3(256), 0, ctx->stream, (const PT *)d_pos, (const LT *)d_len, d_rev, n,
+    hipLaunchKernelGGL((k_feed_reads<PT, LT>), dim3(g), dim3(256), 0, ctx->stream, (const PT *)d_pos, (const LT *)d_len, ulen, d_rev, n,
                        base, nbits, (u64 *)d_F, (const u64 *)d_R, d_state);
     PMX_CHECK_LAUNCH("k_feed_reads");
-    hipLaunchKernelGGL((k_feed_finish<PT, LT>), dim3(g), dim3(256), 0, ctx->stream, (const PT *)d_pos, (const LT *)d_len, d_rev, n,
+    hipLaunchKernelGGL((k_feed_finish<PT, LT>), dim3(g), dim3(256), 0, ctx->stream, (const PT *)d_pos, (const LT *)d_len, ulen, d_rev, n,
                        nbits, (u64 *)d_R, d_state);
     PMX_CHECK_LAUNCH("k_feed_finish");
     return PMX_OK;
 }
 
 int pmx_launch_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *d_pos, uint32_t pos_bytes,
-                          const void *d_len, uint32_t len_bytes, const unsigned char *d_rev, uint64_t n, uint64_t base,
-                          uint64_t *d_state)
+                          const void *d_len, uint32_t len_bytes, int64_t uniform_len, const unsigned char *d_rev, uint64_t n,
+                          uint64_t base, uint64_t *d_state)
 {
     if (n == 0) return PMX_OK;
     u64 *st = (u64 *)d_state;
-    if (pos_bytes == 4 && len_bytes == 4) return launch_feed<int32_t, int32_t>(ctx, d_F, d_R, nbits, d_pos, d_len, d_rev, n, base, st);
-    if (pos_bytes == 4 && len_bytes == 8) return launch_feed<int32_t, int64_t>(ctx, d_F, d_R, nbits, d_pos, d_len, d_rev, n, base, st);
-    if (pos_bytes == 8 && len_bytes == 4) return launch_feed<int64_t, int32_t>(ctx, d_F, d_R, nbits, d_pos, d_len, d_rev, n, base, st);
-    if (pos_bytes == 8 && len_bytes == 8) return launch_feed<int64_t, int64_t>(ctx, d_F, d_R, nbits, d_pos, d_len, d_rev, n, base, st);
-    pmx_set_error("pmx_feed_reads: positions and read lengths must be 4 or 8 bytes wide (int32 / int64)");
+    if (len_bytes == 0) d_len = nullptr;     // one length for every read
+#define FEED(PT, LT) return launch_feed<PT, LT>(ctx, d_F, d_R, nbits, d_pos, d_len, uniform_len, d_rev, n, base, st)
+    if (pos_bytes == 4 && (len_bytes == 4 || len_bytes == 0)) FEED(int32_t, int32_t);
+    if (pos_bytes == 8 && (len_bytes == 8 || len_bytes == 0)) FEED(int64_t, int64_t);
+    if (pos_bytes == 4 && len_bytes == 2) FEED(int32_t, uint16_t);
+    if (pos_bytes == 8 && len_bytes == 2) FEED(int64_t, uint16_t);
+    if (pos_bytes == 4 && len_bytes == 8) FEED(int32_t, int64_t);
+    if (pos_bytes == 8 && len_bytes == 4) FEED(int64_t, int32_t);
+#undef FEED
+    pmx_set_error("pmx_feed_reads: positions must be 4 or 8 bytes wide (int32 / int64), read lengths 2, 4 or 8 (uint16 / int32 / int64) or 0 (uniform)");
     return PMX_ERR_INVALID;
 }
 

@@ -159,8 +159,33 @@ class Context:
         self.device = int(device)
 
     # -- lifecycle
+    # -- a pool of device bit-vectors: calculators of successive samples on one context reuse each other's allocations
+    # (hipMalloc / hipFree synchronise; 288 GB of HBM hold the vectors of many genomes)
+    _POOL_GRANULE = 1 << 22          # bits
+
+    def pool_alloc(self, nbits: int):
+        """(device pointer, capacity in bits) of a bit-vector of >= nbits from the context's pool.  NOT cleared."""
+        cap = -(-int(nbits) // self._POOL_GRANULE) * self._POOL_GRANULE
+        free = self.__dict__.setdefault("_pool", {}).setdefault(cap, [])
+        if free:
+            return free.pop(), cap
+        return self.bits_alloc(cap), cap
+
+    def pool_free(self, d_words: int, cap: int):
+        self.__dict__.setdefault("_pool", {}).setdefault(int(cap), []).append(d_words)
+
+    def pool_release(self):
+        for cap, ptrs in self.__dict__.get("_pool", {}).items():
+            for p in ptrs:
+                self.bits_free(p)
+        self._pool = {}
+
     def close(self):
         if getattr(self, "_h", None):
+            try:
+                self.pool_release()
+            except Exception:
+                pass
             for p in list(getattr(self, "_pinned", {}).values()):
                 self._L.pmx_host_free(self._h, ctypes.c_void_p(p))
             self._pinned = {}
@@ -251,22 +276,31 @@ class Context:
     @staticmethod
     def _int_array(a: np.ndarray, what: str) -> np.ndarray:
         a = np.asarray(a)
-        if a.dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+        ok = (np.dtype(np.int32), np.dtype(np.int64)) + ((np.dtype(np.uint16),) if what == "readlen" else ())
+        if a.dtype not in ok:
             a = a.astype(np.int64)
         return np.ascontiguousarray(a)
 
     def feed_reads(self, d_F: int, d_R: int, nbits: int, pos: np.ndarray, readlen: np.ndarray, is_reverse: np.ndarray,
                    reads_before: int, d_state: int):
-        """pmx_feed_reads: a run of reads of one chromosome in file order (int32 / int64 arrays, strand as bool / uint8).
+        """pmx_feed_reads: a run of reads of one chromosome in file order (int32 / int64 positions, uint16 / int32 / int64
+        read lengths -- or ONE int for a run of reads of the same length --, strand as bool / uint8; other integer types are
+        converted).
         Returns the arrays actually handed over: keep them alive until the next synchronising call."""
         pos = self._int_array(pos, "pos")
-        readlen = self._int_array(readlen, "readlen")
         rev = np.ascontiguousarray(is_reverse)
         if rev.dtype != np.uint8:
             rev = rev.view(np.uint8) if rev.dtype == np.bool_ else rev.astype(np.uint8)
-        assert pos.size == readlen.size == rev.size
+        if np.ndim(readlen) == 0:                    # one length for every read of the run: nothing to copy for it
+            readlen = np.array([int(readlen)], dtype=np.int64)
+            len_bytes = 0
+            assert pos.size == rev.size
+        else:
+            readlen = self._int_array(readlen, "readlen")
+            len_bytes = readlen.dtype.itemsize
+            assert pos.size == readlen.size == rev.size
         _check(self._L, self._L.pmx_feed_reads(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R), int(nbits), pos.ctypes.data,
-                                               pos.dtype.itemsize, readlen.ctypes.data, readlen.dtype.itemsize, rev.ctypes.data,
+                                               pos.dtype.itemsize, readlen.ctypes.data, len_bytes, rev.ctypes.data,
                                                pos.size, int(reads_before), ctypes.c_void_p(d_state)))
         return pos, readlen, rev
 

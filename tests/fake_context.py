@@ -7,9 +7,35 @@ from oracle import model as oracle
 from pymasc_amd import ffi
 
 
+class _View:
+    """dict-like access to the fake device memory by ANY address inside an allocation (the calculator hands out slots of
+    one arena as base + offset)."""
+
+    def __init__(self):
+        self.blocks = {}
+
+    def __setitem__(self, p, arr):
+        self.blocks[p] = arr
+
+    def pop(self, p, default=None):
+        return self.blocks.pop(p, default)
+
+    def clear(self):
+        self.blocks.clear()
+
+    def __getitem__(self, p):
+        if p in self.blocks:
+            return self.blocks[p]
+        for base, arr in self.blocks.items():
+            if base <= p < base + arr.size * 8:
+                assert (p - base) % 8 == 0
+                return arr[(p - base) // 8:]
+        raise KeyError(p)
+
+
 class FakeContext:
     def __init__(self):
-        self._mem = {}
+        self._mem = _View()
         self._next = 0x1000
 
     def close(self):
@@ -20,12 +46,22 @@ class FakeContext:
 
     def bits_alloc(self, nbits):
         p = self._next
-        self._next += 0x1000
+        self._next += (ffi.nwords(nbits) * 8 + 0x1fff) & ~0xfff
         self._mem[p] = np.zeros(ffi.nwords(nbits), dtype=np.uint64)
         return p
 
     def bits_free(self, p):
         self._mem.pop(p, None)
+
+    def pool_alloc(self, nbits):
+        return self.bits_alloc(nbits), nbits
+
+    def pool_free(self, p, cap):
+        self.bits_free(p)
+
+    def cc_batch_dev(self, d_F, d_R, d_M, nbits, max_shift, read_len, flags, d_out):
+        for i in range(len(d_F)):
+            self.cc_dev(d_F[i], d_R[i], d_M[i] if d_M else None, nbits[i], max_shift, read_len, flags, d_out[i])
 
     def bits_clear(self, p, nbits):
         self._mem[p][:ffi.nwords(nbits)] = 0
@@ -76,3 +112,55 @@ class FakeContext:
     def mappable_len_dev(self, d_M, nbits, max_shift, flags, d_out):
         M = np.ascontiguousarray(self._mem[d_M][:ffi.nwords(nbits)])
         self._mem[d_out][:max_shift + 1] = oracle.mappable_len_readless(M, nbits, max_shift).astype(np.uint64)
+
+    # ---- the stream-ordered feeders (pmx_feed_reads, pmx_bits_set_regions_async, pmx_mappable_len_batch_dev): the reference's
+    # per-read rules restated read by read (mscc.pyx:351-418), state words as in include/pymasc_amd.h
+    def feed_reads(self, d_F, d_R, nbits, pos, readlen, is_reverse, reads_before, d_state):
+        F, R, st = self._mem[d_F], self._mem[d_R], self._mem[d_state]
+        pos, rev = np.asarray(pos).tolist(), np.asarray(is_reverse).astype(bool).tolist()
+        readlen = [int(readlen)] * len(pos) if np.ndim(readlen) == 0 else np.asarray(readlen).tolist()
+        last = int(st[ffi.PMX_FEED_LAST_POS]) if reads_before else 0
+        last_f = int(st[ffi.PMX_FEED_LAST_FORWARD_POS])
+        fs = rs = nf = nr = 0
+        for i, (p, l, r) in enumerate(zip(pos, readlen, rev)):
+            if p < last and not int(st[ffi.PMX_FEED_FIRST_UNSORTED]):
+                st[ffi.PMX_FEED_FIRST_UNSORTED] = ffi.PMX_FEED_ERR_BASE - (reads_before + i)
+            last = p
+            bit = p + l - 1 if r else p
+            if bit < 0 or bit >= nbits:
+                if not int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]):
+                    st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE] = ffi.PMX_FEED_ERR_BASE - (reads_before + i)
+                continue
+            w, m = bit >> 6, np.uint64(1) << np.uint64(bit & 63)
+            if not r:
+                if p == last_f:
+                    continue
+                last_f = p
+                fs += l
+                nf += 1
+                F[w] |= m
+            elif not int(R[w]) & int(m):
+                R[w] |= m
+                rs += l
+                nr += 1
+        st[ffi.PMX_FEED_FORWARD_LEN_SUM] += np.uint64(fs)
+        st[ffi.PMX_FEED_REVERSE_LEN_SUM] += np.uint64(rs)
+        st[ffi.PMX_FEED_FORWARD_KEPT] += np.uint64(nf)
+        st[ffi.PMX_FEED_REVERSE_KEPT] += np.uint64(nr)
+        st[ffi.PMX_FEED_LAST_POS] = max(last, 0)
+        st[ffi.PMX_FEED_LAST_FORWARD_POS] = last_f
+        st[ffi.PMX_FEED_READS] += np.uint64(len(pos))
+        return pos, readlen, rev
+
+    def bits_set_regions_async(self, p, nbits, first, last, first_offset=0, d_state=None):
+        w = self._mem[p]
+        for a, b in zip(np.asarray(first).tolist(), np.asarray(last).tolist()):
+            a += first_offset
+            b = min(b, nbits - 1)
+            if b >= a:
+                oracle.lib().pmo_set_region(oracle._p(w), int(a), int(b))
+        return first, last
+
+    def mappable_len_batch_dev(self, d_M, nbits, max_shift, flags, d_out):
+        for m, nb, o in zip(d_M, nbits, d_out):
+            self.mappable_len_dev(m, nb, max_shift, flags, o)

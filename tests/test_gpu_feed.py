@@ -53,7 +53,8 @@ def device_feed(ctx, pos, rlen, rev, nbits, cuts, pdt, ldt):
     return F, R, st
 
 
-@pytest.mark.parametrize("pdt,ldt", [(np.int32, np.int32), (np.int64, np.int64), (np.int32, np.int64), (np.int64, np.int32)])
+@pytest.mark.parametrize("pdt,ldt", [(np.int32, np.int32), (np.int64, np.int64), (np.int32, np.int64), (np.int64, np.int32),
+                                     (np.int32, np.uint16), (np.int64, np.uint16)])
 @pytest.mark.parametrize("nchunks", [1, 2, 7])
 def test_feed_reads_matches_the_reference_rules(ctx, nchunks, pdt, ldt):
     S, L, glen = 300, 36, 200000
@@ -87,6 +88,23 @@ def test_chunk_boundaries_inside_runs_of_equal_positions(ctx):
     np.testing.assert_array_equal(F, wF)
     np.testing.assert_array_equal(R, wR)
     assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+
+
+def test_uniform_read_length_as_a_scalar(ctx):
+    S, L, glen = 200, 36, 100000
+    rng = np.random.default_rng(17)
+    pos, rlen, rev = make_reads(rng, 20000, glen, lens=(50,))
+    wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
+    d_F, d_R, d_st = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits), ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    k1 = ctx.feed_reads(d_F, d_R, nbits, pos[:9000].astype(np.int32), 50, rev[:9000], 0, d_st)
+    k2 = ctx.feed_reads(d_F, d_R, nbits, pos[9000:], 50, rev[9000:], 9000, d_st)
+    np.testing.assert_array_equal(ctx.bits_download(d_F, nbits), wF)
+    np.testing.assert_array_equal(ctx.bits_download(d_R, nbits), wR)
+    st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+    assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+    for d in (d_F, d_R, d_st):
+        ctx.bits_free(d)
+    del k1, k2
 
 
 def test_first_unsorted_and_first_out_of_range_read_are_recorded(ctx):

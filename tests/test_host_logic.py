@@ -144,11 +144,24 @@ def test_a_read_beyond_the_vector_is_refused_when_it_is_fed():
     calc.feed_forward_read("a", nbits - 1, 36)           # last bit of the vector
     with pytest.raises(IndexError):
         calc.feed_forward_read("a", nbits, 36)
+    # a chunk fed in bulk is walked by the device only: its out-of-range read (dropped there) is reported when the results
+    # of the chromosome are fetched, after everything fetched has been stored
+    calc.feed_reads("b", np.array([10, nbits + 5]), np.array([36, 36]), np.array([False, False]))
     with pytest.raises(IndexError):
-        calc.feed_reads("b", np.array([10, nbits + 5]), np.array([36, 36]), np.array([False, False]))
-    calc.feed_forward_read("b", 20, 36)
-    calc.finishup_calculation()
+        calc.finishup_calculation()
     assert calc.get_result("a").chrom.forward_sum == 2 and calc.get_result("b").chrom.forward_sum == 1
+
+
+def test_an_unsorted_read_inside_a_bulk_chunk_is_reported_when_results_are_fetched():
+    calc = CCHipCalculator(50, 36, ["a", "b"], [5000, 5000], context=FakeContext())
+    calc.feed_reads("a", np.array([10, 300, 200, 400]), np.array([36] * 4), np.array([False, True, False, True]))
+    with pytest.raises(ReadUnsortedError):
+        calc.flush("a")
+        calc.get_result("a")
+    calc = CCHipCalculator(50, 36, ["a", "b"], [5000, 5000], context=FakeContext())
+    calc.feed_reads("a", np.array([10, 300]), np.array([36] * 2), np.array([False, True]))
+    with pytest.raises(ReadUnsortedError):       # the first read of a chunk against the reads fed before: at once
+        calc.feed_reads("a", np.array([299, 400]), np.array([36] * 2), np.array([False, True]))
 
 
 def test_get_result_unknown_chrom_is_keyerror():

@@ -75,8 +75,14 @@ def test_an_exception_in_the_launcher_leaves_no_rank_behind(monkeypatch):
         started.append(p)
         return p
 
-    def interrupt(_seconds):
-        raise KeyboardInterrupt
+    real_sleep = launch.time.sleep
+    calls = []
+
+    def interrupt(seconds):          # (launch.time IS the time module: only the launcher's first poll is interrupted)
+        calls.append(seconds)
+        if len(calls) == 1:
+            raise KeyboardInterrupt
+        real_sleep(seconds)
 
     monkeypatch.setattr(launch.subprocess, "Popen", recording_popen)
     monkeypatch.setattr(launch.time, "sleep", interrupt)
