@@ -52,6 +52,11 @@ def parse():
                          "and gap lengths sampled from the reference's test track hg19_36mer-test.bedGraph (860 run edges "
                          "per 64 Kbit, 23 %% mappable: the only real-track statistics available offline), tiled to the genome")
     ap.add_argument("--chroms", type=int, default=24, help="use only the first K hg38 chromosomes (debug)")
+    ap.add_argument("--run-on", type=float, default=2000.0, help="synthetic track: mean mappable run length (BASELINE.md: 2000)")
+    ap.add_argument("--run-off", type=float, default=500.0, help="synthetic track: mean gap between runs (BASELINE.md: 500)")
+    ap.add_argument("--no-hint", action="store_true",
+                    help="do not pass PMX_FLAG_WINDOW_ONLY for dense reads / run edges (what CCHipCalculator derives from the "
+                         "counts it holds): the kernels find out by themselves (sweeps)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="one rank only: initialise a 1-rank process group and run the exchange through its collectives "
                          "(RCCL all_gather_into_tensor + all_reduce on the second stream) instead of the local shortcut")
@@ -259,7 +264,8 @@ def main():
         s, i = jobs[j]
         name, length = chroms[i]
         vecs.append(synth.make_chromosome(ctx, device, f"{name}.s{s}", length, S, L, 0xC0FFEE + i + 1000 * s,
-                                          density=args.density, with_m=with_m, keep_host=e2e, track=args.track))
+                                          density=args.density, with_m=with_m, keep_host=e2e, track=args.track,
+                                          mean_on=args.run_on, mean_off=args.run_off))
     t_gen = time.perf_counter() - t_gen
     total_bp = sum(costs)
 
@@ -279,7 +285,8 @@ def main():
     from pymasc_amd.calculator import DENSE_READS_PER_BP, DENSE_RUNS_PER_BP
     dense_reads = bool(vecs) and max(max(v.n_forward, v.n_reverse) / max(v.length, 1) for v in vecs) > DENSE_READS_PER_BP
     dense_runs = bool(vecs) and with_m and max(v.n_runs / max(v.length, 1) for v in vecs) > DENSE_RUNS_PER_BP
-    step_flags = flags | (ffi.PMX_FLAG_WINDOW_ONLY if (dense_reads or dense_runs) and args.path == "auto" else 0)
+    hinted = (dense_reads or dense_runs) and args.path == "auto" and not args.no_hint
+    step_flags = flags | (ffi.PMX_FLAG_WINDOW_ONLY if hinted else 0)
 
     def step():
         # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev) on tstream, then the exchange
@@ -357,7 +364,8 @@ def main():
     # rocprofv3 passes of this same command: tools/tools_r3_profile.sh -> profiles/r3_traffic*.json).  Quoted only when
     # the summary was measured on THIS build of the library and on this workload.
     workload_tag = (f"{args.workload}/{args.mode}/S{S}/L{L}/rho{args.density}/chroms{len(chroms)}/path{args.path}/"
-                    f"track{args.track}/gpus{world}")
+                    f"track{args.track}" + ("" if (args.run_on, args.run_off) == (2000.0, 500.0) else f"-{args.run_on:g}-{args.run_off:g}")
+                    + ("/nohint" if args.no_hint else "") + f"/gpus{world}")
     traffic, traffic_src = None, None
     prof, why = committed_profile("traffic", workload_tag)
     if prof is not None:
@@ -453,13 +461,28 @@ def main():
             names = [v.name for v in vecs]
             lens = [v.length for v in vecs]
 
+            stamps = []
+
             def calc_step():
+                t0 = time.perf_counter()
                 calc = CCHipCalculator(S, L, names, lens, bwfeeder=TrackFeeder(tracks) if with_m else None, context=ctx)
                 for v in vecs:
                     calc.feed_reads(v.name, *reads[v.name])
-                calc.finishup_calculation()
+                t1 = time.perf_counter()
+                if os.environ.get("BENCH_CALC_PROFILE") == "2" and len(stamps) == 2:
+                    import cProfile
+                    import pstats
+                    pr = cProfile.Profile()
+                    pr.enable()
+                    calc.finishup_calculation()
+                    pr.disable()
+                    pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
+                else:
+                    calc.finishup_calculation()
                 whole = calc.get_whole_result()
+                t2 = time.perf_counter()
                 calc.close()
+                stamps.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
                 return whole
             calc_step()
             fence()
@@ -477,6 +500,9 @@ def main():
                 whole = calc_step()
             fence()
             dtc = (time.perf_counter() - t1) / n_e2e
+            if os.environ.get("BENCH_CALC_PROFILE"):
+                print("[calc leg] feed (host, paced by the copies) / finishup + results / close (ms):",
+                      [[round(x * 1e3, 2) for x in st] for st in stamps[-3:]], file=sys.stderr)
             # rows equal to the resident-vector run (job order = this rank's slot order at one rank)
             hr = rows.cpu().numpy()
             for slot, j in enumerate(mine):
@@ -530,6 +556,9 @@ def main():
                             "; stands in for ENCFF000VPI.bam (configs 2-3), which is not available offline")),
             "mode": args.mode,
             "kernel_path": args.path,
+            "window_only_hint": bool(hinted),
+            "run_edges_per_64kbit": (round(2 * 65536 * sum(v.n_runs for v in vecs) / max(sum(v.length for v in vecs), 1), 1)
+                                     if with_m and vecs else None),
             "parallelism": f"chromosome jobs of {nsamples} genome(s) LPT-sharded over {world} GPU(s), one process per "
                            "GPU; all-gather rows + all-reduce totals on a second stream"
                            + (" (1-rank RCCL group, collectives forced)" if args.force_collectives and world == 1 else ""),

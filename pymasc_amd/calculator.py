@@ -31,7 +31,7 @@ import numpy as np
 from . import ffi
 from .exceptions import ReadUnsortedError
 from .result import (BothChromResult, BothGenomeWideResult, EmptyMSCCResult, EmptyNCCResult, MSCCGenomeWideResult,
-                     MSCCResult, NCCGenomeWideResult, NCCResult)
+                     MSCCResult, NCCGenomeWideResult, NCCResult, calc_cc_batch)
 
 logger = logging.getLogger(__name__)
 
@@ -443,6 +443,10 @@ class CCHipCalculator:
         nrow = ffi.PMX_NROWS * (KS + 1)
         c = L - 1
         error: Optional[BaseException] = None
+        new_ncc: List[NCCResult] = []
+        new_mscc: List[MSCCResult] = []
+        ncc_rows: List[np.ndarray] = []
+        mscc_rows: List[Tuple[np.ndarray, ...]] = []
         for p in pending:
             out = raw[p.slot, :nrow].reshape(ffi.PMX_NROWS, KS + 1)
             st = raw[p.slot, nrow:]
@@ -467,9 +471,13 @@ class CCHipCalculator:
                     max_shift=S, read_len=L, genomelen=p.glen, forward_sum=fsum, reverse_sum=rsum,
                     forward_read_len_sum=f_rls, reverse_read_len_sum=r_rls,
                     ccbins=out[ffi.PMX_ROW_NCC_CCBINS, :S + 1].tolist())
-                res.calc_cc()
+                new_ncc.append(res)
+                ncc_rows.append(out[ffi.PMX_ROW_NCC_CCBINS, :S + 1])
             if p.has_m:
                 by_shift = out[ffi.PMX_ROW_MLEN].tolist() if p.known is None else [int(p.known[abs(c - d)]) for d in range(S + 1)]
+                mscc_rows.append((out[ffi.PMX_ROW_MSCC_CCBINS, :S + 1], out[ffi.PMX_ROW_MSCC_FSUM, :S + 1],
+                                  out[ffi.PMX_ROW_MSCC_RSUM, :S + 1],
+                                  out[ffi.PMX_ROW_MLEN, :S + 1] if p.known is None else np.array(by_shift[:S + 1], dtype=np.uint64)))
                 # the reference stores mappable_len by LAG: d < L -> index L-1-d, L <= d < 2L-1 skipped
                 # (same value by symmetry), d >= 2L-1 appended (mscc.pyx:271,292-298)
                 head = by_shift[:min(L, S + 1)][::-1]
@@ -482,7 +490,10 @@ class CCHipCalculator:
                     reverse_sum=out[ffi.PMX_ROW_MSCC_RSUM, :S + 1].tolist(),
                     forward_read_len_sum=f_rls, reverse_read_len_sum=r_rls,
                     ccbins=out[ffi.PMX_ROW_MSCC_CCBINS, :S + 1].tolist(), mappable_len=mlen)
-                mres.calc_cc()
+                new_mscc.append(mres)
+        # NCCResult.calc_cc / MSCCResult.calc_cc (mscc.pyx:320-323), all chromosomes at once, from the rows as fetched
+        calc_cc_batch(new_ncc, new_mscc, np.stack(ncc_rows).astype(np.int64) if ncc_rows else None,
+                      tuple(np.stack([r[k] for r in mscc_rows]).astype(np.int64) for k in range(4)) if mscc_rows else None)
         if error is not None:
             raise error
 

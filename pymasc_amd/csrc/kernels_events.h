@@ -36,7 +36,10 @@
 #define EV_HI 36u                         // ... and above it (read_len - 1 bits, + the partners' M bits)
 #define EV_CAPF 768u                      // list capacities = the dense-tile thresholds (read density ~1 % per strand)
 #define EV_CAPR 1000u                     // reverse reads of the tile + of the max_shift bits above it (< 1024: rank field)
-#define EV_CAPE 384u                      // run edges of everything staged
+#ifndef EV_CAPE_SMALL
+#define EV_CAPE_SMALL 1024u               // run edges of everything staged, max_shift <= 1023 (EV_CAPE(BIG): the LDS of the BIG
+#endif                                    // instantiations is spent on histograms, their edge list stays at 384)
+#define EV_CAPE(BIG) ((BIG) ? 384u : EV_CAPE_SMALL)
 #define EV_POS 0x1ffffu                   // 17 bits of biased position (BIG: 16384 + 65536 + 8192 + 1152 staged bits at most)
 #define EV_PAD 12u                        // sentinel entries behind the read lists
 #define EV_RSENT 0x3fffffffu              // reverse-list sentinel: beyond every range, and (sentinel - lo) stays positive as
@@ -98,7 +101,7 @@ struct EvLds {
     static constexpr u32 LF = 0;                                    // (+EV_PAD: sentinels; the loops read ahead of their entry)
     static constexpr u32 LR = LF + EV_CAPF + EV_PAD;
     static constexpr u32 LE = LR + EV_CAPR + EV_PAD;
-    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE + 4 : 0u);      // WT: [5][4 waves] scan totals
+    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE(BIG) + 4 : 0u);   // WT: [5][4 waves] scan totals
     static constexpr u32 MISC = WT + 32;
     static constexpr u32 IDXF = MISC + 16;                          // u16 per 512-bit block of the tile (+ end): list index of
     static constexpr u32 IDXR = IDXF + (HAS_M ? 66u : 0u);          // its first forward / reverse read
@@ -413,7 +416,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             // Too many READS only: the cross-correlation window kernel takes it, but its run edges are still listed here for the
             // edge pairs of the mappable-length pass (DO_MLEN), so that deep data on an ordinary track does not push that pass onto
             // its window kernel as well.
-            const bool dense_e = HAS_M && nE > EV_CAPE;
+            const bool dense_e = HAS_M && nE > EV_CAPE(BIG);
             const bool dense_r = nF > EV_CAPF || nR > EV_CAPR;
             dense = dense_e || dense_r;
             do_edges = HAS_M && !dense_e && (!dense || DO_MLEN);
@@ -474,10 +477,12 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 cntU += pendU;
             }
             if (NSG == 1) {
-                // stretch state (uniform): the second tile in a row FAR above the capacities (deep data, not a marginal density or a
-                // local pile-up) ends this workgroup's work in the chromosome.  Marginal tiles are flagged one by one: handing
-                // whole ranges over on their account would leave the window kernel with a few fully loaded workgroups.
-                dense_run = (2 * nF > 3 * EV_CAPF || 2 * nR > 3 * EV_CAPR || dense_e) ? dense_run + 1 : 0u;   // (run edges: dense stretches of a track are regional, the capacity itself is the trigger)
+                // stretch state (uniform): the second DENSE tile in a row ends this workgroup's work in the chromosome: its
+                // remaining tiles go to the window kernels unseen.  A density right at a list capacity (about half the tiles
+                // overflow) or above it would otherwise pay for staging + counting every tile here AND for the window kernel
+                // on most of them (round 2: +30 % between 1.1 % and 2 % reads per strand, +40 % at 330-370 run edges per
+                // tile); isolated dense tiles -- a pile-up, a repeat -- are still flagged one by one.
+                dense_run = dense ? dense_run + 1 : 0u;
                 if (dense_run >= 2) {
                     const u32 end = pj.tile_end < g1 ? pj.tile_end : g1;   // (pj is still the job of tile g here)
                     for (u32 t = g + 1 + tid; t < end; t += 256) {
@@ -803,7 +808,8 @@ struct EvTailPlan {
 __global__ void __launch_bounds__(EV_TAIL_THREADS)
 k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailPlan plan, const u32 *__restrict__ slab_cc,
               const u32 *__restrict__ slab_ac, const u32 *__restrict__ n_flagged, u32 S, u32 out_stride, u32 has_m, u32 do_ncc,
-              u32 max_lag, u32 lagcap, int32_t c, u32 fused, u32 rowlen, u32 slow_path)
+              u32 max_lag, u32 lagcap, int32_t c, u32 fused, u32 rowlen, u32 slow_path, const u32 *__restrict__ plan_cc,
+              const u32 *__restrict__ plan_ac)
 {
     __shared__ long long part[256];
     __shared__ long long tot[2];
@@ -817,19 +823,30 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
         if (flagged) {
             u64 *P = jb.out2, *N = jb.out2 + lagcap, *scal = jb.out2 + 2 * (size_t)lagcap;
             const size_t stride = (size_t)AC_SEG_ROWS * 1024;
+            // (workgroup ranges: the device-side plan of k_plan_flagged when there is one; empty ranges wrote no segment)
+            const u32 ac_first = plan_ac ? plan_ac[PLAN_JOBWG + 2 * job] : plan.ac_first[job];
+            const u32 ac_last = plan_ac ? plan_ac[PLAN_JOBWG + 2 * job + 1] : plan.ac_last[job];
             for (u32 k = tid; k <= max_lag; k += EV_TAIL_THREADS) {
                 u64 sp = 0, sn = 0;
-                for (u32 w = plan.ac_first[job]; w <= plan.ac_last[job]; w++) {
+#pragma unroll 4
+                for (u32 w = ac_first; w <= ac_last; w++) {
+                    // (a workgroup with an empty range wrote nothing: its segment is read and dropped -- a select, not a
+                    // branch, so that the loads of the unrolled iterations overlap)
+                    const bool live = !plan_ac || plan_ac[w] != plan_ac[w + 1];
                     const u32 *seg = slab_ac + (size_t)(w + job) * stride;
-                    sp += seg[k];
-                    sn += seg[1024 + k];
+                    const u32 vp = seg[k], vn = seg[1024 + k];
+                    sp += live ? vp : 0u;
+                    sn += live ? vn : 0u;
                 }
                 P[k] += sp;
                 N[k] += sn;
             }
             if (tid < 2) {
                 u64 sc = 0;
-                for (u32 w = plan.ac_first[job]; w <= plan.ac_last[job]; w++) sc += slab_ac[(size_t)(w + job) * stride + 2 * 1024 + tid];
+                for (u32 w = ac_first; w <= ac_last; w++) {
+                    const u32 v = slab_ac[(size_t)(w + job) * stride + 2 * 1024 + tid];
+                    sc += (!plan_ac || plan_ac[w] != plan_ac[w + 1]) ? v : 0u;
+                }
                 scal[tid] += sc;
             }
             __threadfence_block();
@@ -870,6 +887,8 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
         // rows of the window kernel's segments: 0 ncc, 1 fsum, 2 cc, 3 rsum, 4 scalars (|F|, |R|)
         const u32 dst_row[4] = {PMX_ROW_NCC_CCBINS, PMX_ROW_MSCC_FSUM, PMX_ROW_MSCC_CCBINS, PMX_ROW_MSCC_RSUM};
         const size_t stride = (size_t)SP_SEG_ROWS * 1024;
+        const u32 cc_first = plan_cc ? plan_cc[PLAN_JOBWG + 2 * job] : plan.cc_first[job];
+        const u32 cc_last = plan_cc ? plan_cc[PLAN_JOBWG + 2 * job + 1] : plan.cc_last[job];
         for (u32 r = 0; r < 4; r++) {
             if (r == 0 ? !do_ncc : !has_m) continue;
             // the rows with prefix sums stay with the block that took them (y = 0); ncc -> y = 2, cc -> y = 3
@@ -878,13 +897,19 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
             for (u32 d = tid; d <= S; d += EV_TAIL_THREADS) {
                 u64 sum = 0;
 #pragma unroll 4
-                for (u32 w = plan.cc_first[job]; w <= plan.cc_last[job]; w++) sum += slab_cc[(size_t)(w + job) * stride + r * 1024 + d];
+                for (u32 w = cc_first; w <= cc_last; w++) {
+                    const u32 v = slab_cc[(size_t)(w + job) * stride + r * 1024 + d];
+                    sum += (!plan_cc || plan_cc[w] != plan_cc[w + 1]) ? v : 0u;
+                }
                 dst[d] += sum;
             }
         }
         if (blockIdx.y == 2 && tid < 2) {
             u64 sc = 0;
-            for (u32 w = plan.cc_first[job]; w <= plan.cc_last[job]; w++) sc += slab_cc[(size_t)(w + job) * stride + 4 * 1024 + tid];
+            for (u32 w = cc_first; w <= cc_last; w++) {
+                const u32 v = slab_cc[(size_t)(w + job) * stride + 4 * 1024 + tid];
+                sc += (!plan_cc || plan_cc[w] != plan_cc[w + 1]) ? v : 0u;
+            }
             jb.out[(size_t)PMX_ROW_SCALARS * out_stride + tid] += sc;
         }
     }

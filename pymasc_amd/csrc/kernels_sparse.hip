@@ -642,7 +642,8 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 template <bool HAS_M, bool DO_NCC, bool CH>
 __global__ void __launch_bounds__(256, CH ? (HAS_M ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
 k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
-            u32 *__restrict__ slab, const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged)
+            u32 *__restrict__ slab, const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged,
+            const u32 *__restrict__ plan)
 {
     if (n_flagged && *n_flagged == 0) return;   // the event kernel took every tile (uniform over the whole grid)
     typedef SpLds<HAS_M> L;
@@ -654,8 +655,10 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     const u32 tid = threadIdx.x;
     const SlotGeom sg = slot_geom(lgG, tid);
 
-    const u32 g0 = blockIdx.x * tiles_per_wg;
-    const u32 g1 = g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles;
+    // tile range of this workgroup: equal shares of the tile sequence, or -- behind the event kernel -- the range
+    // k_plan_flagged cut for it (equal shares of the FLAGGED tiles, see there)
+    const u32 g0 = plan ? plan[blockIdx.x] : blockIdx.x * tiles_per_wg;
+    const u32 g1 = plan ? plan[blockIdx.x + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
     if (g0 >= g1) return;
 
     for (u32 i = tid; i < 40; i += 256) lds[L::ZERO + i] = 0;
@@ -1265,7 +1268,7 @@ __device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 fi
 template <bool CH>
 __global__ void __launch_bounds__(256, CH ? AC_WAVES_CH : AC_WAVES)
 k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab,
-                 const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged)
+                 const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged, const u32 *__restrict__ plan = nullptr)
 {
     typedef AcLds L;
     if (n_flagged && *n_flagged == 0) return;   // the pair kernel took every tile (uniform over the whole grid)
@@ -1277,8 +1280,8 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     const u32 tid = threadIdx.x;
     const SlotGeom sg = slot_geom(lgG, tid);
 
-    const u32 g0 = blockIdx.x * tiles_per_wg;
-    const u32 g1 = g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles;
+    const u32 g0 = plan ? plan[blockIdx.x] : blockIdx.x * tiles_per_wg;          // (see k_cc_sparse)
+    const u32 g1 = plan ? plan[blockIdx.x + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
     if (g0 >= g1) return;
 
     for (u32 i = tid; i < 40; i += 256) lds[L::ZERO + i] = 0;
@@ -1817,6 +1820,113 @@ k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 lagcap, u32 mode, int3
     autocorr_finish_job(jb, part, max_lag, lagcap, mode, c, max_shift, out_stride);
 }
 
+// Work split of a window kernel that runs BEHIND the event / pair kernel and only sees the tiles it flagged.  Equal shares
+// of the tile sequence would leave the flagged stretches (a read-dense or edge-dense region of a chromosome; a range a
+// workgroup of the event kernel handed over) to the one or two workgroups whose share they fall into, with everybody else
+// idle: the window pass then took 70 % of its full-genome time for 10 % of the tiles.  This kernel (one block) cuts the
+// tile sequence into nwg contiguous ranges with equal numbers of FLAGGED tiles instead:
+//   plan[w], w = 0..nwg         range bounds in the launch's global tile sequence (plan[0] = 0, plan[nwg] = total)
+//   plan[PLAN_JOBWG + 2 job..]  first / last workgroup whose range meets the job's tiles (k_events_tail sums their slab
+//                               segments; a workgroup with an empty range wrote none and is skipped there)
+// Contiguous ranges keep the window kernels' per-(workgroup, job) bookkeeping as it is.
+#define PLAN_JOBWG 4096u
+#define PLAN_WORDS (PLAN_JOBWG + 2 * SP_MAXJOBS)
+// The flag array is scanned in its RAW layout (job i's tiles at [flag0_i, flag0_i + ntiles_i) + padding): 16 flags per thread
+// and pass with one 16-byte load, a block scan per pass.
+__global__ void __launch_bounds__(1024)
+k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const unsigned char *__restrict__ flags, u32 raw_flags,
+               const u32 *__restrict__ n_flagged, u32 flags_per_count, u32 *__restrict__ plan)
+{
+    // flags set in the array: the producer counts ITS tiles, each of which sets flags_per_count entries (an event tile is two
+    // tiles of k_cc_sparse; the second may be a padding entry behind the job's last tile: it maps to the next job's first tile,
+    // a valid cut point like any other)
+    const u32 F = *n_flagged * flags_per_count;
+    if (F == 0) return;            // nothing flagged: the window kernel returns at once and nobody reads the plan
+    __shared__ u32 part[16];
+    __shared__ u32 jflag0[SP_MAXJOBS + 1], jtile0[SP_MAXJOBS];
+    __shared__ u32 sb[PLAN_JOBWG];     // the bounds once more, for the job ranges at the end (nwg < PLAN_JOBWG)
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < njobs) {
+        jflag0[tid] = jobs.j[tid].flag0;
+        jtile0[tid] = jobs.j[tid].tile0;
+    }
+    if (tid == 0) jflag0[njobs] = 0xffffffffu;
+    for (u32 w = tid; w <= nwg; w += 1024) {   // (a bound nobody writes -- fewer flags set than counted -- is an empty range)
+        sb[w] = total_tiles;
+        plan[w] = total_tiles;
+    }
+    __syncthreads();
+    u32 running = 0;               // flagged entries before this pass (uniform)
+    for (u32 f0 = 0; f0 < raw_flags; f0 += 1024 * 16) {
+        const u32 f = f0 + 16 * tid;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (f < raw_flags) q = *reinterpret_cast<const uint4 *>(flags + f);
+        const u32 qs[4] = {q.x & 0x01010101u, q.y & 0x01010101u, q.z & 0x01010101u, q.w & 0x01010101u};   // (flags are 0 / 1)
+        const u32 cnt = __popc(qs[0]) + __popc(qs[1]) + __popc(qs[2]) + __popc(qs[3]);
+        u32 x = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 y = __shfl_up(x, off, 64);
+            if (lane >= (u32)off) x += y;
+        }
+        if (lane == 63) part[wave] = x;
+        __syncthreads();
+        u32 rank = running + x - cnt, tot = 0;
+        for (u32 w = 0; w < 16; w++) {
+            if (w < wave) rank += part[w];
+            tot += part[w];
+        }
+        running += tot;
+        __syncthreads();
+        if (cnt) {
+            // workgroup w takes the flagged tiles of rank [w F / nwg, (w + 1) F / nwg): its range starts AT the first of them
+#pragma unroll
+            for (u32 k = 0; k < 16; k++) {
+                if (!((qs[k >> 2] >> (8 * (k & 3))) & 1u)) continue;
+                const u32 w_lo = (u32)(((u64)rank * nwg + F - 1) / F), w_hi = (u32)(((u64)(rank + 1) * nwg + F - 1) / F);
+                if (w_lo < w_hi) {
+                    u32 ji = 0;
+                    while (jflag0[ji + 1] <= f + k) ji++;
+                    const u32 t = jtile0[ji] + (f + k - jflag0[ji]);     // raw flag index -> tile of the launch's sequence
+                    for (u32 w = w_lo; w < w_hi && w < nwg; w++) {
+                        plan[w] = t;
+                        sb[w] = t;
+                    }
+                }
+                rank++;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        plan[0] = 0;
+        plan[nwg] = total_tiles;
+        sb[0] = 0;
+        sb[nwg] = total_tiles;
+    }
+    __syncthreads();
+    if (tid < njobs) {
+        // first = the first workgroup whose range ends above the job's first tile, last = the last one that starts below
+        // its end (the bounds are non-decreasing: two binary searches in LDS)
+        const u32 a = jobs.j[tid].tile0, b = a + jobs.j[tid].ntiles;
+        u32 lo = 0, hi = nwg - 1;
+        while (lo < hi) {                       // smallest w with sb[w + 1] > a
+            const u32 mid = (lo + hi) >> 1;
+            if (sb[mid + 1] > a) hi = mid;
+            else lo = mid + 1;
+        }
+        const u32 first = lo;
+        lo = first;
+        hi = nwg - 1;
+        while (lo < hi) {                       // largest w with sb[w] < b  (w = first qualifies: sb[first] <= a < b)
+            const u32 mid = (lo + hi + 1) >> 1;
+            if (sb[mid] < b) lo = mid;
+            else hi = mid - 1;
+        }
+        plan[PLAN_JOBWG + 2 * tid] = first;
+        plan[PLAN_JOBWG + 2 * tid + 1] = lo;
+    }
+}
+
 #include "kernels_events.h"
 
 // ---- host side ----------------------------------------------------------------------------------------------
@@ -2056,7 +2166,7 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
             memset(&tp, 0, sizeof tp);
             hipLaunchKernelGGL(k_events_tail, dim3(n, 1), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
                                (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)d_nflagged, max_shift, out_stride, 1u,
-                               do_ncc ? 1u : 0u, 0u, 1024u, (int32_t)c, 0u, pl.hn, 0u);
+                               do_ncc ? 1u : 0u, 0u, 1024u, (int32_t)c, 0u, pl.hn, 0u, (const u32 *)nullptr, (const u32 *)nullptr);
             PMX_CHECK_LAUNCH("k_events_tail");
         }
     }
@@ -2078,7 +2188,7 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
         if (rc) return rc;
 #define SP_LAUNCH(HM, NC)                                                                                              \
     hipLaunchKernelGGL((k_cc_sparse<HM, NC, true>), dim3(nwg), dim3(256), 0, ctx->stream, tabW, n, total, tpw, (int32_t)c, 5u, \
-                       ctx->d_slab_fb, (const unsigned char *)d_flags, (const u32 *)d_nflagged)
+                       ctx->d_slab_fb, (const unsigned char *)d_flags, (const u32 *)d_nflagged, (const u32 *)nullptr)
         if (has_m && do_ncc) SP_LAUNCH(true, true);
         else if (has_m) SP_LAUNCH(true, false);
         else SP_LAUNCH(false, true);
@@ -2143,7 +2253,8 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     const bool use_events = events_enabled() && !ctx->window_only && !chunked;
     const bool fuse_mlen = use_events && has_m && fused && njobs <= SP_MAXJOBS && pmx_events_can_fuse_mlen(max_shift, fused_lag);
     unsigned char *d_flags = nullptr, *d_flags_ac = nullptr;
-    u32 *d_nflagged = nullptr;
+    u32 *d_nflagged = nullptr, *d_plan_cc = nullptr, *d_plan_ac = nullptr;
+    size_t flag_bytes_all = 0;     // raw length of a flag array (multiple of 16)
     if (use_events) {
         uint64_t total_flags = 0;
         for (size_t i = 0; i < vjobs.size(); i++) {
@@ -2151,11 +2262,14 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             total_flags += (vjobs[i].job->nbits + SP_TB - 1) / SP_TB + EV_NQ;   // padding: an event tile flags EV_NQ window tiles
         }
         const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
-        int rc = pmx_ensure_flags_cc(ctx, 2 * flag_bytes + 16);
+        int rc = pmx_ensure_flags_cc(ctx, 2 * flag_bytes + 16 + 2 * PLAN_WORDS * sizeof(u32));
         if (rc) return rc;
         d_flags = ctx->d_flags_cc;                   // tiles of the cross-correlation window kernel (32 Kbit)
         d_flags_ac = ctx->d_flags_cc + flag_bytes;   // tiles of the autocorrelation window kernel (64 Kbit), same flag0 per job
         d_nflagged = (u32 *)(ctx->d_flags_cc + 2 * flag_bytes);
+        flag_bytes_all = flag_bytes;
+        d_plan_cc = (u32 *)(ctx->d_flags_cc + 2 * flag_bytes + 16);   // work split of the two window launches (k_plan_flagged)
+        d_plan_ac = d_plan_cc + PLAN_WORDS;
         PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, 2 * flag_bytes + 16, ctx->stream));
         if (fuse_mlen) fused->done = true;   // row MLEN and scalar [2] are written by this call (k_events_tail)
     }
@@ -2221,11 +2335,17 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         rc = use_events ? pmx_ensure_slab_fb(ctx, wwords) : pmx_ensure_slab(ctx, wwords);
         if (rc) return rc;
         u32 *const wslab = use_events ? ctx->d_slab_fb : ctx->d_slab;
+        if (use_events) {
+            // the flagged tiles in equal shares (one small block; returns at once when nothing was flagged)
+            hipLaunchKernelGGL(k_plan_flagged, dim3(1), dim3(1024), 0, ctx->stream, tabW, n, total, nwg, (const unsigned char *)d_flags,
+                               (u32)flag_bytes_all, (const u32 *)d_nflagged, (u32)EV_NQ, d_plan_cc);
+            PMX_CHECK_LAUNCH("k_plan_flagged");
+        }
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, use_events);
         if (rc) return rc;
 #define SP_LAUNCH(HM, NC, CK)                                                                                       \
     hipLaunchKernelGGL((k_cc_sparse<HM, NC, CK>), dim3(nwg), dim3(256), 0, ctx->stream, tabW, n, total, tpw, c, lgG, \
-                       wslab, (const unsigned char *)d_flags, (const u32 *)d_nflagged)
+                       wslab, (const unsigned char *)d_flags, (const u32 *)d_nflagged, (const u32 *)(use_events ? d_plan_cc : nullptr))
         if (chunked) {
             if (has_m && do_ncc) SP_LAUNCH(true, true, true);
             else if (has_m) SP_LAUNCH(true, false, true);
@@ -2267,10 +2387,14 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             plan_launch(ctx, va.data(), n, true, AC_WAVES, &tabA, &total, &tpw, &nwg);
             rc = pmx_ensure_slab_ac(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
             if (rc) return rc;
+            hipLaunchKernelGGL(k_plan_flagged, dim3(1), dim3(1024), 0, ctx->stream, tabA, n, total, nwg, (const unsigned char *)d_flags_ac,
+                               (u32)flag_bytes_all, (const u32 *)(d_nflagged + 1), 1u, d_plan_ac);
+            PMX_CHECK_LAUNCH("k_plan_flagged");
             rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl, true);
             if (rc) return rc;
             hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwg), dim3(256), 0, ctx->stream, tabA, n, total, tpw,
-                               lg_slot_lanes(fused_lag + 1), ctx->d_slab_ac, (const unsigned char *)d_flags_ac, (const u32 *)(d_nflagged + 1));
+                               lg_slot_lanes(fused_lag + 1), ctx->d_slab_ac, (const unsigned char *)d_flags_ac, (const u32 *)(d_nflagged + 1),
+                               (const u32 *)d_plan_ac);
             PMX_CHECK_LAUNCH("k_autocorr_edges");
             rc = pmx_prof_end(ctx, &tl);
             if (rc) return rc;
@@ -2281,7 +2405,8 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         }
         hipLaunchKernelGGL(k_events_tail, dim3(n, 4), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
                            (const u32 *)ctx->d_slab_fb, (const u32 *)ctx->d_slab_ac, (const u32 *)d_nflagged, max_shift, out_stride,
-                           has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c, fuse_mlen ? 1u : 0u, 1024u, 1u);
+                           has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c, fuse_mlen ? 1u : 0u, 1024u, 1u,
+                           (const u32 *)d_plan_cc, (const u32 *)(fuse_mlen ? d_plan_ac : nullptr));
         PMX_CHECK_LAUNCH("k_events_tail");
     }
     return PMX_OK;

@@ -207,6 +207,70 @@ def aggregate_results(results: Mapping[str, Any]) -> GenomeWideResult:
     raise TypeError(f"Unknown result type: {type(first)}")
 
 
+def calc_cc_batch(ncc: List["NCCResult"], mscc: List["MSCCResult"], ncc_bins: Optional[np.ndarray] = None,
+                  mscc_rows: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]] = None) -> None:
+    """calc_cc() of many chromosomes' results at once: the same elementwise float64 operations as normalised_cc, row by
+    row of one 2-D array instead of a Python call (and a handful of small numpy calls) per chromosome -- a genome's worth
+    of results takes a fraction of a millisecond instead of a few.  Bit-identical values (no reductions are reordered).
+    Inside a PyMaSC installation the results are the reference's own objects: their own calc_cc() is called.
+    ncc_bins [len(ncc), S+1] / mscc_rows = (ccbins, forward_sum, reverse_sum, mappable length by SHIFT), each
+    [len(mscc), S+1]: the integer rows the results were built from, when the caller still holds them as arrays (all results
+    of one geometry then) -- saves turning the results' lists back into arrays."""
+    if REFERENCE_TYPES:
+        for r in list(ncc) + list(mscc):
+            r.calc_cc()
+        return
+
+    def rows(cc2d, zero, results):
+        for r, row, z in zip(results, cc2d, zero):
+            r.cc = np.full(row.shape, np.nan, dtype=np.float64) if z else row.copy()
+
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if ncc_bins is not None and len(ncc):
+            bins = np.asarray(ncc_bins, dtype=np.int64)
+            glen = np.array([r.genomelen for r in ncc], dtype=np.float64)[:, None]
+            denom = glen - np.arange(bins.shape[1], dtype=np.float64)[None, :]
+            fmean = np.array([float(r.forward_sum) for r in ncc])[:, None] / glen
+            rmean = np.array([float(r.reverse_sum) for r in ncc])[:, None] / glen
+            geo = ((fmean * (1 - fmean)) * (rmean * (1 - rmean))) ** 0.5
+            rows((bins / denom - fmean * rmean) / geo, bins.sum(axis=1) == 0, ncc)
+            ncc = []
+        if mscc_rows is not None and len(mscc):
+            bins = np.asarray(mscc_rows[0], dtype=np.int64)
+            tot = np.asarray(mscc_rows[3], dtype=np.float64)
+            fmean = np.asarray(mscc_rows[1], dtype=np.float64) / tot
+            rmean = np.asarray(mscc_rows[2], dtype=np.float64) / tot
+            geo = ((fmean * (1 - fmean)) * (rmean * (1 - rmean))) ** 0.5
+            rows((bins / tot - fmean * rmean) / geo, bins.sum(axis=1) == 0, mscc)
+            mscc = []
+        for group in _by_shape(ncc):
+            S1 = group[0].max_shift + 1
+            bins = np.array([r.ccbins[:S1] for r in group], dtype=np.int64)
+            glen = np.array([r.genomelen for r in group], dtype=np.float64)[:, None]
+            denom = glen - np.arange(S1, dtype=np.float64)[None, :]
+            fmean = np.array([float(r.forward_sum) for r in group])[:, None] / glen
+            rmean = np.array([float(r.reverse_sum) for r in group])[:, None] / glen
+            geo = ((fmean * (1 - fmean)) * (rmean * (1 - rmean))) ** 0.5
+            rows((bins / denom - fmean * rmean) / geo, bins.sum(axis=1) == 0, group)
+        for group in _by_shape(mscc):
+            S1, L = group[0].max_shift + 1, group[0].read_len
+            bins = np.array([r.ccbins[:S1] for r in group], dtype=np.int64)
+            lag = [np.array(r.mappable_len, dtype=np.float64) for r in group]
+            tot = np.array([np.concatenate((g[:L][::-1], g[1:]))[:S1] for g in lag])
+            fmean = np.array([r.forward_sum[:S1] for r in group], dtype=np.float64) / tot
+            rmean = np.array([r.reverse_sum[:S1] for r in group], dtype=np.float64) / tot
+            geo = ((fmean * (1 - fmean)) * (rmean * (1 - rmean))) ** 0.5
+            rows((bins / tot - fmean * rmean) / geo, bins.sum(axis=1) == 0, group)
+
+
+def _by_shape(results):
+    groups: Dict[Tuple[int, int, int], list] = {}
+    for r in results:
+        n = len(r.mappable_len) if hasattr(r, "mappable_len") else 0
+        groups.setdefault((r.max_shift, r.read_len, n), []).append(r)
+    return list(groups.values())
+
+
 # ---- inside a PyMaSC installation: emit the reference's own types ------------------------------------------------
 REFERENCE_TYPES = False
 try:

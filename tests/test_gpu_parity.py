@@ -228,7 +228,7 @@ def test_bits_builders_match_oracle(ctx):
 EVENT_TILE = 65536      # kernels_events.h: EV_TB
 EVENT_CAP_F = 768       # EV_CAPF: forward reads of one tile
 EVENT_CAP_R = 1000      # EV_CAPR: reverse reads of the tile + of the max_shift bits above it
-EVENT_CAP_E = 384       # EV_CAPE: run edges of everything staged for the tile
+EVENT_CAP_E = 1024      # EV_CAPE_SMALL: run edges of everything staged for the tile (max_shift <= 1023)
 
 
 def _exact_count_bits(rng, nbits, lo, hi, k):

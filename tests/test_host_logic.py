@@ -224,6 +224,41 @@ def _check_tiny_shift_ranges(context_factory):
         ctx.close()
 
 
+def test_calc_cc_batch_is_bit_identical_to_calc_cc():
+    """Results of a fetch get their cc curves in one vectorised pass (result.calc_cc_batch): the same float64 operations
+    as NCCResult.calc_cc / MSCCResult.calc_cc element by element, all-zero bins -> NaN included."""
+    import copy
+    rng = np.random.default_rng(1)
+    ncc, mscc = [], []
+    for k, (S, L) in enumerate([(300, 36), (300, 36), (300, 36), (20, 36), (100, 50), (300, 36)]):
+        bins = rng.integers(0, 50, S + 1).tolist() if k != 2 else [0] * (S + 1)
+        ncc.append(R.NCCResult(max_shift=S, read_len=L, genomelen=10**6 + k, forward_sum=5000 + k, reverse_sum=4000,
+                               forward_read_len_sum=1, reverse_read_len_sum=1, ccbins=bins))
+        by = rng.integers(1000, 5000, S + 1).tolist()
+        head = by[:min(L, S + 1)][::-1]
+        mlen = [None] * (L - len(head)) + head + (by[2 * L - 1:] if S >= 2 * L - 1 else [])
+        mscc.append(R.MSCCResult(max_shift=S, read_len=L, genomelen=10**6, forward_sum=rng.integers(0, 900, S + 1).tolist(),
+                                 reverse_sum=rng.integers(0, 900, S + 1).tolist(), forward_read_len_sum=1, reverse_read_len_sum=1,
+                                 ccbins=bins, mappable_len=mlen))
+    one = copy.deepcopy(ncc) + copy.deepcopy(mscc)
+    for r in one:
+        r.calc_cc()
+    R.calc_cc_batch(ncc, mscc)
+    for a, b in zip(one, ncc + mscc):
+        assert a.cc.dtype == b.cc.dtype == np.float64 and np.array_equal(a.cc, b.cc, equal_nan=True)
+    # ... and from the integer rows as arrays (what the calculator holds when it fetches a genome's results)
+    same = [k for k in (0, 1, 2, 5)]
+    n2, m2 = [copy.deepcopy(ncc[k]) for k in same], [copy.deepcopy(mscc[k]) for k in same]
+    for r in n2 + m2:
+        r.cc = None
+    by_shift = [[m.mappable_len[abs(d - 35)] for d in range(301)] for m in m2]
+    R.calc_cc_batch(n2, m2, np.array([r.ccbins for r in n2]),
+                    (np.array([r.ccbins for r in m2]), np.array([r.forward_sum for r in m2]),
+                     np.array([r.reverse_sum for r in m2]), np.array(by_shift)))
+    for k, a, b in zip(same, n2, m2):
+        assert np.array_equal(a.cc, one[k].cc, equal_nan=True) and np.array_equal(b.cc, one[len(ncc) + k].cc, equal_nan=True)
+
+
 def test_tiny_shift_ranges_host():
     _check_tiny_shift_ranges(FakeContext)
 
