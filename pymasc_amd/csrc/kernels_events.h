@@ -37,7 +37,7 @@
 #define EV_CAPF 768u                      // list capacities = the dense-tile thresholds (read density ~1 % per strand)
 #define EV_CAPR 1000u                     // reverse reads of the tile + of the max_shift bits above it (< 1024: rank field)
 #ifndef EV_CAPE_SMALL
-#define EV_CAPE_SMALL 1024u               // run edges of everything staged, max_shift <= 1023 (EV_CAPE(BIG): the LDS of the BIG
+#define EV_CAPE_SMALL 1536u               // run edges of everything staged, max_shift <= 1023 (EV_CAPE(BIG): the LDS of the BIG
 #endif                                    // instantiations is spent on histograms, their edge list stays at 384)
 #define EV_CAPE(BIG) ((BIG) ? 384u : EV_CAPE_SMALL)
 #define EV_POS 0x1ffffu                   // 17 bits of biased position (BIG: 16384 + 65536 + 8192 + 1152 staged bits at most)
@@ -137,13 +137,20 @@ __device__ __forceinline__ u32 ev_role_mlo_index(u32 tid) { return BIG ? tid : (
 
 template <bool HAS_M, bool GUARD, bool BIG>
 __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, const u32 *__restrict__ R,
-                                         const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid, u32 nhr, u32 lo)
+                                         const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid, u32 nhr, u32 lo,
+                                         bool skip_reads)
 {
+    if (skip_reads) nhr = 0;   // (uniform) the reads of this stretch belong to the window kernel: only M is staged
 #pragma unroll
     for (u32 q = 0; q < EV_NQ; q++) {
         const int64_t j = d0 + (int64_t)q * SP_TBW + 4 * (int64_t)tid;
-        er.f[q] = ld_quad<GUARD>(F, j, nbits);
-        er.r[q] = ld_quad<GUARD>(R, j, nbits);
+        if (skip_reads) {
+            er.f[q] = make_uint4(0, 0, 0, 0);
+            er.r[q] = make_uint4(0, 0, 0, 0);
+        } else {
+            er.f[q] = ld_quad<GUARD>(F, j, nbits);
+            er.r[q] = ld_quad<GUARD>(R, j, nbits);
+        }
         if (HAS_M) {
             er.m[q] = ld_quad<GUARD>(M, j, nbits);
             const int64_t j0 = d0 + (int64_t)q * SP_TBW + 4 * (int64_t)(tid & ~63u) - 1;   // uniform over the wave
@@ -157,7 +164,7 @@ __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, 
     // separate branches target the same registers, and the compiler then waits for everything in flight between them
     const u32 ht = tid & 63u, hw = tid >> 6;
     const bool m_lo = HAS_M && ev_role_mlo<BIG>(tid, lo), m_hi = HAS_M && hw == 2 && ht < 9, r_hi = hw == 3 && ht < nhr;
-    const u32 *hp = (m_lo || m_hi) ? M : R;
+    const u32 *hp = (m_lo || m_hi || skip_reads) ? M : R;   // (skip_reads without M does not occur)
     int64_t jh = d0 + 4 * (int64_t)tid;
     if (m_lo) jh = d0 - (int64_t)lo + 4 * (int64_t)ev_role_mlo_index<BIG>(tid);
     if (m_hi || r_hi) jh = d0 + EV_TBW + 4 * (int64_t)ht;
@@ -172,7 +179,8 @@ __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, 
 }
 
 template <bool HAS_M, bool BIG>
-__device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u32 local_tile, u32 tid, u32 nhr, u32 lo)
+__device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u32 local_tile, u32 tid, u32 nhr, u32 lo,
+                                             bool skip_reads = false)
 {
     const int64_t d0 = (int64_t)local_tile * EV_TBW;
     const int64_t low = d0 - (int64_t)lo - 1;
@@ -180,9 +188,9 @@ __device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u3
     const uint64_t hi = (uint64_t)d0 + EV_TBW + above;
     const bool interior = jb.aligned16 && low >= 0 && hi + 2 <= jb.nbits / 32;
     if (interior)
-        ev_fetch<HAS_M, false, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo);
+        ev_fetch<HAS_M, false, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads);
     else
-        ev_fetch<HAS_M, true, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo);
+        ev_fetch<HAS_M, true, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads);
 }
 
 // forward list entry: bits 0..16 biased position, 17..26 index of the first reverse read at or above it, 31 = M[x]
@@ -250,7 +258,7 @@ template <bool HAS_M, bool DO_NCC, bool DO_MLEN, u32 NSG, bool BIG>
 __global__ void __launch_bounds__(256 * NSG, (HAS_M || BIG) ? EV_WAVES : EV_WAVES_NCC)
 k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr, u32 max_lag,
             u32 hn_arg, u32 lo_arg, u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags,
-            unsigned char *__restrict__ tile_flags_ac, u32 *__restrict__ n_flagged)
+            unsigned char *__restrict__ tile_flags_ac, u32 *__restrict__ n_flagged, u32 *__restrict__ jobstat)
 {
     typedef EvLds<HAS_M, BIG> L;
     static_assert(BIG || NSG == 1, "the max_shift <= 1023 instantiations are one sub-group per workgroup");
@@ -305,9 +313,19 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     // Read-dense stretches (deep data: every tile far above the list capacities): after two such tiles in a row the
     // workgroup hands the REST of its tile range in this chromosome to the window kernels in one go (flags only, nothing
     // staged): the event kernel then costs two tiles per workgroup instead of a wasted pass over everything.  (NSG == 1)
-    u32 dense_run = 0;   // (uniform)
+    // Dense chromosomes (NSG == 1).  Every workgroup adds what it sees to three counters of the JOB (jobstat: tiles seen,
+    // read-dense, edge-dense tiles), and once most tiles of a chromosome turn out dense everybody stops staging it tile by
+    // tile -- job_mode: 1 = the reads of the rest of my range go to the cross-correlation window kernel unseen (the run
+    // edges are still listed here when the mappable-length pass is fused: F and R are not even loaded), 2 = the whole
+    // rest goes to both window kernels.  A job-wide verdict keeps the workgroups of a chromosome together: with a
+    // per-workgroup rule the unlucky ones walked their whole range while the others had left (round 3, first try), and a
+    // density right at a list capacity paid for both kernels (round 2: +30 % between 1.1 % and 2 % reads per strand).
+    // Isolated dense tiles -- a pile-up, a repeat -- are flagged one by one whatever the verdict.
+    u32 job_mode = 0;                  // (uniform)
+    bool cur_skip = false, next_skip = false;   // (uniform) the tile in the registers / the next fetch leaves F and R out
     u32 cur_tile0 = pj.tile0, cur_flag0 = pj.flag0;   // of the job whose tiles are being processed (index ji)
-    u32 cntF = 0, cntR = 0, cntB = 0, cnt0 = 0;   // per-thread: |F|, |R|, Bf, R0 of the tiles taken here
+    u32 cntB = 0, cnt0 = 0;                       // per-thread: Bf, R0 of the tiles taken here (|F|, |R|: uniform per tile, added
+                                                  // to xch[8], xch[9] in LDS by one thread: no register lives across tiles for them)
     u32 cntM = 0, cntU = 0;                       // DO_MLEN: popcount(M), runs starting in them
     u32 accF = 0, accR = 0;                       // (uniform) listed forward / reverse reads since the histograms' last flush
     bool seg_written = false;                     // (uniform) this (workgroup, job) segment already holds a flush
@@ -417,7 +435,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             // edge pairs of the mappable-length pass (DO_MLEN), so that deep data on an ordinary track does not push that pass onto
             // its window kernel as well.
             const bool dense_e = HAS_M && nE > EV_CAPE(BIG);
-            const bool dense_r = nF > EV_CAPF || nR > EV_CAPR;
+            const bool dense_r = cur_skip || nF > EV_CAPF || nR > EV_CAPR;
             dense = dense_e || dense_r;
             do_edges = HAS_M && !dense_e && (!dense || DO_MLEN);
             const u32 my_tile = g + sg;
@@ -445,15 +463,25 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                         idxR[128] = (unsigned short)nRt;
                     }
                 }
-                cntF += cF[0] + cF[1];
-                cntR += cR[0] + cR[1];
-            } else if (tid == 0) {
+                if (tid == 0) {
+                    atomicAdd(&xch[8 + 0], nF);
+                    atomicAdd(&xch[8 + 1], nRt);
+                }
+            } else {
                 // dense tile: left to k_cc_sparse (both of its 32-Kbit tiles; the flag array is padded per job)
-                const u32 f = cur_flag0 + EV_NQ * (my_tile - cur_tile0);
-                for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
-                if (DO_MLEN && dense_e) tile_flags_ac[cur_flag0 + (my_tile - cur_tile0)] = 1;   // (its window tile is this tile; same padded indexing)
-                atomicAdd(n_flagged, 1u);
-                if (DO_MLEN && dense_e) atomicAdd(n_flagged + 1, 1u);
+                if (tid == 0) {
+                    const u32 f = cur_flag0 + EV_NQ * (my_tile - cur_tile0);
+                    for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
+                    if (DO_MLEN && dense_e) tile_flags_ac[cur_flag0 + (my_tile - cur_tile0)] = 1;   // (its window tile is this tile; same padded indexing)
+                    if (NSG > 1) {
+                        atomicAdd(n_flagged, 1u);
+                        if (DO_MLEN && dense_e) atomicAdd(n_flagged + 1, 1u);
+                    }
+                }
+                if (NSG == 1 && tid == 0) {      // (added to n_flagged when the workgroup leaves the job)
+                    xch[14] += 1;
+                    if (DO_MLEN && dense_e) xch[15] += 1;
+                }
             }
             if (do_edges) {
                 // the run edges (+ those of the halos) in position order
@@ -477,25 +505,37 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 cntU += pendU;
             }
             if (NSG == 1) {
-                // stretch state (uniform): the second DENSE tile in a row ends this workgroup's work in the chromosome: its
-                // remaining tiles go to the window kernels unseen.  A density right at a list capacity (about half the tiles
-                // overflow) or above it would otherwise pay for staging + counting every tile here AND for the window kernel
-                // on most of them (round 2: +30 % between 1.1 % and 2 % reads per strand, +40 % at 330-370 run edges per
-                // tile); isolated dense tiles -- a pile-up, a repeat -- are still flagged one by one.
-                dense_run = dense ? dense_run + 1 : 0u;
-                if (dense_run >= 2) {
+                if (tid == 0) {
+                    // the job's counters; a dense tile also reads them back and leaves its verdict for everybody (after B1)
+                    u32 verdict = 0;
+                    u32 *st = jobstat + 4 * ji;
+                    if (!dense) {
+                        atomicAdd(st, 1u);
+                    } else if (job_mode == 0) {
+                        const u32 seen = atomicAdd(st, 1u) + 1;
+                        const u32 nr = atomicAdd(st + 1, dense_r ? 1u : 0u) + (dense_r ? 1u : 0u);
+                        const u32 ne = atomicAdd(st + 2, dense_e ? 1u : 0u) + (dense_e ? 1u : 0u);
+                        if (seen >= 16 && 10 * ne > 6 * seen) verdict = 2;
+                        else if (seen >= 16 && 10 * (nr + ne) > 6 * seen) verdict = 1;
+                    }
+                    sgb[L::MISC] = verdict;
+                }
+                if (job_mode == 2 || (job_mode == 1 && !(HAS_M && DO_MLEN))) {
+                    // the rest of my range in this chromosome: flags only, nothing staged
                     const u32 end = pj.tile_end < g1 ? pj.tile_end : g1;   // (pj is still the job of tile g here)
+                    const bool ac_too = DO_MLEN && job_mode == 2;
                     for (u32 t = g + 1 + tid; t < end; t += 256) {
                         const u32 f = cur_flag0 + EV_NQ * (t - cur_tile0);
                         for (u32 i = 0; i < EV_NQ; i++) tile_flags[f + i] = 1;
-                        if (DO_MLEN) tile_flags_ac[cur_flag0 + (t - cur_tile0)] = 1;
+                        if (ac_too) tile_flags_ac[cur_flag0 + (t - cur_tile0)] = 1;
                     }
                     if (tid == 0 && end > g + 1) {
-                        atomicAdd(n_flagged, end - (g + 1));
-                        if (DO_MLEN) atomicAdd(n_flagged + 1, end - (g + 1));
+                        xch[14] += end - (g + 1);
+                        if (ac_too) xch[15] += end - (g + 1);
                     }
                     gnext = end;
-                    dense_run = 0;
+                } else if (job_mode == 1) {
+                    next_skip = true;   // from the next fetch on
                 }
             }
         }
@@ -511,21 +551,26 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             if (gnext >= pj.tile_end) {   // rare: the next tile belongs to the next job
                 jn = ji + 1;
                 load_job(pj, jobs.j[jn]);
-                dense_run = 0;
+                next_skip = false;
             }
             if (NSG > 1) {
                 const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
                 act_var = gnext + sg < lim;
             }
-            if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, gnext + sg - pj.tile0, tid, nhr, LO);
+            if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, gnext + sg - pj.tile0, tid, nhr, LO, NSG == 1 && next_skip);
         } else if (NSG > 1) {
             act_var = false;
         }
+        const bool fetched_skip = NSG == 1 && next_skip;
         EV_STAMP(4)
         if (EV_PRIO_STAGE) __builtin_amdgcn_s_setprio(0);
         __syncthreads();   // B1: lists, M words and edge ranks visible
         if (EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(EV_PRIO_EVENTS);
         EV_STAMP(5)
+        if (NSG == 1) {
+            const u32 v = __builtin_amdgcn_readfirstlane(sgb[L::MISC]);   // thread 0's verdict on the job (see job_mode)
+            job_mode = v > job_mode ? v : job_mode;
+        }
         if (act && !dense) {
             // Work items are blocks of 64 drivers of three kinds; kind k deals its blocks to the waves starting at a
             // different wave, so that the odd blocks of the kinds land on different waves.  The loops are bound by LDS
@@ -700,6 +745,15 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         // another iteration could overflow a 16-bit cell (bounds in the comment of EvLds): flush now
         const bool risk = HAS_M && (BIG ? (accF + NSG * EV_CAPF > 32767u || 3u * (accR + NSG * EV_CAPR) > 32767u)
                                         : accF + EV_CAPF > 65535u);
+        if (NSG == 1 && leaving && tid == 0) {
+            // tiles flagged in this job: one atomic per workgroup and job, not per tile (47 k adds to one word serialise in L2
+            // when every tile is dense)
+            const u32 pc = xch[14], pa = xch[15];
+            if (pc) atomicAdd(n_flagged, pc);
+            if (pa) atomicAdd(n_flagged + 1, pa);
+            xch[14] = 0;
+            xch[15] = 0;
+        }
         if (leaving || risk) {
             // histograms of this (workgroup, job) -> its slab segment (added to it from the second flush on); cleared
             __syncthreads();
@@ -753,22 +807,21 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             seg_written = true;
             if (leaving) {
                 // scalars: |F|, |R|, Bf, R0, popcount(M), runs -> row 4 of the segment
-                u32 v[6] = {cntF, cntR, cntB, cnt0, cntM, cntU};
+                u32 v[6] = {0, 0, cntB, cnt0, cntM, cntU};
 #pragma unroll
-                for (u32 k = 0; k < 6; k++)
+                for (u32 k = 2; k < 6; k++)
                     for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
                 if ((gt & 63u) == 0) {
 #pragma unroll
-                    for (u32 k = 0; k < 6; k++)
+                    for (u32 k = 2; k < 6; k++)
                         if (k < 4 || DO_MLEN) atomicAdd(&xch[8 + k], v[k]);
                 }
+
                 __syncthreads();
                 if (gt < 6) {
                     seg[4 * HN + gt] = xch[8 + gt];
                     xch[8 + gt] = 0;
                 }
-                cntF = 0;
-                cntR = 0;
                 cntB = 0;
                 cnt0 = 0;
                 cntM = 0;
@@ -776,6 +829,11 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 seg_written = false;
             }
         }
+        if (jn != ji) {
+            job_mode = 0;
+            next_skip = false;
+        }
+        cur_skip = fetched_skip;
         ji = jn;
         cur_tile0 = pj.tile0;
         cur_flag0 = pj.flag0;
@@ -823,29 +881,27 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
         if (flagged) {
             u64 *P = jb.out2, *N = jb.out2 + lagcap, *scal = jb.out2 + 2 * (size_t)lagcap;
             const size_t stride = (size_t)AC_SEG_ROWS * 1024;
-            // (workgroup ranges: the device-side plan of k_plan_flagged when there is one; empty ranges wrote no segment)
-            const u32 ac_first = plan_ac ? plan_ac[PLAN_JOBWG + 2 * job] : plan.ac_first[job];
-            const u32 ac_last = plan_ac ? plan_ac[PLAN_JOBWG + 2 * job + 1] : plan.ac_last[job];
+            // (the workgroups that wrote a segment for this job: entries [i0, i1) of the device-side plan's list of non-empty
+            // ranges (k_plan_flagged) when there is one, else the host's static range)
+            const u32 i0 = plan_ac ? plan_ac[PLAN_JOBWG + 2 * job] : plan.ac_first[job];
+            const u32 i1 = plan_ac ? plan_ac[PLAN_JOBWG + 2 * job + 1] : plan.ac_last[job] + 1;
             for (u32 k = tid; k <= max_lag; k += EV_TAIL_THREADS) {
                 u64 sp = 0, sn = 0;
 #pragma unroll 4
-                for (u32 w = ac_first; w <= ac_last; w++) {
-                    // (a workgroup with an empty range wrote nothing: its segment is read and dropped -- a select, not a
-                    // branch, so that the loads of the unrolled iterations overlap)
-                    const bool live = !plan_ac || plan_ac[w] != plan_ac[w + 1];
+                for (u32 i = i0; i < i1; i++) {
+                    const u32 w = plan_ac ? plan_ac[PLAN_LIST + i] : i;
                     const u32 *seg = slab_ac + (size_t)(w + job) * stride;
-                    const u32 vp = seg[k], vn = seg[1024 + k];
-                    sp += live ? vp : 0u;
-                    sn += live ? vn : 0u;
+                    sp += seg[k];
+                    sn += seg[1024 + k];
                 }
                 P[k] += sp;
                 N[k] += sn;
             }
             if (tid < 2) {
                 u64 sc = 0;
-                for (u32 w = ac_first; w <= ac_last; w++) {
-                    const u32 v = slab_ac[(size_t)(w + job) * stride + 2 * 1024 + tid];
-                    sc += (!plan_ac || plan_ac[w] != plan_ac[w + 1]) ? v : 0u;
+                for (u32 i = i0; i < i1; i++) {
+                    const u32 w = plan_ac ? plan_ac[PLAN_LIST + i] : i;
+                    sc += slab_ac[(size_t)(w + job) * stride + 2 * 1024 + tid];
                 }
                 scal[tid] += sc;
             }
@@ -887,8 +943,8 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
         // rows of the window kernel's segments: 0 ncc, 1 fsum, 2 cc, 3 rsum, 4 scalars (|F|, |R|)
         const u32 dst_row[4] = {PMX_ROW_NCC_CCBINS, PMX_ROW_MSCC_FSUM, PMX_ROW_MSCC_CCBINS, PMX_ROW_MSCC_RSUM};
         const size_t stride = (size_t)SP_SEG_ROWS * 1024;
-        const u32 cc_first = plan_cc ? plan_cc[PLAN_JOBWG + 2 * job] : plan.cc_first[job];
-        const u32 cc_last = plan_cc ? plan_cc[PLAN_JOBWG + 2 * job + 1] : plan.cc_last[job];
+        const u32 i0 = plan_cc ? plan_cc[PLAN_JOBWG + 2 * job] : plan.cc_first[job];       // (see the autocorrelation branch)
+        const u32 i1 = plan_cc ? plan_cc[PLAN_JOBWG + 2 * job + 1] : plan.cc_last[job] + 1;
         for (u32 r = 0; r < 4; r++) {
             if (r == 0 ? !do_ncc : !has_m) continue;
             // the rows with prefix sums stay with the block that took them (y = 0); ncc -> y = 2, cc -> y = 3
@@ -897,18 +953,18 @@ k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailP
             for (u32 d = tid; d <= S; d += EV_TAIL_THREADS) {
                 u64 sum = 0;
 #pragma unroll 4
-                for (u32 w = cc_first; w <= cc_last; w++) {
-                    const u32 v = slab_cc[(size_t)(w + job) * stride + r * 1024 + d];
-                    sum += (!plan_cc || plan_cc[w] != plan_cc[w + 1]) ? v : 0u;
+                for (u32 i = i0; i < i1; i++) {
+                    const u32 w = plan_cc ? plan_cc[PLAN_LIST + i] : i;
+                    sum += slab_cc[(size_t)(w + job) * stride + r * 1024 + d];
                 }
                 dst[d] += sum;
             }
         }
         if (blockIdx.y == 2 && tid < 2) {
             u64 sc = 0;
-            for (u32 w = cc_first; w <= cc_last; w++) {
-                const u32 v = slab_cc[(size_t)(w + job) * stride + 4 * 1024 + tid];
-                sc += (!plan_cc || plan_cc[w] != plan_cc[w + 1]) ? v : 0u;
+            for (u32 i = i0; i < i1; i++) {
+                const u32 w = plan_cc ? plan_cc[PLAN_LIST + i] : i;
+                sc += slab_cc[(size_t)(w + job) * stride + 4 * 1024 + tid];
             }
             jb.out[(size_t)PMX_ROW_SCALARS * out_stride + tid] += sc;
         }

@@ -329,6 +329,23 @@ __device__ __forceinline__ uint4 ld_quad(const u32 *__restrict__ p, int64_t j, u
     return v;
 }
 
+// Behind the event / pair kernel: the next tile at or after `g` (below `lim`) whose flag is set, or lim.  64 flags per trip
+// (one byte per lane + a ballot; every wave of the workgroup runs it and gets the same answer): with the flagged tiles in
+// equal shares (k_plan_flagged) a range can hold thousands of unflagged tiles, and one dependent byte load per tile was
+// 0.5 us each.
+__device__ __forceinline__ u32 next_flagged_tile(const unsigned char *__restrict__ flags, u32 g, u32 lim)
+{
+    const u32 lane = threadIdx.x & 63u;
+    while (g < lim) {
+        const u32 t = g + lane;
+        const bool set = t < lim && flags[t] != 0;
+        const unsigned long long b = __ballot(set);
+        if (b) return g + (u32)__builtin_ctzll(b);
+        g += 64;
+    }
+    return lim;
+}
+
 struct TileRegs {
     uint4 f, r, m, h;   // main F / R / M quads of this thread + one halo quad (threads 0..34)
 };
@@ -657,8 +674,8 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
 
     // tile range of this workgroup: equal shares of the tile sequence, or -- behind the event kernel -- the range
     // k_plan_flagged cut for it (equal shares of the FLAGGED tiles, see there)
-    const u32 g0 = plan ? plan[blockIdx.x] : blockIdx.x * tiles_per_wg;
-    const u32 g1 = plan ? plan[blockIdx.x + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
+    const u32 g0 = plan ? plan[2 * blockIdx.x] : blockIdx.x * tiles_per_wg;
+    const u32 g1 = plan ? plan[2 * blockIdx.x + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
     if (g0 >= g1) return;
 
     for (u32 i = tid; i < 40; i += 256) lds[L::ZERO + i] = 0;
@@ -749,7 +766,7 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
             gnext = g + 1;
             if (tile_flags) {
                 const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
-                while (gnext < lim && !tile_flags[pj.flag0 + gnext - pj.tile0]) gnext++;
+                gnext = pj.tile0 + next_flagged_tile(tile_flags + pj.flag0, gnext - pj.tile0, lim - pj.tile0);
             }
             if (gnext < g1) {
                 if (gnext >= pj.tile_end) {   // rare: the next tile belongs to the next job
@@ -1280,8 +1297,8 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     const u32 tid = threadIdx.x;
     const SlotGeom sg = slot_geom(lgG, tid);
 
-    const u32 g0 = plan ? plan[blockIdx.x] : blockIdx.x * tiles_per_wg;          // (see k_cc_sparse)
-    const u32 g1 = plan ? plan[blockIdx.x + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
+    const u32 g0 = plan ? plan[2 * blockIdx.x] : blockIdx.x * tiles_per_wg;      // (see k_cc_sparse)
+    const u32 g1 = plan ? plan[2 * blockIdx.x + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
     if (g0 >= g1) return;
 
     for (u32 i = tid; i < 40; i += 256) lds[L::ZERO + i] = 0;
@@ -1358,7 +1375,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
             gnext = g + 1;
             if (!CH && tile_flags) {
                 const u32 je = jobs.j[ji].tile0 + jobs.j[ji].ntiles, lim = je < g1 ? je : g1;
-                while (gnext < lim && !tile_flags[jobs.j[ji].flag0 + gnext - jobs.j[ji].tile0]) gnext++;
+                gnext = jobs.j[ji].tile0 + next_flagged_tile(tile_flags + jobs.j[ji].flag0, gnext - jobs.j[ji].tile0, lim - jobs.j[ji].tile0);
             }
             if (gnext < g1) {
                 if (gnext >= jobs.j[ji].tile0 + jobs.j[ji].ntiles) jn = ji + 1;
@@ -1825,14 +1842,36 @@ k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 lagcap, u32 mode, int3
 // workgroup of the event kernel handed over) to the one or two workgroups whose share they fall into, with everybody else
 // idle: the window pass then took 70 % of its full-genome time for 10 % of the tiles.  This kernel (one block) cuts the
 // tile sequence into nwg contiguous ranges with equal numbers of FLAGGED tiles instead:
-//   plan[w], w = 0..nwg         range bounds in the launch's global tile sequence (plan[0] = 0, plan[nwg] = total)
-//   plan[PLAN_JOBWG + 2 job..]  first / last workgroup whose range meets the job's tiles (k_events_tail sums their slab
-//                               segments; a workgroup with an empty range wrote none and is skipped there)
+//   plan[2 w], plan[2 w + 1]    range [start, end) of workgroup w in the launch's global tile sequence
+//   plan[PLAN_LIST + i]         the workgroups with a non-empty range, in order
+//   plan[PLAN_JOBWG + 2 job..]  entries [first, end) of that list whose ranges meet the job's tiles (k_events_tail sums their
+//                               slab segments; a workgroup with an empty range wrote none)
 // Contiguous ranges keep the window kernels' per-(workgroup, job) bookkeeping as it is.
-#define PLAN_JOBWG 4096u
-#define PLAN_WORDS (PLAN_JOBWG + 2 * SP_MAXJOBS)
+#define PLAN_JOBWG 4096u                      // [2 x SP_MAXJOBS] per job: first / last index into the list below
+#define PLAN_LIST (PLAN_JOBWG + 2 * SP_MAXJOBS)   // the workgroups with a non-empty range, in order
+#define PLAN_WORDS (PLAN_LIST + 2048u)
 // The flag array is scanned in its RAW layout (job i's tiles at [flag0_i, flag0_i + ntiles_i) + padding): 16 flags per thread
 // and pass with one 16-byte load, a block scan per pass.
+__device__ __forceinline__ u32 plan_block_scan(u32 v, u32 *part, u32 tid, u32 *total)   // exclusive; ends with a barrier
+{
+    u32 x = v;
+    const u32 lane = tid & 63, wave = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 y = __shfl_up(x, off, 64);
+        if (lane >= (u32)off) x += y;
+    }
+    if (lane == 63) part[wave] = x;
+    __syncthreads();
+    u32 base = x - v, tot = 0;
+    for (u32 w = 0; w < 16; w++) {
+        if (w < wave) base += part[w];
+        tot += part[w];
+    }
+    *total = tot;
+    __syncthreads();
+    return base;
+}
+
 __global__ void __launch_bounds__(1024)
 k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const unsigned char *__restrict__ flags, u32 raw_flags,
                const u32 *__restrict__ n_flagged, u32 flags_per_count, u32 *__restrict__ plan)
@@ -1844,85 +1883,111 @@ k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const
     if (F == 0) return;            // nothing flagged: the window kernel returns at once and nobody reads the plan
     __shared__ u32 part[16];
     __shared__ u32 jflag0[SP_MAXJOBS + 1], jtile0[SP_MAXJOBS];
-    __shared__ u32 sb[PLAN_JOBWG];     // the bounds once more, for the job ranges at the end (nwg < PLAN_JOBWG)
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ u32 sb[2049];       // first flagged tile of every workgroup (nwg <= 2048)
+    __shared__ u32 wl[2048];       // the workgroups with a non-empty range ...
+    __shared__ u32 se[2048];       // ... and where their ranges end
+    const u32 tid = threadIdx.x;
     if (tid < njobs) {
         jflag0[tid] = jobs.j[tid].flag0;
         jtile0[tid] = jobs.j[tid].tile0;
     }
     if (tid == 0) jflag0[njobs] = 0xffffffffu;
-    for (u32 w = tid; w <= nwg; w += 1024) {   // (a bound nobody writes -- fewer flags set than counted -- is an empty range)
-        sb[w] = total_tiles;
-        plan[w] = total_tiles;
-    }
+    for (u32 w = tid; w <= nwg; w += 1024) sb[w] = total_tiles;   // (a start nobody writes -- fewer flags set than counted -- is an empty range)
     __syncthreads();
     u32 running = 0;               // flagged entries before this pass (uniform)
     for (u32 f0 = 0; f0 < raw_flags; f0 += 1024 * 16) {
         const u32 f = f0 + 16 * tid;
         uint4 q = make_uint4(0, 0, 0, 0);
         if (f < raw_flags) q = *reinterpret_cast<const uint4 *>(flags + f);
-        const u32 qs[4] = {q.x & 0x01010101u, q.y & 0x01010101u, q.z & 0x01010101u, q.w & 0x01010101u};   // (flags are 0 / 1)
-        const u32 cnt = __popc(qs[0]) + __popc(qs[1]) + __popc(qs[2]) + __popc(qs[3]);
-        u32 x = cnt;
-        for (int off = 1; off < 64; off <<= 1) {
-            const u32 y = __shfl_up(x, off, 64);
-            if (lane >= (u32)off) x += y;
-        }
-        if (lane == 63) part[wave] = x;
-        __syncthreads();
-        u32 rank = running + x - cnt, tot = 0;
-        for (u32 w = 0; w < 16; w++) {
-            if (w < wave) rank += part[w];
-            tot += part[w];
-        }
+        // (flags are 0 / 1) one bit per flag: the four low bits of the bytes of a dword gathered by a multiplication
+        const u32 m16 = (((q.x & 0x01010101u) * 0x01020408u) >> 24) | ((((q.y & 0x01010101u) * 0x01020408u) >> 24) << 4) |
+                        ((((q.z & 0x01010101u) * 0x01020408u) >> 24) << 8) | ((((q.w & 0x01010101u) * 0x01020408u) >> 24) << 12);
+        const u32 cnt = __popc(m16);
+        u32 tot;
+        const u32 rank = running + plan_block_scan(cnt, part, tid, &tot);
         running += tot;
-        __syncthreads();
-        if (cnt) {
-            // workgroup w takes the flagged tiles of rank [w F / nwg, (w + 1) F / nwg): its range starts AT the first of them
-#pragma unroll
-            for (u32 k = 0; k < 16; k++) {
-                if (!((qs[k >> 2] >> (8 * (k & 3))) & 1u)) continue;
-                const u32 w_lo = (u32)(((u64)rank * nwg + F - 1) / F), w_hi = (u32)(((u64)(rank + 1) * nwg + F - 1) / F);
-                if (w_lo < w_hi) {
+        if (cnt && F < nwg) {
+            // fewer flagged tiles than workgroups: the flagged tile of rank r is workgroup r's, alone (see the ranges below)
+            u32 m = m16, r = rank;
+            while (m) {
+                const u32 k = (u32)__builtin_ctz(m);
+                m &= m - 1;
+                u32 ji = 0;
+                while (jflag0[ji + 1] <= f + k) ji++;
+                if (r < nwg) sb[r] = jtile0[ji] + (f + k - jflag0[ji]);   // raw flag index -> tile of the launch's sequence
+                r++;
+            }
+        } else if (cnt) {
+            // workgroup w takes the flagged tiles of rank [w F / nwg, (w + 1) F / nwg): its range starts AT the first of them.
+            // The workgroups whose first tile is one of my cnt entries (ranks [rank, rank + cnt)): three divisions per thread,
+            // then floor(w F / nwg) step by step (a division per entry took 100 us: 64-bit divisions are long dependent VALU
+            // sequences and one block does all of this)
+            const u32 w_lo = (u32)(((u64)rank * nwg + F - 1) / F), w_hi = (u32)(((u64)(rank + cnt) * nwg + F - 1) / F);
+            u64 prod = (u64)w_lo * F;
+            u32 quo = (u32)(prod / nwg), rem = (u32)(prod - (u64)quo * nwg);
+            for (u32 w = w_lo; w < w_hi && w < nwg; w++) {
+                u32 m = m16;             // my (quo - rank)-th set flag (0-based): drop the lower ones
+                for (u32 r = quo - rank; r > 0 && m; r--) m &= m - 1;
+                if (m) {                                       // (always, while F is the number of flags set)
+                    const u32 k = (u32)__builtin_ctz(m);
                     u32 ji = 0;
                     while (jflag0[ji + 1] <= f + k) ji++;
-                    const u32 t = jtile0[ji] + (f + k - jflag0[ji]);     // raw flag index -> tile of the launch's sequence
-                    for (u32 w = w_lo; w < w_hi && w < nwg; w++) {
-                        plan[w] = t;
-                        sb[w] = t;
-                    }
+                    sb[w] = jtile0[ji] + (f + k - jflag0[ji]);
                 }
-                rank++;
+                u64 nr = (u64)rem + F;                         // (w + 1) F = quo' nwg + rem'
+                while (nr >= nwg) {
+                    nr -= nwg;
+                    quo++;
+                }
+                rem = (u32)nr;
             }
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        plan[0] = 0;
-        plan[nwg] = total_tiles;
-        sb[0] = 0;
-        sb[nwg] = total_tiles;
+    if (tid == 0) sb[nwg] = total_tiles;
+    __syncthreads();
+    // ranges [start, end) per workgroup.  F >= nwg: a range runs up to the next one's start.  Fewer flagged tiles than
+    // workgroups: a workgroup has ONE tile or none, and its range is that tile alone -- otherwise it would walk the flags of
+    // thousands of tiles up to the next flagged one (0.3 ms for half a dozen flagged tiles).  Then the workgroups that have
+    // tiles, compacted (an empty range wrote no slab segment).
+    u32 nlive = 0;
+    for (u32 w0 = 0; w0 < nwg; w0 += 1024) {
+        const u32 w = w0 + tid;
+        u32 start = 0, end = 0, live = 0;
+        if (w < nwg) {
+            start = sb[w];
+            live = start < sb[w + 1] ? 1u : 0u;
+            end = F < nwg ? start + live : sb[w + 1];
+            plan[2 * w] = start;
+            plan[2 * w + 1] = end;
+        }
+        u32 tot;
+        const u32 idx = nlive + plan_block_scan(live, part, tid, &tot);
+        if (live) {
+            wl[idx] = w;
+            se[idx] = end;
+            plan[PLAN_LIST + idx] = w;
+        }
+        nlive += tot;
     }
     __syncthreads();
     if (tid < njobs) {
-        // first = the first workgroup whose range ends above the job's first tile, last = the last one that starts below
-        // its end (the bounds are non-decreasing: two binary searches in LDS)
+        // list entries whose range meets the job's tiles [a, b): starts and ends increase along the list
         const u32 a = jobs.j[tid].tile0, b = a + jobs.j[tid].ntiles;
-        u32 lo = 0, hi = nwg - 1;
-        while (lo < hi) {                       // smallest w with sb[w + 1] > a
+        u32 lo = 0, hi = nlive;                 // first i with end_i > a
+        while (lo < hi) {
             const u32 mid = (lo + hi) >> 1;
-            if (sb[mid + 1] > a) hi = mid;
+            if (se[mid] > a) hi = mid;
             else lo = mid + 1;
         }
         const u32 first = lo;
-        lo = first;
-        hi = nwg - 1;
-        while (lo < hi) {                       // largest w with sb[w] < b  (w = first qualifies: sb[first] <= a < b)
-            const u32 mid = (lo + hi + 1) >> 1;
-            if (sb[mid] < b) lo = mid;
-            else hi = mid - 1;
+        hi = nlive;                             // first i with start_i >= b
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (sb[wl[mid]] >= b) hi = mid;
+            else lo = mid + 1;
         }
-        plan[PLAN_JOBWG + 2 * tid] = first;
+        plan[PLAN_JOBWG + 2 * tid] = first;     // entries [first, end) of the list
         plan[PLAN_JOBWG + 2 * tid + 1] = lo;
     }
 }
@@ -2085,7 +2150,7 @@ static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p)
 
 template <bool HAS_M, bool DO_NCC, u32 NSG>
 static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTable &tab, u32 n, u32 total, u32 tpw, u32 nwg, u32 c,
-                         u32 max_shift, u32 nhr, unsigned char *d_flags, u32 *d_nflagged)
+                         u32 max_shift, u32 nhr, unsigned char *d_flags, u32 *d_nflagged, u32 *d_jobstat)
 {
     auto kern = k_cc_events<HAS_M, DO_NCC, false, NSG, true>;
     static bool attr_set = false;   // (a context is single-threaded; the attribute is per process and device function)
@@ -2095,7 +2160,7 @@ static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTable &ta
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256 * NSG), pl.lds_bytes, ctx->stream, tab, n, total, tpw, c, max_shift, nhr, 0u,
-                       pl.hn, pl.lo, ctx->d_slab, d_flags, d_flags, d_nflagged);
+                       pl.hn, pl.lo, ctx->d_slab, d_flags, d_flags, d_nflagged, d_jobstat);
     PMX_CHECK_LAUNCH("k_cc_events (max_shift > 1023)");
     return PMX_OK;
 }
@@ -2120,11 +2185,13 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
         total_flags += (jobs[i].nbits + SP_TB - 1) / SP_TB + EV_NQ;   // padding: an event tile flags EV_NQ window tiles
     }
     const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
-    int rc = pmx_ensure_flags_cc(ctx, flag_bytes + 16);
+    const size_t stat_bytes = 4 * SP_MAXJOBS * sizeof(u32);
+    int rc = pmx_ensure_flags_cc(ctx, flag_bytes + 16 + stat_bytes);
     if (rc) return rc;
     unsigned char *d_flags = ctx->d_flags_cc;
     u32 *d_nflagged = (u32 *)(ctx->d_flags_cc + flag_bytes);
-    PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, flag_bytes + 16, ctx->stream));
+    u32 *d_jobstat = d_nflagged + 4;     // per job: tiles seen / read-dense / edge-dense (k_cc_events, one sub-group)
+    PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, flag_bytes + 16 + stat_bytes, ctx->stream));
 
     ReduceSpec rs_ev = rs;
     for (u32 i = 0; i < nr; i++)
@@ -2143,6 +2210,7 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
         SpJobTable tab;
         memset(&tab, 0, sizeof tab);
         uint32_t total, tpw, nwg;
+        if (lo) PMX_HIP(hipMemsetAsync(d_jobstat, 0, stat_bytes, ctx->stream));   // (the next 32 jobs)
         plan_launch(ctx, ev.data(), n, false, pl.wg_per_cu, &tab, &total, &tpw, &nwg, EV_TB);
         rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * EV_SEG_ROWS * pl.hn + (size_t)nwg * 4 * pl.nsg * 12 * 2 + 64);
         if (rc) return rc;
@@ -2150,9 +2218,9 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_EVENTS, &tl);
         if (rc) return rc;
 #define EVB(HM, NC)                                                                                                         \
-    (pl.nsg == 1   ? ev_big_launch<HM, NC, 1>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged)     \
-     : pl.nsg == 2 ? ev_big_launch<HM, NC, 2>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged)     \
-                   : ev_big_launch<HM, NC, 4>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged))
+    (pl.nsg == 1   ? ev_big_launch<HM, NC, 1>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat)  \
+     : pl.nsg == 2 ? ev_big_launch<HM, NC, 2>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat)  \
+                   : ev_big_launch<HM, NC, 4>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat))
         rc = has_m ? (do_ncc ? EVB(true, true) : EVB(true, false)) : EVB(false, true);
 #undef EVB
         if (rc) return rc;
@@ -2253,7 +2321,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     const bool use_events = events_enabled() && !ctx->window_only && !chunked;
     const bool fuse_mlen = use_events && has_m && fused && njobs <= SP_MAXJOBS && pmx_events_can_fuse_mlen(max_shift, fused_lag);
     unsigned char *d_flags = nullptr, *d_flags_ac = nullptr;
-    u32 *d_nflagged = nullptr, *d_plan_cc = nullptr, *d_plan_ac = nullptr;
+    u32 *d_nflagged = nullptr, *d_plan_cc = nullptr, *d_plan_ac = nullptr, *d_jobstat = nullptr;
     size_t flag_bytes_all = 0;     // raw length of a flag array (multiple of 16)
     if (use_events) {
         uint64_t total_flags = 0;
@@ -2262,15 +2330,17 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             total_flags += (vjobs[i].job->nbits + SP_TB - 1) / SP_TB + EV_NQ;   // padding: an event tile flags EV_NQ window tiles
         }
         const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
-        int rc = pmx_ensure_flags_cc(ctx, 2 * flag_bytes + 16 + 2 * PLAN_WORDS * sizeof(u32));
+        const size_t stat_bytes = 4 * SP_MAXJOBS * sizeof(u32);
+        int rc = pmx_ensure_flags_cc(ctx, 2 * flag_bytes + 16 + stat_bytes + 2 * PLAN_WORDS * sizeof(u32));
         if (rc) return rc;
         d_flags = ctx->d_flags_cc;                   // tiles of the cross-correlation window kernel (32 Kbit)
         d_flags_ac = ctx->d_flags_cc + flag_bytes;   // tiles of the autocorrelation window kernel (64 Kbit), same flag0 per job
         d_nflagged = (u32 *)(ctx->d_flags_cc + 2 * flag_bytes);
+        d_jobstat = (u32 *)(ctx->d_flags_cc + 2 * flag_bytes + 16);   // per job: tiles seen / read-dense / edge-dense (k_cc_events)
         flag_bytes_all = flag_bytes;
-        d_plan_cc = (u32 *)(ctx->d_flags_cc + 2 * flag_bytes + 16);   // work split of the two window launches (k_plan_flagged)
+        d_plan_cc = d_jobstat + 4 * SP_MAXJOBS;      // work split of the two window launches (k_plan_flagged)
         d_plan_ac = d_plan_cc + PLAN_WORDS;
-        PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, 2 * flag_bytes + 16, ctx->stream));
+        PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, 2 * flag_bytes + 16 + stat_bytes, ctx->stream));
         if (fuse_mlen) fused->done = true;   // row MLEN and scalar [2] are written by this call (k_events_tail)
     }
     ReduceSpec rs_ev = rs;
@@ -2285,6 +2355,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         pmx_timed_launch tl;
         if (use_events) {
             memset(&tab, 0, sizeof tab);
+            if (lo) PMX_HIP(hipMemsetAsync(d_jobstat, 0, 4 * SP_MAXJOBS * sizeof(u32), ctx->stream));   // (the next 32 jobs)
             plan_launch(ctx, &vjobs[lo], n, false, has_m ? EV_WAVES : EV_WAVES_NCC, &tab, &total, &tpw, &nwg, EV_TB);
             rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * EV_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
             if (rc) return rc;
@@ -2293,7 +2364,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             const u32 nhr = (max_shift + 1 + 127) / 128;   // quads of R above a tile that hold partners of its forward reads
 #define EV_LAUNCH(HM, NC, ML)                                                                                          \
     hipLaunchKernelGGL((k_cc_events<HM, NC, ML, 1, false>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, (u32)c, \
-                       max_shift, nhr, fused_lag, 1024u, (u32)EV_LO, ctx->d_slab, d_flags, d_flags_ac, d_nflagged)
+                       max_shift, nhr, fused_lag, 1024u, (u32)EV_LO, ctx->d_slab, d_flags, d_flags_ac, d_nflagged, d_jobstat)
             if (has_m && do_ncc && fuse_mlen) EV_LAUNCH(true, true, true);
             else if (has_m && do_ncc) EV_LAUNCH(true, true, false);
             else if (has_m && fuse_mlen) EV_LAUNCH(true, false, true);
@@ -2337,6 +2408,10 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         u32 *const wslab = use_events ? ctx->d_slab_fb : ctx->d_slab;
         if (use_events) {
             // the flagged tiles in equal shares (one small block; returns at once when nothing was flagged)
+            if (nwg > 2048) {
+                pmx_set_error("k_plan_flagged: %u workgroups exceed its tables", nwg);
+                return PMX_ERR_INVALID;
+            }
             hipLaunchKernelGGL(k_plan_flagged, dim3(1), dim3(1024), 0, ctx->stream, tabW, n, total, nwg, (const unsigned char *)d_flags,
                                (u32)flag_bytes_all, (const u32 *)d_nflagged, (u32)EV_NQ, d_plan_cc);
             PMX_CHECK_LAUNCH("k_plan_flagged");
