@@ -254,9 +254,9 @@ __device__ __forceinline__ void ev_add_cell(u32 *row, u32 cell, u32 val)
 // E[j] E[j + k] over the edges j of the tile, k = 1..max_lag, and popcount(M) / the runs starting in the tile.
 // NSG sub-groups of 256 threads; BIG: max_shift up to EV_MAX_SHIFT, geometry in the arguments `hn_arg` (entries per
 // histogram row) and `lo_arg` (dwords of M staged below a tile), histograms in dynamic LDS; !BIG: max_shift <= 1023.
-template <bool HAS_M, bool DO_NCC, bool DO_MLEN, u32 NSG, bool BIG>
+template <bool HAS_M, bool DO_NCC, bool DO_MLEN, u32 NSG, bool BIG, typename JT = SpJobTable>
 __global__ void __launch_bounds__(256 * NSG, (HAS_M || BIG) ? EV_WAVES : EV_WAVES_NCC)
-k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr, u32 max_lag,
+k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr, u32 max_lag,
             u32 hn_arg, u32 lo_arg, u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags,
             unsigned char *__restrict__ tile_flags_ac, u32 *__restrict__ n_flagged, u32 *__restrict__ jobstat)
 {
@@ -296,8 +296,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         for (u32 i = gt; i < L::o_sg(HN); i += NT) lds[i] = 0;
     }
 
-    u32 ji = 0;
-    while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
+    FIRST_JOB(ji, JT, jobs, njobs, g0)
     u32 jn = ji;
     EvRegs er;
     SpJobRegs pj;   // job of the tiles being prefetched (index jn), held in scalar registers
@@ -322,6 +321,8 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     // density right at a list capacity paid for both kernels (round 2: +30 % between 1.1 % and 2 % reads per strand).
     // Isolated dense tiles -- a pile-up, a repeat -- are flagged one by one whatever the verdict.
     u32 job_mode = 0;                  // (uniform)
+    u32 unreported = 0;                // (uniform) tiles of this job seen since my last report to jobstat
+    bool had_dense = false;            // (uniform) a verdict may have been left in LDS since the job began
     bool cur_skip = false, next_skip = false;   // (uniform) the tile in the registers / the next fetch leaves F and R out
     u32 cur_tile0 = pj.tile0, cur_flag0 = pj.flag0;   // of the job whose tiles are being processed (index ji)
     u32 cntB = 0, cnt0 = 0;                       // per-thread: Bf, R0 of the tiles taken here (|F|, |R|: uniform per tile, added
@@ -505,20 +506,25 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
                 cntU += pendU;
             }
             if (NSG == 1) {
-                if (tid == 0) {
-                    // the job's counters; a dense tile also reads them back and leaves its verdict for everybody (after B1)
-                    u32 verdict = 0;
-                    u32 *st = jobstat + 4 * ji;
-                    if (!dense) {
-                        atomicAdd(st, 1u);
-                    } else if (job_mode == 0) {
-                        const u32 seen = atomicAdd(st, 1u) + 1;
+                // the job's counters.  A workgroup reports when it meets a dense tile -- that tile and the tiles it has seen since
+                // its last report, so every report is unbiased -- and leaves its verdict for everybody (read after B1): the
+                // ordinary tile costs no global atomic, and a workgroup that never sees a dense tile never asks for a verdict
+                // (a dense REGION of a chromosome is handed over by the workgroups inside it only).
+                if (!dense) {
+                    unreported++;
+                } else {
+                    if (tid == 0 && job_mode == 0) {
+                        u32 *st = jobstat + 4 * ji;
+                        const u32 seen = atomicAdd(st, unreported + 1) + unreported + 1;
                         const u32 nr = atomicAdd(st + 1, dense_r ? 1u : 0u) + (dense_r ? 1u : 0u);
                         const u32 ne = atomicAdd(st + 2, dense_e ? 1u : 0u) + (dense_e ? 1u : 0u);
+                        u32 verdict = 0;
                         if (seen >= 16 && 10 * ne > 6 * seen) verdict = 2;
                         else if (seen >= 16 && 10 * (nr + ne) > 6 * seen) verdict = 1;
+                        sgb[L::MISC] = verdict;
                     }
-                    sgb[L::MISC] = verdict;
+                    unreported = 0;
+                    had_dense = true;
                 }
                 if (job_mode == 2 || (job_mode == 1 && !(HAS_M && DO_MLEN))) {
                     // the rest of my range in this chromosome: flags only, nothing staged
@@ -567,7 +573,7 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         __syncthreads();   // B1: lists, M words and edge ranks visible
         if (EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(EV_PRIO_EVENTS);
         EV_STAMP(5)
-        if (NSG == 1) {
+        if (NSG == 1 && had_dense) {
             const u32 v = __builtin_amdgcn_readfirstlane(sgb[L::MISC]);   // thread 0's verdict on the job (see job_mode)
             job_mode = v > job_mode ? v : job_mode;
         }
@@ -832,6 +838,9 @@ k_cc_events(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
         if (jn != ji) {
             job_mode = 0;
             next_skip = false;
+            unreported = 0;
+            if (had_dense && tid_ == 0) sgb[L::MISC] = 0;   // (read again after the next tile's B1 at the earliest)
+            had_dense = false;
         }
         cur_skip = fetched_skip;
         ji = jn;
@@ -863,8 +872,9 @@ struct EvTailPlan {
 };
 
 #define EV_TAIL_THREADS 1024u   // (the additions of the slow path are one block per chromosome: as many threads as shifts)
+template <typename JT = SpJobTable>
 __global__ void __launch_bounds__(EV_TAIL_THREADS)
-k_events_tail(const u32 *__restrict__ slab, const SpJobTable jobs, const EvTailPlan plan, const u32 *__restrict__ slab_cc,
+k_events_tail(const u32 *__restrict__ slab, const JT jobs, const EvTailPlan plan, const u32 *__restrict__ slab_cc,
               const u32 *__restrict__ slab_ac, const u32 *__restrict__ n_flagged, u32 S, u32 out_stride, u32 has_m, u32 do_ncc,
               u32 max_lag, u32 lagcap, int32_t c, u32 fused, u32 rowlen, u32 slow_path, const u32 *__restrict__ plan_cc,
               const u32 *__restrict__ plan_ac)

@@ -31,6 +31,7 @@
 #include "pmx_common.h"
 
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #define SP_TB 32768u                 // driver bits per tile
@@ -71,6 +72,30 @@ struct SpJobDev {
 struct SpJobTable {
     SpJobDev j[SP_MAXJOBS];
 };
+// The same table in DEVICE memory, any number of jobs (uploaded per launch on the launch's stream): the launches of
+// max_shift > 1023 -- the event kernel over hundreds of chromosomes, the window kernel over (chromosome x shift chunk)
+// jobs -- take all their jobs at once instead of 32 per launch (BASELINE config 5: 120 launches per step became 10).
+struct SpJobTableRef {
+    const SpJobDev *j;
+};
+
+// ji = the job of global tile g0 (tile0 is increasing): a linear scan of the table in the kernel arguments (at most 32
+// jobs), a binary search of a device-side table.  A macro on purpose: with the table passed BY REFERENCE to a helper, the
+// compiler dropped the scan of the kernel-argument table altogether (every workgroup started at job 0: a memory fault on
+// the first launch with a workgroup range beyond job 0's tiles... and on launches with one job, harmlessly right).
+#define FIRST_JOB(ji, JT, jobs, njobs, g0)                                         \
+    u32 ji = 0;                                                                    \
+    if constexpr (std::is_same<JT, SpJobTableRef>::value) {                        \
+        u32 lo_ = 0, hi_ = (njobs) - 1; /* the last job with tile0 <= g0 */        \
+        while (lo_ < hi_) {                                                        \
+            const u32 mid_ = (lo_ + hi_ + 1) >> 1;                                 \
+            if ((jobs).j[mid_].tile0 <= (g0)) lo_ = mid_;                          \
+            else hi_ = mid_ - 1;                                                   \
+        }                                                                          \
+        ji = lo_;                                                                  \
+    } else {                                                                       \
+        while (ji + 1 < (njobs) && (jobs).j[ji + 1].tile0 <= (g0)) ji++;           \
+    }
 
 // The fields of the job whose tiles are being prefetched, held in (scalar) registers: the table lives in the kernel
 // argument segment, and indexing it per tile cost a chain of four dependent scalar loads (~0.5 us) in every tile.
@@ -656,9 +681,9 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 #ifndef SP_ROLES
 #define SP_ROLES 0                 // 1: waves 0-1 carry (ncc, mscc.ccbins), waves 2-3 (mscc.fsum, mscc.rsum) -- A/B build
 #endif
-template <bool HAS_M, bool DO_NCC, bool CH>
+template <bool HAS_M, bool DO_NCC, bool CH, typename JT = SpJobTable>
 __global__ void __launch_bounds__(256, CH ? (HAS_M ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
-k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
+k_cc_sparse(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
             u32 *__restrict__ slab, const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged,
             const u32 *__restrict__ plan)
 {
@@ -704,9 +729,8 @@ k_cc_sparse(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
     u32 cntR_thread = 0;          // NCC-only mode: popcount of R accumulated per thread
     bool seg_written = false;     // this (workgroup, job) slab segment already holds a partial conversion
 
-    // job of the first tile (njobs is small)
-    u32 ji = 0;
-    while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
+    // job of the first tile
+    FIRST_JOB(ji, JT, jobs, njobs, g0)
 
 #ifdef SP_STAMPS
     unsigned long long stamp_acc[SP_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1074,7 +1098,8 @@ struct ReduceSpec {
 
 #define RS_NBX 32u   // chunks of 32 elements per row of 1024 shifts (rowlen / 32 in general); a block takes the chunks blockIdx.x, + gridDim.x, ...
 __device__ __forceinline__ u32 rs_rowlen(const ReduceSpec &rs) { return rs.rowlen ? rs.rowlen : 1024u; }
-__device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ slab, const SpJobTable &jobs, u32 seg_rows,
+template <typename JT>
+__device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ slab, const JT &jobs, u32 seg_rows,
                                                       const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r, u32 bx,
                                                       u64 (*part)[32])   // part[blockDim.x / 32][32]
 {
@@ -1132,7 +1157,8 @@ __device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ sl
     }
 }
 
-__device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab, const SpJobTable &jobs, u32 seg_rows,
+template <typename JT>
+__device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab, const JT &jobs, u32 seg_rows,
                                                     const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r)
 {
     __shared__ u64 part[32][32];   // (blocks of 256 or 1024 threads)
@@ -1142,8 +1168,9 @@ __device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab
     }
 }
 
+template <typename JT = SpJobTable>
 __global__ void __launch_bounds__(256)
-k_reduce_segments(const u32 *__restrict__ slab, const SpJobTable jobs, u32 seg_rows, ReduceSpec rs,
+k_reduce_segments(const u32 *__restrict__ slab, const JT jobs, u32 seg_rows, ReduceSpec rs,
                   const u32 *__restrict__ gate)
 {
     reduce_segments_row(slab, jobs, seg_rows, rs, gate, blockIdx.y);
@@ -1282,9 +1309,9 @@ __device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 fi
     }
 }
 
-template <bool CH>
+template <bool CH, typename JT = SpJobTable>
 __global__ void __launch_bounds__(256, CH ? AC_WAVES_CH : AC_WAVES)
-k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab,
+k_autocorr_edges(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab,
                  const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged, const u32 *__restrict__ plan = nullptr)
 {
     typedef AcLds L;
@@ -1311,8 +1338,7 @@ k_autocorr_edges(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     u32 cntM = 0, cntU = 0;
     bool seg_written = false;
 
-    u32 ji = 0;
-    while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
+    FIRST_JOB(ji, JT, jobs, njobs, g0)
 
     AcRegs ar;
     ac_fetch_job<CH>(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid, tile_flags);
@@ -1573,8 +1599,9 @@ __device__ __forceinline__ void ap_emit(const uint4 e, const uint4 m, u32 idx, u
 }
 
 // segment of a (workgroup, job) pair in the pair slab: [P: nl][N: nl][scalars: 16] u32
+template <typename JT = SpJobTable>
 __global__ void __launch_bounds__(256, AP_WAVES)
-k_autocorr_pairs(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 max_lag, u32 nl, u32 nh,
+k_autocorr_pairs(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 max_lag, u32 nl, u32 nh,
                  u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags, u32 *__restrict__ n_flagged)
 {
     extern __shared__ __align__(16) u32 ap_lds[];
@@ -1591,8 +1618,7 @@ k_autocorr_pairs(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
     if (g0 >= g1) return;
     for (u32 i = tid; i < 2 * nl; i += 256) ap_lds[i] = 0;
 
-    u32 ji = 0;
-    while (ji + 1 < njobs && jobs.j[ji + 1].tile0 <= g0) ji++;
+    FIRST_JOB(ji, JT, jobs, njobs, g0)
     u32 jn = ji;
     ApRegs ar;
     ap_fetch_job(ar, jobs.j[ji], g0 - jobs.j[ji].tile0, tid, nh);
@@ -1736,8 +1762,9 @@ k_autocorr_pairs(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 tiles_pe
 
 // out2[row][i] (+)= sum over the workgroups that touched the job of their pair-slab segments (see k_reduce_segments):
 // 32 consecutive elements x 8 workgroup phases per block
+template <typename JT = SpJobTable>
 __global__ void __launch_bounds__(256)
-k_reduce_pairs(const u32 *__restrict__ slab, const SpJobTable jobs, u32 nl, u32 max_lag, u32 lagcap, u32 accumulate)
+k_reduce_pairs(const u32 *__restrict__ slab, const JT jobs, u32 nl, u32 max_lag, u32 lagcap, u32 accumulate)
 {
     __shared__ u64 part[8][32];
     const u32 job = blockIdx.z, row = blockIdx.y;          // row 0: P, 1: N, 2: scalars
@@ -1828,8 +1855,9 @@ __device__ __forceinline__ void autocorr_finish_job(const SpJobDev &jb, long lon
     }
 }
 
+template <typename JT = SpJobTable>
 __global__ void __launch_bounds__(256)
-k_autocorr_finish(const SpJobTable jobs, u32 max_lag, u32 lagcap, u32 mode, int32_t c, u32 max_shift, u32 out_stride)
+k_autocorr_finish(const JT jobs, u32 max_lag, u32 lagcap, u32 mode, int32_t c, u32 max_shift, u32 out_stride)
 {
     __shared__ long long part[256];
     const SpJobDev &jb = jobs.j[blockIdx.x];
@@ -2021,12 +2049,12 @@ struct VJob {
 };
 
 // Cuts the global tile sequence of a launch into per-workgroup ranges and fills the device job table.
-static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr, uint32_t wg_per_cu, SpJobTable *tab,
+static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr, uint32_t wg_per_cu, SpJobDev *out,
                         uint32_t *total_tiles, uint32_t *tiles_per_wg, uint32_t *nwg, uint64_t tile_bits_override = 0)
 {
     uint32_t t = 0;
     for (uint32_t i = 0; i < n; i++) {
-        SpJobDev &d = tab->j[i];
+        SpJobDev &d = out[i];
         const pmx_job &jb = *vj[i].job;
         const uint64_t bits = jb.nbits + (autocorr ? 1 : 0);   // edges live on [0, nbits]
         const uint64_t tile_bits = tile_bits_override ? tile_bits_override : (autocorr ? AC_TB : SP_TB);
@@ -2055,7 +2083,7 @@ static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr,
     const uint32_t tpw = (uint32_t)((t + want - 1) / want);
     const uint32_t nw = (t + tpw - 1) / tpw;
     for (uint32_t i = 0; i < n; i++) {
-        SpJobDev &d = tab->j[i];
+        SpJobDev &d = out[i];
         d.wg_first = d.tile0 / tpw;
         d.wg_last = (d.tile0 + d.ntiles - 1) / tpw;
     }
@@ -2063,6 +2091,22 @@ static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr,
     *tiles_per_wg = tpw;
     *nwg = nw;
 }
+
+static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr, uint32_t wg_per_cu, SpJobTable *tab,
+                        uint32_t *total_tiles, uint32_t *tiles_per_wg, uint32_t *nwg, uint64_t tile_bits_override = 0)
+{
+    plan_launch(ctx, vj, n, autocorr, wg_per_cu, tab->j, total_tiles, tiles_per_wg, nwg, tile_bits_override);
+}
+
+// a launch's job table in device memory (any number of jobs)
+static int upload_table(pmx_ctx *ctx, const std::vector<SpJobDev> &v, SpJobTableRef *ref)
+{
+    const void *d = nullptr;
+    int rc = pmx_upload_jobtab(ctx, v.data(), v.size() * sizeof(SpJobDev), &d);
+    ref->j = (const SpJobDev *)d;
+    return rc;
+}
+#define SP_MAXJOBS_REF 2048u   // jobs per launch with a device-side table (bounds the slab: one segment per job beside the workgroups')
 
 // (chromosome x chunk-of-1024-shifts) jobs of a batch, in launches of at most SP_MAXJOBS
 static void expand_chunks(const pmx_job *jobs, uint32_t njobs, uint32_t nshifts, std::vector<VJob> &out,
@@ -2149,10 +2193,10 @@ static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p)
 }
 
 template <bool HAS_M, bool DO_NCC, u32 NSG>
-static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTable &tab, u32 n, u32 total, u32 tpw, u32 nwg, u32 c,
+static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTableRef &tab, u32 n, u32 total, u32 tpw, u32 nwg, u32 c,
                          u32 max_shift, u32 nhr, unsigned char *d_flags, u32 *d_nflagged, u32 *d_jobstat)
 {
-    auto kern = k_cc_events<HAS_M, DO_NCC, false, NSG, true>;
+    auto kern = k_cc_events<HAS_M, DO_NCC, false, NSG, true, SpJobTableRef>;
     static bool attr_set = false;   // (a context is single-threaded; the attribute is per process and device function)
     if (!attr_set) {
         PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2162,6 +2206,47 @@ static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTable &ta
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256 * NSG), pl.lds_bytes, ctx->stream, tab, n, total, tpw, c, max_shift, nhr, 0u,
                        pl.hn, pl.lo, ctx->d_slab, d_flags, d_flags, d_nflagged, d_jobstat);
     PMX_CHECK_LAUNCH("k_cc_events (max_shift > 1023)");
+    return PMX_OK;
+}
+
+// The window kernel in chunks of 1024 shifts over (chromosome x chunk) jobs with a device-side job table: every job of the
+// batch in launches of SP_MAXJOBS_REF (BASELINE config 5: 1000 jobs, one launch).  d_flags / d_nflagged: only the tiles the
+// event kernel flagged (the launch returns at once when there are none) and the sums are ADDED by a gated reduce;
+// null: every tile, rows written.
+static int launch_cc_window_chunks(pmx_ctx *ctx, const std::vector<VJob> &vjobs, bool has_m, bool do_ncc, int32_t c,
+                                   const ReduceSpec &rs, u32 nr, u32 nz, const unsigned char *d_flags, const u32 *d_nflagged)
+{
+    const bool behind_events = d_flags != nullptr;
+    for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS_REF) {
+        const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS_REF ? vjobs.size() - lo : SP_MAXJOBS_REF);
+        std::vector<SpJobDev> tab(n);
+        memset(tab.data(), 0, n * sizeof(SpJobDev));
+        uint32_t total, tpw, nwg;
+        plan_launch(ctx, &vjobs[lo], n, false, has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC, tab.data(), &total, &tpw, &nwg);
+        const size_t wwords = (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64;
+        int rc = behind_events ? pmx_ensure_slab_fb(ctx, wwords) : pmx_ensure_slab(ctx, wwords);
+        if (rc) return rc;
+        u32 *const wslab = behind_events ? ctx->d_slab_fb : ctx->d_slab;
+        SpJobTableRef ref;
+        rc = upload_table(ctx, tab, &ref);
+        if (rc) return rc;
+        pmx_timed_launch tl;
+        rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, behind_events);
+        if (rc) return rc;
+#define SP_LAUNCH(HM, NC)                                                                                                   \
+    hipLaunchKernelGGL((k_cc_sparse<HM, NC, true, SpJobTableRef>), dim3(nwg), dim3(256), 0, ctx->stream, ref, n, total, tpw, c, 5u, \
+                       wslab, d_flags, d_nflagged, (const u32 *)nullptr)
+        if (has_m && do_ncc) SP_LAUNCH(true, true);
+        else if (has_m) SP_LAUNCH(true, false);
+        else SP_LAUNCH(false, true);
+#undef SP_LAUNCH
+        PMX_CHECK_LAUNCH("k_cc_sparse");
+        rc = pmx_prof_end(ctx, &tl);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_reduce_segments<SpJobTableRef>, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)wslab, ref,
+                           (u32)SP_SEG_ROWS, rs, d_nflagged);
+        PMX_CHECK_LAUNCH("k_reduce_segments");
+    }
     return PMX_OK;
 }
 
@@ -2185,7 +2270,8 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
         total_flags += (jobs[i].nbits + SP_TB - 1) / SP_TB + EV_NQ;   // padding: an event tile flags EV_NQ window tiles
     }
     const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
-    const size_t stat_bytes = 4 * SP_MAXJOBS * sizeof(u32);
+    const uint32_t per_launch = njobs < SP_MAXJOBS_REF ? njobs : SP_MAXJOBS_REF;
+    const size_t stat_bytes = 4 * (size_t)per_launch * sizeof(u32);
     int rc = pmx_ensure_flags_cc(ctx, flag_bytes + 16 + stat_bytes);
     if (rc) return rc;
     unsigned char *d_flags = ctx->d_flags_cc;
@@ -2198,8 +2284,8 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
         if (rs.dst_row[i] == PMX_ROW_MSCC_FSUM || rs.dst_row[i] == PMX_ROW_MSCC_RSUM) rs_ev.is_signed[i] = 1;
     rs_ev.rowlen = pl.hn;
     const u32 nhr = (max_shift + 1 + 127) / 128;   // quads of R above a tile that hold partners of its forward reads
-    for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS) {
-        const uint32_t n = njobs - lo < SP_MAXJOBS ? njobs - lo : SP_MAXJOBS;
+    for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS_REF) {
+        const uint32_t n = njobs - lo < SP_MAXJOBS_REF ? njobs - lo : SP_MAXJOBS_REF;
         std::vector<VJob> ev(n);
         for (uint32_t i = 0; i < n; i++) {
             ev[i].job = &jobs[lo + i];
@@ -2207,69 +2293,51 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
             ev[i].d_n = max_shift + 1;
             ev[i].flag0 = flag0[lo + i];
         }
-        SpJobTable tab;
-        memset(&tab, 0, sizeof tab);
+        std::vector<SpJobDev> tab(n);
+        memset(tab.data(), 0, n * sizeof(SpJobDev));
         uint32_t total, tpw, nwg;
-        if (lo) PMX_HIP(hipMemsetAsync(d_jobstat, 0, stat_bytes, ctx->stream));   // (the next 32 jobs)
-        plan_launch(ctx, ev.data(), n, false, pl.wg_per_cu, &tab, &total, &tpw, &nwg, EV_TB);
+        if (lo) PMX_HIP(hipMemsetAsync(d_jobstat, 0, stat_bytes, ctx->stream));   // (the next launch's jobs)
+        plan_launch(ctx, ev.data(), n, false, pl.wg_per_cu, tab.data(), &total, &tpw, &nwg, EV_TB);
         rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * EV_SEG_ROWS * pl.hn + (size_t)nwg * 4 * pl.nsg * 12 * 2 + 64);
+        if (rc) return rc;
+        SpJobTableRef ref;
+        rc = upload_table(ctx, tab, &ref);
         if (rc) return rc;
         pmx_timed_launch tl;
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_EVENTS, &tl);
         if (rc) return rc;
 #define EVB(HM, NC)                                                                                                         \
-    (pl.nsg == 1   ? ev_big_launch<HM, NC, 1>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat)  \
-     : pl.nsg == 2 ? ev_big_launch<HM, NC, 2>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat)  \
-                   : ev_big_launch<HM, NC, 4>(ctx, pl, tab, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat))
+    (pl.nsg == 1   ? ev_big_launch<HM, NC, 1>(ctx, pl, ref, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat)  \
+     : pl.nsg == 2 ? ev_big_launch<HM, NC, 2>(ctx, pl, ref, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat)  \
+                   : ev_big_launch<HM, NC, 4>(ctx, pl, ref, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat))
         rc = has_m ? (do_ncc ? EVB(true, true) : EVB(true, false)) : EVB(false, true);
 #undef EVB
         if (rc) return rc;
         rc = pmx_prof_end(ctx, &tl);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream,
-                           (const u32 *)ctx->d_slab, tab, (u32)EV_SEG_ROWS, rs_ev, (const u32 *)nullptr);
+        hipLaunchKernelGGL(k_reduce_segments<SpJobTableRef>, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream,
+                           (const u32 *)ctx->d_slab, ref, (u32)EV_SEG_ROWS, rs_ev, (const u32 *)nullptr);
         PMX_CHECK_LAUNCH("k_reduce_segments");
         if (has_m) {
             EvTailPlan tp;
             memset(&tp, 0, sizeof tp);
-            hipLaunchKernelGGL(k_events_tail, dim3(n, 1), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
-                               (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)d_nflagged, max_shift, out_stride, 1u,
+            hipLaunchKernelGGL(k_events_tail<SpJobTableRef>, dim3(n, 1), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab,
+                               ref, tp, (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)d_nflagged, max_shift, out_stride, 1u,
                                do_ncc ? 1u : 0u, 0u, 1024u, (int32_t)c, 0u, pl.hn, 0u, (const u32 *)nullptr, (const u32 *)nullptr);
             PMX_CHECK_LAUNCH("k_events_tail");
         }
     }
-    // the flagged tiles: window kernel per (chromosome, chunk of 1024 shifts); nothing flagged: every launch returns at once
+    // the flagged tiles: window kernel per (chromosome, chunk of 1024 shifts); nothing flagged: the launch returns at once
     std::vector<VJob> vjobs;
     expand_chunks(jobs, njobs, max_shift + 1, vjobs, flag0.data());
     ReduceSpec rs_w = rs;
     rs_w.accumulate = 1;
-    for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS) {
-        const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS ? vjobs.size() - lo : SP_MAXJOBS);
-        SpJobTable tabW;
-        memset(&tabW, 0, sizeof tabW);
-        uint32_t total, tpw, nwg;
-        plan_launch(ctx, &vjobs[lo], n, false, has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC, &tabW, &total, &tpw, &nwg);
-        rc = pmx_ensure_slab_fb(ctx, (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
-        if (rc) return rc;
-        pmx_timed_launch tl;
-        rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, true);
-        if (rc) return rc;
-#define SP_LAUNCH(HM, NC)                                                                                              \
-    hipLaunchKernelGGL((k_cc_sparse<HM, NC, true>), dim3(nwg), dim3(256), 0, ctx->stream, tabW, n, total, tpw, (int32_t)c, 5u, \
-                       ctx->d_slab_fb, (const unsigned char *)d_flags, (const u32 *)d_nflagged, (const u32 *)nullptr)
-        if (has_m && do_ncc) SP_LAUNCH(true, true);
-        else if (has_m) SP_LAUNCH(true, false);
-        else SP_LAUNCH(false, true);
-#undef SP_LAUNCH
-        PMX_CHECK_LAUNCH("k_cc_sparse");
-        rc = pmx_prof_end(ctx, &tl);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab_fb, tabW,
-                           (u32)SP_SEG_ROWS, rs_w, (const u32 *)d_nflagged);
-        PMX_CHECK_LAUNCH("k_reduce_segments");
-    }
-    return PMX_OK;
+    return launch_cc_window_chunks(ctx, vjobs, has_m, do_ncc, (int32_t)c, rs_w, nr, nz, d_flags, d_nflagged);
 }
+
+// jobs one call of pmx_launch_cc_sparse_batch takes: launches with a device-side job table take the whole batch
+uint32_t pmx_cc_batch_jobs(uint32_t max_shift) { return max_shift > 1023 ? SP_MAXJOBS_REF : SP_MAXJOBS; }
+uint32_t pmx_autocorr_batch_jobs(void) { return SP_MAXJOBS_REF; }
 
 int pmx_events_take_big(uint32_t max_shift)
 {
@@ -2316,6 +2384,8 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
 
     std::vector<VJob> vjobs;
     expand_chunks(jobs, njobs, max_shift + 1, vjobs);
+    if (chunked)   // the window kernel alone over (chromosome x shift chunk) jobs (max_shift > 8191, or the event kernel disabled)
+        return launch_cc_window_chunks(ctx, vjobs, has_m, do_ncc, c, rs, nr, nz, nullptr, nullptr);
 
     // Pass 1 (sparse tiles): the event kernel over every chromosome; tiles whose lists would overflow are flagged.
     const bool use_events = events_enabled() && !ctx->window_only && !chunked;
@@ -2503,6 +2573,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
     const bool chunked = max_lag > 1023;
     const u32 lagcap = (u32)(((size_t)max_lag + 1 + 1023) / 1024 * 1024);
     const u32 lgG = chunked ? 5u : lg_slot_lanes(max_lag + 1);
+    typedef SpJobTableRef JT;   // job tables in device memory: every chromosome of the batch in one launch of each kernel
 
     // Pass 1 (sparse-edge tiles): pair enumeration over every chromosome; tiles with more than AP_CAP edges are flagged.
     // PMX_AUTOCORR_PAIRS=0 in the environment keeps everything on the window kernel (A/B measurements, tests).
@@ -2515,6 +2586,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
     unsigned char *d_flags = nullptr;
     u32 *d_nflagged = nullptr;
     const u32 nl = (max_lag + 1 + 63) / 64 * 64;
+    int rc;
     if (use_pairs) {
         uint64_t total_flags = 0;
         for (uint32_t i = 0; i < njobs; i++) {
@@ -2522,7 +2594,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
             total_flags += (jobs[i].nbits + 1 + AC_TB - 1) / AC_TB + AP_NQ / AC_NQ;   // padding: a pair tile flags AP_NQ / AC_NQ window tiles
         }
         const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
-        int rc = pmx_ensure_flags(ctx, flag_bytes + 16);
+        rc = pmx_ensure_flags(ctx, flag_bytes + 16);
         if (rc) return rc;
         d_flags = ctx->d_flags;
         d_nflagged = (u32 *)(ctx->d_flags + flag_bytes);
@@ -2534,8 +2606,8 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         u32 per_cu = (u32)((160u * 1024u) / (lds_bytes + 512));
         if (per_cu > AP_WAVES) per_cu = AP_WAVES;
         if (per_cu < 1) per_cu = 1;
-        for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS) {
-            const uint32_t n = njobs - lo < SP_MAXJOBS ? njobs - lo : SP_MAXJOBS;
+        for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS_REF) {
+            const uint32_t n = njobs - lo < SP_MAXJOBS_REF ? njobs - lo : SP_MAXJOBS_REF;
             std::vector<VJob> vj(n);
             for (uint32_t i = 0; i < n; i++) {
                 vj[i].job = &jobs[lo + i];
@@ -2543,30 +2615,33 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
                 vj[i].d_n = max_lag + 1;
                 vj[i].flag0 = flag0[lo + i];
             }
-            SpJobTable tab;
-            memset(&tab, 0, sizeof tab);
+            std::vector<SpJobDev> tab(n);
+            memset(tab.data(), 0, n * sizeof(SpJobDev));
             uint32_t total, tpw, nwg;
-            plan_launch(ctx, vj.data(), n, true, per_cu, &tab, &total, &tpw, &nwg, AP_TB);
+            plan_launch(ctx, vj.data(), n, true, per_cu, tab.data(), &total, &tpw, &nwg, AP_TB);
             rc = pmx_ensure_slab2(ctx, (size_t)(nwg + n) * seg_stride);
             if (rc) return rc;
-            pmx_timed_launch tl;
-            rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
+            JT ref;
+            rc = upload_table(ctx, tab, &ref);
             if (rc) return rc;
             if (lds_bytes > 64 * 1024) {   // (max_lag above ~7870: the histograms alone pass 64 KB)
                 static bool attr_set = false;
                 if (!attr_set) {
-                    PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_autocorr_pairs),
+                    PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_autocorr_pairs<JT>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
                     attr_set = true;
                 }
             }
-            hipLaunchKernelGGL(k_autocorr_pairs, dim3(nwg), dim3(256), lds_bytes, ctx->stream, tab, n, total, tpw, max_lag, nl,
+            pmx_timed_launch tl;
+            rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_autocorr_pairs<JT>, dim3(nwg), dim3(256), lds_bytes, ctx->stream, ref, n, total, tpw, max_lag, nl,
                                nh, ctx->d_slab2, d_flags, d_nflagged);
             PMX_CHECK_LAUNCH("k_autocorr_pairs");
             rc = pmx_prof_end(ctx, &tl);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_reduce_pairs, dim3((max_lag + 1 + 31) / 32 < 64 ? (max_lag + 1 + 31) / 32 : 64, 3, n), dim3(256), 0, ctx->stream,
-                               (const u32 *)ctx->d_slab2, tab, nl, max_lag, lagcap, 0u);
+            hipLaunchKernelGGL(k_reduce_pairs<JT>, dim3((max_lag + 1 + 31) / 32 < 64 ? (max_lag + 1 + 31) / 32 : 64, 3, n), dim3(256), 0,
+                               ctx->stream, (const u32 *)ctx->d_slab2, ref, nl, max_lag, lagcap, 0u);
             PMX_CHECK_LAUNCH("k_reduce_pairs");
         }
     }
@@ -2586,41 +2661,47 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
     rs.accumulate = use_pairs ? 1 : 0;
     rs.out_stride = out_stride;
 
-    for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS) {
-        const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS ? vjobs.size() - lo : SP_MAXJOBS);
-        SpJobTable tab;
-        memset(&tab, 0, sizeof tab);
+    for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS_REF) {
+        const uint32_t n = (uint32_t)(vjobs.size() - lo < SP_MAXJOBS_REF ? vjobs.size() - lo : SP_MAXJOBS_REF);
+        std::vector<SpJobDev> tab(n);
+        memset(tab.data(), 0, n * sizeof(SpJobDev));
         uint32_t total, tpw, nwg;
-        plan_launch(ctx, &vjobs[lo], n, true, chunked ? AC_WAVES_CH : AC_WAVES, &tab, &total, &tpw, &nwg);
-        int rc = pmx_ensure_slab_ac(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
+        plan_launch(ctx, &vjobs[lo], n, true, chunked ? AC_WAVES_CH : AC_WAVES, tab.data(), &total, &tpw, &nwg);
+        rc = pmx_ensure_slab_ac(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
+        if (rc) return rc;
+        JT ref;
+        rc = upload_table(ctx, tab, &ref);
         if (rc) return rc;
         pmx_timed_launch tl;
         rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl);
         if (rc) return rc;
         if (chunked)
-            hipLaunchKernelGGL(k_autocorr_edges<true>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,
-                               ctx->d_slab_ac, (const unsigned char *)d_flags, (const u32 *)d_nflagged);
+            hipLaunchKernelGGL((k_autocorr_edges<true, JT>), dim3(nwg), dim3(256), 0, ctx->stream, ref, n, total, tpw, lgG,
+                               ctx->d_slab_ac, (const unsigned char *)d_flags, (const u32 *)d_nflagged, (const u32 *)nullptr);
         else
-            hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, lgG,
-                               ctx->d_slab_ac, (const unsigned char *)d_flags, (const u32 *)d_nflagged);
+            hipLaunchKernelGGL((k_autocorr_edges<false, JT>), dim3(nwg), dim3(256), 0, ctx->stream, ref, n, total, tpw, lgG,
+                               ctx->d_slab_ac, (const unsigned char *)d_flags, (const u32 *)d_nflagged, (const u32 *)nullptr);
         PMX_CHECK_LAUNCH("k_autocorr_edges");
         rc = pmx_prof_end(ctx, &tl);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_reduce_segments, dim3(32, 3, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab_ac, tab,
+        hipLaunchKernelGGL(k_reduce_segments<JT>, dim3(32, 3, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab_ac, ref,
                            (u32)AC_SEG_ROWS, rs, (const u32 *)d_nflagged);
         PMX_CHECK_LAUNCH("k_reduce_segments");
     }
     // the recurrence needs every chunk of a chromosome: run it once all launches are queued (same stream)
-    for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS) {
-        const uint32_t n = njobs - lo < SP_MAXJOBS ? njobs - lo : SP_MAXJOBS;
-        SpJobTable tab;
-        memset(&tab, 0, sizeof tab);
+    for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS_REF) {
+        const uint32_t n = njobs - lo < SP_MAXJOBS_REF ? njobs - lo : SP_MAXJOBS_REF;
+        std::vector<SpJobDev> tab(n);
+        memset(tab.data(), 0, n * sizeof(SpJobDev));
         for (uint32_t i = 0; i < n; i++) {
-            tab.j[i].flags = 1;
-            tab.j[i].out = (u64 *)jobs[lo + i].d_out;
-            tab.j[i].out2 = (u64 *)jobs[lo + i].d_out2;
+            tab[i].flags = 1;
+            tab[i].out = (u64 *)jobs[lo + i].d_out;
+            tab[i].out2 = (u64 *)jobs[lo + i].d_out2;
         }
-        hipLaunchKernelGGL(k_autocorr_finish, dim3(n), dim3(256), 0, ctx->stream, tab, max_lag, lagcap, mode,
+        JT ref;
+        rc = upload_table(ctx, tab, &ref);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_autocorr_finish<JT>, dim3(n), dim3(256), 0, ctx->stream, ref, max_lag, lagcap, mode,
                            (int32_t)read_len - 1, max_shift, out_stride);
         PMX_CHECK_LAUNCH("k_autocorr_finish");
     }

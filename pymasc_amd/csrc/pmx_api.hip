@@ -104,6 +104,17 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
         ctx->feed_used[i] = false;
     }
     ctx->feed_next = 0;
+    for (int i = 0; i < 2; i++) {
+        ctx->d_jobtab[i] = nullptr;
+        ctx->jobtab_bytes[i] = 0;
+    }
+    for (int i = 0; i < PMX_JOBTAB_SLOTS; i++) {
+        ctx->h_jobtab[i] = nullptr;
+        ctx->h_jobtab_bytes[i] = 0;
+        ctx->jobtab_done[i] = nullptr;
+        ctx->jobtab_used[i] = false;
+    }
+    ctx->jobtab_next = 0;
     ctx->copy_stream = nullptr;
     ctx->feed_copied = nullptr;
     ctx->d_build_err = nullptr;
@@ -161,6 +172,12 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (ctx->feed_copied) (void)hipEventDestroy(ctx->feed_copied);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d_build_err) (void)hipFree(ctx->d_build_err);
+    for (int i = 0; i < 2; i++)
+        if (ctx->d_jobtab[i]) (void)hipFree(ctx->d_jobtab[i]);
+    for (int i = 0; i < PMX_JOBTAB_SLOTS; i++) {
+        if (ctx->h_jobtab[i]) (void)hipHostFree(ctx->h_jobtab[i]);
+        if (ctx->jobtab_done[i]) (void)hipEventDestroy(ctx->jobtab_done[i]);
+    }
     for (auto &tl : ctx->timed) {
         (void)hipEventDestroy(tl.start);
         (void)hipEventDestroy(tl.stop);
@@ -202,6 +219,43 @@ int pmx_ensure_scratch(pmx_ctx *ctx, size_t words)
     size_t want = words < 4096 ? 4096 : words;
     PMX_HIP(hipMalloc((void **)&ctx->d_scratch, want * sizeof(u64)));
     ctx->scratch_words = want;
+    return PMX_OK;
+}
+
+int pmx_upload_jobtab(pmx_ctx *ctx, const void *src, size_t bytes, const void **d)
+{
+    const int si = ctx->stream == ctx->aux_stream ? 1 : 0;
+    if (ctx->jobtab_bytes[si] < bytes) {
+        if (ctx->d_jobtab[si]) {
+            PMX_HIP(hipStreamSynchronize(ctx->stream));
+            PMX_HIP(hipFree(ctx->d_jobtab[si]));
+            ctx->d_jobtab[si] = nullptr;
+            ctx->jobtab_bytes[si] = 0;
+        }
+        const size_t want = bytes * 2 + 4096;
+        PMX_HIP(hipMalloc(&ctx->d_jobtab[si], want));
+        ctx->jobtab_bytes[si] = want;
+    }
+    // page-locked staging slot: taken again only after the copy out of it has run
+    const uint32_t slot = ctx->jobtab_next;
+    ctx->jobtab_next = (slot + 1) % PMX_JOBTAB_SLOTS;
+    if (!ctx->jobtab_done[slot]) PMX_HIP(hipEventCreateWithFlags(&ctx->jobtab_done[slot], hipEventDisableTiming));
+    if (ctx->jobtab_used[slot]) PMX_HIP(hipEventSynchronize(ctx->jobtab_done[slot]));
+    if (ctx->h_jobtab_bytes[slot] < bytes) {
+        if (ctx->h_jobtab[slot]) PMX_HIP(hipHostFree(ctx->h_jobtab[slot]));
+        ctx->h_jobtab[slot] = nullptr;
+        ctx->h_jobtab_bytes[slot] = 0;
+        const size_t want = bytes * 2 + 4096;
+        PMX_HIP(hipHostMalloc(&ctx->h_jobtab[slot], want, hipHostMallocDefault));
+        ctx->h_jobtab_bytes[slot] = want;
+    }
+    memcpy(ctx->h_jobtab[slot], src, bytes);
+    // (the device buffer of a stream is reused by every upload on it: the copy is ordered behind the kernels that still read
+    // the previous table, which were queued on the same stream)
+    PMX_HIP(hipMemcpyAsync(ctx->d_jobtab[si], ctx->h_jobtab[slot], bytes, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipEventRecord(ctx->jobtab_done[slot], ctx->stream));
+    ctx->jobtab_used[slot] = true;
+    *d = ctx->d_jobtab[si];
     return PMX_OK;
 }
 
@@ -867,9 +921,9 @@ int pmx_mappable_len_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *con
         }
         return PMX_OK;
     }
-    const uint32_t chunk = pmx_sparse_max_jobs();
+    const uint32_t chunk = pmx_autocorr_batch_jobs();
     const size_t ac_words = pmx_autocorr_scratch_words(max_shift);
-    pmx_job jobs[64];
+    std::vector<pmx_job> jobs(njobs < chunk ? njobs : chunk);
     for (uint32_t lo = 0; lo < njobs; lo += chunk) {
         const uint32_t n = njobs - lo < chunk ? njobs - lo : chunk;
         int rc = pmx_ensure_scratch(ctx, (size_t)n * ac_words);
@@ -882,7 +936,7 @@ int pmx_mappable_len_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *con
             jobs[i].d_out = d_out[lo + i];
             jobs[i].d_out2 = (uint64_t *)(ctx->d_scratch + (size_t)i * ac_words);
         }
-        rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_shift, 0, 1, max_shift, max_shift + 1);
+        rc = pmx_launch_autocorr_edges_batch(ctx, jobs.data(), n, max_shift, 0, 1, max_shift, max_shift + 1);
         if (rc) return rc;
     }
     return PMX_OK;
@@ -987,9 +1041,9 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         }
         return PMX_OK;
     }
-    const uint32_t chunk = pmx_sparse_max_jobs();
+    const uint32_t chunk = pmx_cc_batch_jobs(max_shift);
     const size_t ac_words = pmx_autocorr_scratch_words(max_lag);
-    pmx_job jobs[64];
+    std::vector<pmx_job> jobs(njobs < chunk ? njobs : chunk);
     for (uint32_t lo = 0; lo < njobs; lo += chunk) {
         const uint32_t n = njobs - lo < chunk ? njobs - lo : chunk;
         if (do_mlen) {
@@ -1020,10 +1074,10 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             // the event kernel stages M and lists its run edges anyway: it takes the edge pairs of the mappable-length pass
             // too, and only the window kernel for the tiles it flagged + the recurrence remain of that pass
             pmx_fused_mlen fm;
-            rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, false, max_lag, &fm);
+            rc = pmx_launch_cc_sparse_batch(ctx, jobs.data(), n, max_shift, read_len, do_ncc, stride, false, max_lag, &fm);
             if (rc) return rc;
             if (!fm.done) {   // (not expected: the launcher declined the fusion)
-                rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
+                rc = pmx_launch_autocorr_edges_batch(ctx, jobs.data(), n, max_lag, 1, read_len, max_shift, stride);
                 if (rc) return rc;
             }
             continue;
@@ -1031,14 +1085,14 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         bool forked = false;
         rc = PMX_OK;
         if (do_mlen && !fork) {
-            rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
+            rc = pmx_launch_autocorr_edges_batch(ctx, jobs.data(), n, max_lag, 1, read_len, max_shift, stride);
             if (rc) return rc;
         } else if (do_mlen) {
             PMX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
             PMX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
             hipStream_t main_stream = ctx->stream;
             ctx->stream = ctx->aux_stream;       // the launchers enqueue on ctx->stream (a context is single-threaded)
-            rc = pmx_launch_autocorr_edges_batch(ctx, jobs, n, max_lag, 1, read_len, max_shift, stride);
+            rc = pmx_launch_autocorr_edges_batch(ctx, jobs.data(), n, max_lag, 1, read_len, max_shift, stride);
             ctx->stream = main_stream;
             forked = true;
         }
@@ -1054,7 +1108,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             if (forked) (void)join();
             return rc;
         }
-        rc = pmx_launch_cc_sparse_batch(ctx, jobs, n, max_shift, read_len, do_ncc, stride, !do_mlen);
+        rc = pmx_launch_cc_sparse_batch(ctx, jobs.data(), n, max_shift, read_len, do_ncc, stride, !do_mlen);
         if (forked) {
             const hipError_t er = join();
             if (!rc && er != hipSuccess) {

@@ -39,6 +39,7 @@ struct pmx_timed_launch {
 };
 
 #define PMX_FEED_SLOTS 3
+#define PMX_JOBTAB_SLOTS 8
 
 struct pmx_ctx {
     int device;
@@ -85,6 +86,15 @@ struct pmx_ctx {
     uint32_t feed_next;
     hipStream_t copy_stream;     // H2D copies of the feeders run here, one slot ahead of the kernels on `stream`
     hipEvent_t feed_copied;
+    // job tables in device memory (kernels_sparse.hip: SpJobTableRef): one buffer per stream of the context (main / auxiliary),
+    // filled from a ring of page-locked staging slots so that an upload never waits for the GPU
+    void *d_jobtab[2];
+    size_t jobtab_bytes[2];
+    void *h_jobtab[PMX_JOBTAB_SLOTS];
+    size_t h_jobtab_bytes[PMX_JOBTAB_SLOTS];
+    hipEvent_t jobtab_done[PMX_JOBTAB_SLOTS];
+    bool jobtab_used[PMX_JOBTAB_SLOTS];
+    uint32_t jobtab_next;
     u64 *d_build_err;            // pmx_bits_build_batch: one range-error word per job since the last pmx_bits_build_status
     size_t build_err_cap, build_err_jobs;
     u64 *d_out_stage;
@@ -98,6 +108,9 @@ struct pmx_ctx {
 int pmx_prof_begin(pmx_ctx *ctx, int kernel_id, pmx_timed_launch *tl, bool fallback = false);
 int pmx_prof_end(pmx_ctx *ctx, pmx_timed_launch *tl);
 int pmx_ensure_scratch(pmx_ctx *ctx, size_t words);
+// copies `bytes` of a job table to the device buffer of the context's current stream (stream-ordered; the source may be
+// reused at once); *d receives the device address
+int pmx_upload_jobtab(pmx_ctx *ctx, const void *src, size_t bytes, const void **d);
 
 // ---- launchers implemented next to their kernels --------------------------------------------
 // bits (kernels_bits.hip)
@@ -140,6 +153,8 @@ int pmx_events_can_fuse_mlen(uint32_t max_shift, uint32_t max_lag);
 // the event kernel (not the window kernel in shift chunks) takes this max_shift > 1023
 int pmx_events_take_big(uint32_t max_shift);
 uint32_t pmx_sparse_max_jobs(void);
+uint32_t pmx_cc_batch_jobs(uint32_t max_shift);   // jobs per call of pmx_launch_cc_sparse_batch (device-side job tables beyond 1023 shifts)
+uint32_t pmx_autocorr_batch_jobs(void);           // ... of pmx_launch_autocorr_edges_batch
 // Writes rows NCC_CCBINS / MSCC_FSUM / MSCC_CCBINS / MSCC_RSUM and the scalar row of every job's result block
 // (rows the batch does not produce are written as zeros, MLEN included when there is no mappability).
 int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
