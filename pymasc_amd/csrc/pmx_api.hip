@@ -1061,15 +1061,19 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         // fork: the mappable-length pass on the auxiliary stream, beside the set-bit kernel (they share no output word:
         // row MLEN and scalar [2] belong to the autocorrelation, everything else to the cross-correlation)
         // PMX_AUTOCORR_FORK=0 in the environment keeps everything on the caller's stream (per-kernel profiling)
+        ctx->window_only = (flags & PMX_FLAG_WINDOW_ONLY) != 0;
         static const bool fork_enabled = [] {
             const char *e = getenv("PMX_AUTOCORR_FORK");
             return !(e && e[0] == '0');
         }();
         // beside the shift-chunked instantiation (max_shift > 1023) the fork does not pay (config 5 on one GPU: 17.4 ms
         // forked, 16.5 ms in sequence): the pair pass then holds 40 KB of histograms per workgroup
-        const bool fork = fork_enabled && max_shift <= 1023;
+        static const bool fork_big = [] {   // PMX_AUTOCORR_FORK_BIG=1: also beside the event kernel of max_shift > 1023 (A/B)
+            const char *e = getenv("PMX_AUTOCORR_FORK_BIG");
+            return e && e[0] == '1';
+        }();
+        const bool fork = fork_enabled && (max_shift <= 1023 || (fork_big && pmx_events_take_big(max_shift) && !ctx->window_only));
         int rc;
-        ctx->window_only = (flags & PMX_FLAG_WINDOW_ONLY) != 0;
         if (do_mlen && !ctx->window_only && pmx_events_can_fuse_mlen(max_shift, max_lag)) {
             // the event kernel stages M and lists its run edges anyway: it takes the edge pairs of the mappable-length pass
             // too, and only the window kernel for the tiles it flagged + the recurrence remain of that pass
