@@ -388,7 +388,7 @@ def main():
     #                         stream-ordered call per genome, copies one chromosome ahead of the builder kernels, range check
     #                         deferred) -> pmx_cc_batch_dev -> exchange -> rows
     #   end_to_end_calculator the drop-in boundary itself: CCHipCalculator.feed_reads per chromosome (reads in file order:
-    #                         int32 position + uint16 read length + strand, page-locked) -> finishup_calculation ->
+    #                         int32 position with the strand in its top bit, read length as one int or uint16; page-locked) -> finishup_calculation ->
     #                         get_whole_result (the reference's result objects), rows compared with the resident-vector run
     end_to_end = None
     calc_leg = None
@@ -454,8 +454,9 @@ def main():
                 order = np.argsort(pos, kind="stable")
                 # a run of reads of one length passes that length as a scalar (what a reader of single-end ChIP-seq data sees)
                 uniform = bool((ln == L).all())
-                reads[v.name] = (pinned(pos[order], np.int32), L if uniform else pinned(ln[order], np.uint16),
-                                 pinned(rv[order], np.uint8))
+                # ... and the strand travels in the top bit of the position word (ffi.pack_strand): 4 bytes per read
+                reads[v.name] = (pinned(ffi.pack_strand(pos[order].astype(np.int32), rv[order]), np.int32),
+                                 L if uniform else pinned(ln[order], np.uint16), None)
                 if with_m:      # BigWig (begin, end): set(begin + 1, end)
                     tracks[v.name] = (pinned(v.h_first - 1, np.uint32), h[3], None)
             names = [v.name for v in vecs]
@@ -495,14 +496,20 @@ def main():
                 fence()
                 pr.disable()
                 pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
+            # (the interpreter's generational garbage collector walks every live object of this process -- torch included --
+            # whenever its allocation counters trip: ~45 ms once every few calls here, nothing to do with the path measured;
+            # it is paused for the timed calls, as for any micro-benchmark of Python-level code)
+            import gc
+            gc.collect()
+            gc.disable()
             t1 = time.perf_counter()
             for _ in range(n_e2e):
                 whole = calc_step()
             fence()
             dtc = (time.perf_counter() - t1) / n_e2e
-            if os.environ.get("BENCH_CALC_PROFILE"):
-                print("[calc leg] feed (host, paced by the copies) / finishup + results / close (ms):",
-                      [[round(x * 1e3, 2) for x in st] for st in stamps[-3:]], file=sys.stderr)
+            gc.enable()
+            print("[calc leg] feed (host, paced by the copies) / finishup + results / close (ms), every call:",
+                  [[round(x * 1e3, 2) for x in st] for st in stamps], file=sys.stderr)
             # rows equal to the resident-vector run (job order = this rank's slot order at one rank)
             hr = rows.cpu().numpy()
             for slot, j in enumerate(mine):
@@ -516,11 +523,11 @@ def main():
             nreads = sum(r[0].size for r in reads.values())
             calc_leg = {"value": work_per_step / dtc, "unit": "shifts*bp/s", "ms_per_step": dtc * 1e3, "steps": n_e2e,
                         "reads": int(nreads), "reads_per_s": nreads / dtc,
-                        "h2d_bytes": int(sum(r[0].nbytes + getattr(r[1], "nbytes", 0) + r[2].nbytes for r in reads.values())
+                        "h2d_bytes": int(sum(r[0].nbytes + getattr(r[1], "nbytes", 0) + getattr(r[2], "nbytes", 0) for r in reads.values())
                                          + sum(t[0].nbytes + t[1].nbytes for t in tracks.values())),
-                        "what": "CCHipCalculator (the class handler/factory.py constructs): feed_reads(chrom, int32 pos, read "
-                                "length (one int per chromosome where all reads have it, else uint16), uint8 strand; page-locked "
-                                "arrays in file order) per chromosome -> pmx_feed_reads "
+                        "what": "CCHipCalculator (the class handler/factory.py constructs): feed_reads(chrom, int32 pos with the "
+                                "strand in its top bit, read length (one int per chromosome where all reads have it, else uint16); "
+                                "page-locked arrays in file order) per chromosome -> pmx_feed_reads "
                                 "(duplicate rules + read-length sums + bit set on the device) -> finishup_calculation (one batched "
                                 "pmx_cc_batch_dev, one synchronisation, one copy back) -> get_whole_result (the reference's result "
                                 "objects, cc curves computed); rows equal to the resident-vector run"}

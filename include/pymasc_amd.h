@@ -143,7 +143,8 @@ int pmx_host_free(pmx_ctx *ctx, void *h);
 #define PMX_FEED_WORDS              16
 #define PMX_FEED_ERR_BASE (1ull << 62)
 /* feed_forward_read / feed_reverse_read (mscc.pyx:370-418) for a run of n reads of one chromosome in FILE ORDER:
- * h_pos[i] = 1-based leftmost position, h_readlen[i] = query length, h_is_reverse[i] != 0 for the reverse strand
+ * h_pos[i] = 1-based leftmost position, h_readlen[i] = query length, h_is_reverse[i] != 0 for the reverse strand -- or
+ * h_is_reverse = NULL and the strand PACKED into the top bit of h_pos[i] (set: reverse; 4 bytes per read instead of 5) --
  * (forward bit: pos; reverse bit: pos + readlen - 1).  pos_bytes: 4 (int32) or 8 (int64); len_bytes: 2 (uint16), 4 (int32)
  * or 8 (int64), or 0: every read of the run has the same length and h_readlen points to that ONE int64.  Applies the
  * reference's rules in file order across calls: a forward read at the position of the previous forward read is a

@@ -292,9 +292,10 @@ class CCHipCalculator:
                                                    self._state_ptr(self._cur_slot)))
         self._fed += int(pos.size)
 
-    def feed_reads(self, chrom: str, pos: np.ndarray, readlen: np.ndarray, is_reverse: np.ndarray) -> None:
+    def feed_reads(self, chrom: str, pos: np.ndarray, readlen: np.ndarray, is_reverse: Optional[np.ndarray]) -> None:
         """Bulk variant of the two methods above for one chromosome: arrays in file order (int32 or int64 positions,
-        uint16 / int32 / int64 read lengths or ONE int when every read of the chunk has that length, strand as bool / uint8).  Not part of the reference protocol; it removes the per-read Python call for
+        uint16 / int32 / int64 read lengths or ONE int when every read of the chunk has that length, strand as bool / uint8, or
+        None with the strand packed into the top bit of every position: ffi.pack_strand).  Not part of the reference protocol; it removes the per-read Python call for
         vectorised readers, and the host does not walk the reads at all: the order of the chunk against the reads fed
         before is checked here (first position), everything else -- order inside the chunk, range, duplicates, read-length
         sums -- by the device, so ReadUnsortedError / IndexError for a read inside the chunk are raised when the results
@@ -302,11 +303,14 @@ class CCHipCalculator:
         pos = np.asarray(pos)
         if pos.size == 0:
             return
-        self._check_pos(chrom, int(pos[0]))
+        packed = is_reverse is None
+        top = (1 << (8 * pos.dtype.itemsize - 1)) - 1 if packed else -1      # (mask of the position bits)
+        self._check_pos(chrom, int(pos[0]) & top if packed else int(pos[0]))
         if self._buf.n:                              # reads fed one by one before this chunk go first
             self._to_device(*self._buf.take())
-        self._to_device(pos, readlen if np.ndim(readlen) == 0 else np.asarray(readlen), np.asarray(is_reverse))
-        self._last_pos = max(self._last_pos, int(pos[-1]))
+        self._to_device(pos, readlen if np.ndim(readlen) == 0 else np.asarray(readlen), None if packed else np.asarray(is_reverse))
+        last = int(pos[-1]) & top if packed else int(pos[-1])
+        self._last_pos = max(self._last_pos, last)
 
     # ---- per-chromosome calculation ---------------------------------------------------------------
     def _load_mappability(self, chrom: str, nbits: int):

@@ -19,8 +19,20 @@
 
 #define FEED_ERR_BASE (1ull << 62)   // error words hold FEED_ERR_BASE - index (atomicMax keeps the FIRST index); 0 = none
 
+// position i; with the strand PACKED into the top bit of the position word (rev == nullptr: 4 instead of 5 bytes per read over
+// PCIe) that bit is masked off
 template <typename T>
-__device__ __forceinline__ int64_t feed_ld(const T *p, uint64_t i) { return (int64_t)p[i]; }
+__device__ __forceinline__ int64_t feed_ld(const T *p, uint64_t i, bool packed)
+{
+    const T v = p[i];
+    constexpr T top = (T)((T)1 << (8 * sizeof(T) - 1));
+    return (int64_t)(packed ? (T)(v & (T)~top) : v);
+}
+template <typename T>
+__device__ __forceinline__ bool feed_rev(const T *p, const unsigned char *rev, uint64_t i)
+{
+    return rev ? rev[i] != 0 : p[i] < 0;   // (packed: the sign bit)
+}
 // read lengths: an array, or (null pointer) ONE length for every read of the run
 template <typename T>
 __device__ __forceinline__ int64_t feed_len(const T *p, int64_t uniform, uint64_t i) { return p ? (int64_t)p[i] : uniform; }
@@ -30,9 +42,13 @@ __global__ void __launch_bounds__(256) k_feed_maxlen(const LT *__restrict__ rlen
                                                      uint64_t n, u64 *__restrict__ state)
 {
     u64 m = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t l = feed_len(rlen, ulen, i);
-        if (rev[i] && l > 0 && (u64)l > m) m = (u64)l;
+    if (!rlen) {                       // one length for every read (the strand does not matter for the bound)
+        m = ulen > 0 ? (u64)ulen : 0;
+    } else {
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+            const int64_t l = feed_len(rlen, ulen, i);
+            if ((!rev || rev[i]) && l > 0 && (u64)l > m) m = (u64)l;   // (packed strand: the longest read of either strand)
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const u64 o = __shfl_down(m, off, 64);
@@ -56,12 +72,13 @@ __global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, 
     const int64_t prev_last = base ? (int64_t)state[PMX_FEED_LAST_POS] : 0;            // _last_pos (0 at a chromosome's start)
     const int64_t prev_fwd = (int64_t)state[PMX_FEED_LAST_FORWARD_POS];                 // _last_forward_pos (0 likewise)
     const int64_t maxlen = (int64_t)state[PMX_FEED_MAX_REVERSE_LEN];
+    const bool packed = rev == nullptr;
     u64 fsum = 0, rsum = 0, nf = 0, nr = 0, maxf = 0, e_sort = 0, e_range = 0;
     bool any_f = false;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t p = feed_ld(pos, i), l = feed_len(rlen, ulen, i);
-        const bool rv = rev[i] != 0;
-        const int64_t before = i ? feed_ld(pos, i - 1) : prev_last;
+        const int64_t p = feed_ld(pos, i, packed), l = feed_len(rlen, ulen, i);
+        const bool rv = feed_rev(pos, rev, i);
+        const int64_t before = i ? feed_ld(pos, i - 1, packed) : prev_last;
         if (p < before) {                                                               // mscc.pyx:362-363
             const u64 code = FEED_ERR_BASE - (base + i);
             e_sort = code > e_sort ? code : e_sort;
@@ -75,7 +92,7 @@ __global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, 
         if (!rv) {
             // duplicate: an earlier forward read at this position (sorted input: such reads are the ones right before it)
             bool dup = p == prev_fwd;
-            for (uint64_t j = i; !dup && j > 0 && feed_ld(pos, j - 1) == p; j--) dup = rev[j - 1] == 0;
+            for (uint64_t j = i; !dup && j > 0 && feed_ld(pos, j - 1, packed) == p; j--) dup = !feed_rev(pos, rev, j - 1);
             any_f = true;
             if ((u64)p > maxf) maxf = (u64)p;
             if (!dup) {
@@ -87,9 +104,9 @@ __global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, 
             bool set = (R[bit >> 6] >> (bit & 63)) & 1ull;                              // by an earlier chunk
             const int64_t lowest = bit - maxlen + 1;                                    // by an earlier read of this chunk
             for (uint64_t j = i; !set && j > 0; j--) {
-                const int64_t pj = feed_ld(pos, j - 1);
+                const int64_t pj = feed_ld(pos, j - 1, packed);
                 if (pj < lowest) break;
-                set = rev[j - 1] != 0 && pj + feed_len(rlen, ulen, j - 1) - 1 == bit;
+                set = feed_rev(pos, rev, j - 1) && pj + feed_len(rlen, ulen, j - 1) - 1 == bit;
             }
             if (!set) {
                 rsum += (u64)l;
@@ -145,12 +162,12 @@ __global__ void __launch_bounds__(256) k_feed_finish(const PT *__restrict__ pos,
                                                      u64 *__restrict__ R, u64 *__restrict__ state)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (!rev[i]) continue;
-        const int64_t bit = feed_ld(pos, i) + feed_len(rlen, ulen, i) - 1;
+        if (!feed_rev(pos, rev, i)) continue;
+        const int64_t bit = feed_ld(pos, i, rev == nullptr) + feed_len(rlen, ulen, i) - 1;
         if (bit >= 0 && (uint64_t)bit < nbits) atomicOr(&R[bit >> 6], 1ull << (bit & 63));   // mscc.pyx:416-417
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const int64_t last = feed_ld(pos, n - 1);
+        const int64_t last = feed_ld(pos, n - 1, rev == nullptr);
         state[PMX_FEED_LAST_POS] = last < 0 ? 0 : (u64)last;
         const u64 cf = state[PMX_FEED_CHUNK_FORWARD_POS];
         if (cf) state[PMX_FEED_LAST_FORWARD_POS] = cf - 1;

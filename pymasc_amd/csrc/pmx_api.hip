@@ -743,7 +743,7 @@ int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, c
 {
     if (ctx) (void)hipSetDevice(ctx->device);
     REQUIRE(ctx && d_F && d_R && d_state, "pmx_feed_reads: NULL argument");
-    REQUIRE(n == 0 || (h_pos && h_readlen && h_is_reverse), "pmx_feed_reads: NULL read arrays");
+    REQUIRE(n == 0 || (h_pos && h_readlen), "pmx_feed_reads: NULL read arrays");
     REQUIRE((pos_bytes == 4 || pos_bytes == 8) && (len_bytes == 0 || len_bytes == 2 || len_bytes == 4 || len_bytes == 8),
             "pmx_feed_reads: positions must be 4 or 8 bytes wide, read lengths 2, 4 or 8 (0: one int64 for all)");
     REQUIRE(nbits >= 1 && nbits < (1ull << 40), "pmx_feed_reads: nbits must be in [1, 2^40)");
@@ -756,11 +756,11 @@ int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, c
     if (rc) return rc;
     PMX_HIP(hipMemcpyAsync(d, h_pos, (size_t)n * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
     if (len_bytes) PMX_HIP(hipMemcpyAsync(d + o_len, h_readlen, (size_t)n * len_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-    PMX_HIP(hipMemcpyAsync(d + o_rev, h_is_reverse, (size_t)n, hipMemcpyHostToDevice, ctx->copy_stream));
+    if (h_is_reverse) PMX_HIP(hipMemcpyAsync(d + o_rev, h_is_reverse, (size_t)n, hipMemcpyHostToDevice, ctx->copy_stream));
     rc = feed_publish(ctx);
     if (rc) return rc;
-    rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d, pos_bytes, d + o_len, len_bytes, uniform_len, d + o_rev, n, reads_before,
-                               d_state);
+    rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d, pos_bytes, d + o_len, len_bytes, uniform_len, h_is_reverse ? d + o_rev : nullptr,
+                               n, reads_before, d_state);
     if (rc) return rc;
     return feed_release(ctx, slot);
 }

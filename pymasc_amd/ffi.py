@@ -125,6 +125,17 @@ def load_library(path: Optional[str] = None):
     return L
 
 
+def pack_strand(pos: np.ndarray, is_reverse: np.ndarray) -> np.ndarray:
+    """Positions (int32 / int64) with the strand in their top bit: the 4-bytes-per-read form pmx_feed_reads takes with
+    h_is_reverse = NULL (a reader can emit it directly)."""
+    pos = np.asarray(pos)
+    dt = pos.dtype if pos.dtype in (np.dtype(np.int32), np.dtype(np.int64)) else np.dtype(np.int64)
+    out = pos.astype(dt, copy=True)
+    top = dt.type(-1) << dt.type(8 * dt.itemsize - 1)
+    out[np.asarray(is_reverse, dtype=bool)] |= top
+    return out
+
+
 def build_id() -> str:
     """Source hash compiled into the loaded library (include/pymasc_amd.h: pmx_build_id)."""
     return load_library().pmx_build_id().decode()
@@ -284,23 +295,27 @@ class Context:
     def feed_reads(self, d_F: int, d_R: int, nbits: int, pos: np.ndarray, readlen: np.ndarray, is_reverse: np.ndarray,
                    reads_before: int, d_state: int):
         """pmx_feed_reads: a run of reads of one chromosome in file order (int32 / int64 positions, uint16 / int32 / int64
-        read lengths -- or ONE int for a run of reads of the same length --, strand as bool / uint8; other integer types are
-        converted).
+        read lengths -- or ONE int for a run of reads of the same length --, strand as bool / uint8 -- or is_reverse = None with the strand packed into the top bit of
+        every position (pack_strand) --; other integer types are converted).
         Returns the arrays actually handed over: keep them alive until the next synchronising call."""
         pos = self._int_array(pos, "pos")
-        rev = np.ascontiguousarray(is_reverse)
-        if rev.dtype != np.uint8:
-            rev = rev.view(np.uint8) if rev.dtype == np.bool_ else rev.astype(np.uint8)
+        if is_reverse is None:                       # the strand travels in the top bit of the position word
+            rev = None
+        else:
+            rev = np.ascontiguousarray(is_reverse)
+            if rev.dtype != np.uint8:
+                rev = rev.view(np.uint8) if rev.dtype == np.bool_ else rev.astype(np.uint8)
         if np.ndim(readlen) == 0:                    # one length for every read of the run: nothing to copy for it
             readlen = np.array([int(readlen)], dtype=np.int64)
             len_bytes = 0
-            assert pos.size == rev.size
         else:
             readlen = self._int_array(readlen, "readlen")
             len_bytes = readlen.dtype.itemsize
-            assert pos.size == readlen.size == rev.size
+            assert pos.size == readlen.size
+        assert rev is None or rev.size == pos.size
         _check(self._L, self._L.pmx_feed_reads(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R), int(nbits), pos.ctypes.data,
-                                               pos.dtype.itemsize, readlen.ctypes.data, len_bytes, rev.ctypes.data,
+                                               pos.dtype.itemsize, readlen.ctypes.data, len_bytes,
+                                               rev.ctypes.data if rev is not None else None,
                                                pos.size, int(reads_before), ctypes.c_void_p(d_state)))
         return pos, readlen, rev
 

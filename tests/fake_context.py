@@ -117,7 +117,11 @@ class FakeContext:
     # per-read rules restated read by read (mscc.pyx:351-418), state words as in include/pymasc_amd.h
     def feed_reads(self, d_F, d_R, nbits, pos, readlen, is_reverse, reads_before, d_state):
         F, R, st = self._mem[d_F], self._mem[d_R], self._mem[d_state]
-        pos, rev = np.asarray(pos).tolist(), np.asarray(is_reverse).astype(bool).tolist()
+        pos = np.asarray(pos)
+        if is_reverse is None:            # strand packed into the top bit
+            is_reverse = pos < 0
+            pos = pos & ((1 << (8 * pos.dtype.itemsize - 1)) - 1)
+        pos, rev = pos.tolist(), np.asarray(is_reverse).astype(bool).tolist()
         readlen = [int(readlen)] * len(pos) if np.ndim(readlen) == 0 else np.asarray(readlen).tolist()
         last = int(st[ffi.PMX_FEED_LAST_POS]) if reads_before else 0
         last_f = int(st[ffi.PMX_FEED_LAST_FORWARD_POS])

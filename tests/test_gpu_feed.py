@@ -90,6 +90,27 @@ def test_chunk_boundaries_inside_runs_of_equal_positions(ctx):
     assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
 
 
+@pytest.mark.parametrize("pdt", [np.int32, np.int64])
+def test_strand_packed_into_the_position_word(ctx, pdt):
+    S, L, glen = 200, 36, 150000
+    rng = np.random.default_rng(23)
+    pos, rlen, rev = make_reads(rng, 25000, glen, lens=(20, 36, 50))
+    wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
+    packed = ffi.pack_strand(pos.astype(pdt), rev)
+    assert packed.dtype == np.dtype(pdt) and (packed < 0).sum() == rev.sum()
+    d_F, d_R, d_st = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits), ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    k1 = ctx.feed_reads(d_F, d_R, nbits, packed[:11000], rlen[:11000].astype(np.uint16), None, 0, d_st)
+    k2 = ctx.feed_reads(d_F, d_R, nbits, packed[11000:], rlen[11000:].astype(np.int32), None, 11000, d_st)
+    np.testing.assert_array_equal(ctx.bits_download(d_F, nbits), wF)
+    np.testing.assert_array_equal(ctx.bits_download(d_R, nbits), wR)
+    st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+    assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+    assert int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0 and int(st[ffi.PMX_FEED_LAST_POS]) == int(pos[-1])
+    for d in (d_F, d_R, d_st):
+        ctx.bits_free(d)
+    del k1, k2
+
+
 def test_uniform_read_length_as_a_scalar(ctx):
     S, L, glen = 200, 36, 100000
     rng = np.random.default_rng(17)

@@ -224,6 +224,30 @@ def _check_tiny_shift_ranges(context_factory):
         ctx.close()
 
 
+def test_bulk_feed_with_packed_strand_and_scalar_read_length():
+    """feed_reads(chrom, pos, readlen, None): the strand in the top bit of every position (ffi.pack_strand), and ONE read
+    length for the chunk -- the leanest form a reader can hand over -- give the results of the per-read protocol."""
+    from pymasc_amd import ffi
+    rng = np.random.default_rng(4)
+    names, lens = ["a", "b"], [30000, 9000]
+    one = CCHipCalculator(60, 36, names, lens, context=FakeContext())
+    two = CCHipCalculator(60, 36, names, lens, context=FakeContext())
+    for chrom, glen in zip(names, lens):
+        pos = np.sort(rng.integers(1, glen, size=800)).astype(np.int32)
+        rev = rng.random(800) < 0.5
+        for p, r in zip(pos.tolist(), rev.tolist()):
+            (one.feed_reverse_read if r else one.feed_forward_read)(chrom, p, 36)
+        packed = ffi.pack_strand(pos, rev)
+        two.feed_reads(chrom, packed[:300], 36, None)
+        two.feed_reads(chrom, packed[300:], 36, None)
+    one.finishup_calculation()
+    two.finishup_calculation()
+    for c in names:
+        a, b = one.get_result(c).chrom, two.get_result(c).chrom
+        assert a.ccbins == b.ccbins and (a.forward_sum, a.reverse_sum) == (b.forward_sum, b.reverse_sum)
+        assert (a.forward_read_len_sum, a.reverse_read_len_sum) == (b.forward_read_len_sum, b.reverse_read_len_sum)
+
+
 def test_calc_cc_batch_is_bit_identical_to_calc_cc():
     """Results of a fetch get their cc curves in one vectorised pass (result.calc_cc_batch): the same float64 operations
     as NCCResult.calc_cc / MSCCResult.calc_cc element by element, all-zero bins -> NaN included."""
