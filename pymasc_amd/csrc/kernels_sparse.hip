@@ -1901,9 +1901,11 @@ __device__ __forceinline__ u32 plan_block_scan(u32 v, u32 *part, u32 tid, u32 *t
 }
 
 __global__ void __launch_bounds__(1024)
-k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const unsigned char *__restrict__ flags, u32 raw_flags,
-               const u32 *__restrict__ n_flagged, u32 flags_per_count, u32 *__restrict__ plan)
+k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const unsigned char *__restrict__ flags, u32 raw_lo,
+               u32 raw_hi, const u32 *__restrict__ n_flagged, u32 flags_per_count, u32 *__restrict__ plan)
 {
+    // [raw_lo, raw_hi): the flag entries of THIS launch's jobs (a batch of more than SP_MAXJOBS chromosomes is several
+    // launches over one flag array; n_flagged is zeroed per launch)
     // flags set in the array: the producer counts ITS tiles, each of which sets flags_per_count entries (an event tile is two
     // tiles of k_cc_sparse; the second may be a padding entry behind the job's last tile: it maps to the next job's first tile,
     // a valid cut point like any other)
@@ -1923,10 +1925,17 @@ k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const
     for (u32 w = tid; w <= nwg; w += 1024) sb[w] = total_tiles;   // (a start nobody writes -- fewer flags set than counted -- is an empty range)
     __syncthreads();
     u32 running = 0;               // flagged entries before this pass (uniform)
-    for (u32 f0 = 0; f0 < raw_flags; f0 += 1024 * 16) {
+    for (u32 f0 = raw_lo & ~15u; f0 < raw_hi; f0 += 1024 * 16) {
         const u32 f = f0 + 16 * tid;
         uint4 q = make_uint4(0, 0, 0, 0);
-        if (f < raw_flags) q = *reinterpret_cast<const uint4 *>(flags + f);
+        if (f < raw_hi) q = *reinterpret_cast<const uint4 *>(flags + f);   // (the array is padded to 16 bytes)
+        if (f < raw_lo || f + 16 > raw_hi) {                               // entries of other launches' jobs in my 16 bytes
+            u32 qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (u32 k = 0; k < 16; k++)
+                if (f + k < raw_lo || f + k >= raw_hi) qq[k >> 2] &= ~(0xffu << (8 * (k & 3)));
+            q = make_uint4(qq[0], qq[1], qq[2], qq[3]);
+        }
         // (flags are 0 / 1) one bit per flag: the four low bits of the bytes of a dword gathered by a multiplication
         const u32 m16 = (((q.x & 0x01010101u) * 0x01020408u) >> 24) | ((((q.y & 0x01010101u) * 0x01020408u) >> 24) << 4) |
                         ((((q.z & 0x01010101u) * 0x01020408u) >> 24) << 8) | ((((q.w & 0x01010101u) * 0x01020408u) >> 24) << 12);
@@ -2423,9 +2432,13 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         uint32_t total, tpw, nwg;
         int rc;
         pmx_timed_launch tl;
+        // the flag entries of this launch's jobs
+        const u32 raw_lo = use_events ? vjobs[lo].flag0 : 0u;
+        const u32 raw_hi = use_events ? (lo + n < vjobs.size() ? vjobs[lo + n].flag0 : (u32)flag_bytes_all) : 0u;
         if (use_events) {
             memset(&tab, 0, sizeof tab);
-            if (lo) PMX_HIP(hipMemsetAsync(d_jobstat, 0, 4 * SP_MAXJOBS * sizeof(u32), ctx->stream));   // (the next 32 jobs)
+            // (the next 32 jobs: their own flagged-tile counters and job statistics)
+            if (lo) PMX_HIP(hipMemsetAsync(d_nflagged, 0, 16 + 4 * SP_MAXJOBS * sizeof(u32), ctx->stream));
             plan_launch(ctx, &vjobs[lo], n, false, has_m ? EV_WAVES : EV_WAVES_NCC, &tab, &total, &tpw, &nwg, EV_TB);
             rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * EV_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
             if (rc) return rc;
@@ -2483,7 +2496,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
                 return PMX_ERR_INVALID;
             }
             hipLaunchKernelGGL(k_plan_flagged, dim3(1), dim3(1024), 0, ctx->stream, tabW, n, total, nwg, (const unsigned char *)d_flags,
-                               (u32)flag_bytes_all, (const u32 *)d_nflagged, (u32)EV_NQ, d_plan_cc);
+                               raw_lo, raw_hi, (const u32 *)d_nflagged, (u32)EV_NQ, d_plan_cc);
             PMX_CHECK_LAUNCH("k_plan_flagged");
         }
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, use_events);
@@ -2533,7 +2546,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             rc = pmx_ensure_slab_ac(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
             if (rc) return rc;
             hipLaunchKernelGGL(k_plan_flagged, dim3(1), dim3(1024), 0, ctx->stream, tabA, n, total, nwg, (const unsigned char *)d_flags_ac,
-                               (u32)flag_bytes_all, (const u32 *)(d_nflagged + 1), 1u, d_plan_ac);
+                               raw_lo, raw_hi, (const u32 *)(d_nflagged + 1), 1u, d_plan_ac);
             PMX_CHECK_LAUNCH("k_plan_flagged");
             rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl, true);
             if (rc) return rc;

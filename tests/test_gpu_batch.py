@@ -83,6 +83,29 @@ def test_more_jobs_than_one_job_table(ctx):
         check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
 
 
+@pytest.mark.parametrize("S", [300, 1500])
+def test_dense_tiles_on_both_sides_of_a_job_table(ctx, S):
+    """40 chromosomes = two launches of the max_shift <= 1023 kernels (one beyond): read-dense and edge-dense stretches in
+    chromosomes of BOTH launches, so that the flagged-tile counters, the job statistics and the work split of the window
+    kernels (k_plan_flagged: it scans one flag array shared by the launches) are per launch."""
+    L = 36
+    rng = np.random.default_rng(4040 + S)
+    cases = []
+    for i in range(40):
+        n = 140000 + 7919 * i if i in (5, 31, 33, 39) else 4000 + 613 * i
+        nbits, F, R, M = synth.make_case(500 + i, n, S, L, 0.006, 0.006, True, mean_on=1500, mean_off=400)
+        if i in (5, 33):        # a read-dense tile in the middle
+            F |= synth.random_bits(rng, nbits, 0.06, 70000, 125000)
+            R |= synth.random_bits(rng, nbits, 0.06, 66000, 120000)
+        if i in (31, 39):       # a stretch of very short runs
+            keep = synth.run_bits(np.random.default_rng(1), nbits, 10**9, 1, 0, 66000)
+            M = (M & keep) | synth.run_bits(rng, nbits, 6, 4, 66000, nbits)
+        cases.append((nbits, F, R, M))
+    outs = run_batch(ctx, cases, S, L, True)
+    for (nbits, F, R, M), out in zip(cases, outs):
+        check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
+
+
 def test_dense_tiles_force_counter_spills(ctx):
     # every bit set: thousands of records per tile -> multi-round lists and mid-tile counter folds
     S, L = 200, 36

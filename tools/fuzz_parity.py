@@ -69,6 +69,44 @@ def compare(out, ref, S, with_m, skip_ncc, tag):
     return ok
 
 
+def fuzz_feed(ctx, rng, clen, S, L):
+    """pmx_feed_reads against the oracle's per-read restatement of feed_forward_read / feed_reverse_read (mscc.pyx:351-418):
+    random reads with duplicates on both strands and variable lengths, fed in random chunks, every width combination."""
+    n = int(rng.integers(1, 4000))
+    glen = max(int(clen), 50)
+    pos = np.sort(rng.integers(0, glen, size=n)).astype(np.int64)
+    if rng.random() < 0.5:
+        pos = np.sort(rng.choice(pos, size=n))           # many equal positions
+    rlen = rng.choice(np.asarray([1, 20, 36, 36, 50, 101]), size=n).astype(np.int64)
+    rev = rng.random(n) < rng.random()
+    oc = oracle.OracleCalculator(S, L, ["c"], [glen])
+    for p, l, r in zip(pos.tolist(), rlen.tolist(), rev.tolist()):
+        (oc.feed_reverse_read if r else oc.feed_forward_read)("c", p, l)
+    nbits = oc._nbits
+    d_F, d_R, d_st = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits), ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    cuts = sorted(set(rng.integers(1, n, size=int(rng.integers(0, 5))).tolist())) if n > 1 else []
+    pdt = [np.int32, np.int64][int(rng.integers(0, 2))]
+    ldt = [np.uint16, np.int32, np.int64][int(rng.integers(0, 3))]
+    packed = rng.random() < 0.3
+    keep, fed = [], 0
+    for a, b in zip([0] + cuts, cuts + [n]):
+        if b > a:
+            pp = pos[a:b].astype(pdt)
+            keep.append(ctx.feed_reads(d_F, d_R, nbits, ffi.pack_strand(pp, rev[a:b]) if packed else pp, rlen[a:b].astype(ldt),
+                                       None if packed else rev[a:b], fed, d_st))
+            fed += b - a
+    F, R = ctx.bits_download(d_F, nbits), ctx.bits_download(d_R, nbits)
+    st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+    for d in (d_F, d_R, d_st):
+        ctx.bits_free(d)
+    ok = (np.array_equal(F, oc._F) and np.array_equal(R, oc._R) and int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == oc._f_rls
+          and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == oc._r_rls and int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0
+          and int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 0)
+    if not ok:
+        print("MISMATCH feed_reads", n, glen, S, L, cuts, pdt, ldt, packed, flush=True)
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -111,6 +149,8 @@ def main():
                     continue
                 if not compare(out, ref, S, with_m, skip_ncc, tag):
                     bad += 1
+            if rng.random() < 0.15:
+                bad += fuzz_feed(ctx, rng, clen, S, L)
             if with_m and rng.random() < 0.3:
                 lag = int(rng.choice([S, 300, 1023, 1024, 4000]))
                 if (lag + 1) * nbits < 1.5e9:
