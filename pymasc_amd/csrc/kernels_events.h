@@ -34,12 +34,20 @@
 #define EV_LO 64u                         // dwords of M staged below the tile (2 x max_shift bits), max_shift <= 1023
 #define EV_LO_MAX 512u                    // ... in the BIG instantiations (max_shift <= 8191): a kernel argument
 #define EV_HI 36u                         // ... and above it (read_len - 1 bits, + the partners' M bits)
-#define EV_CAPF 768u                      // list capacities = the dense-tile thresholds (read density ~1 % per strand)
-#define EV_CAPR 1000u                     // reverse reads of the tile + of the max_shift bits above it (< 1024: rank field)
+// The three lists of a tile (forward reads, reverse reads of the tile + of the max_shift bits above it, run edges of
+// everything staged) share ONE pool of LDS: LF at its start, LR behind the forward reads, LE behind the reverse reads
+// (offsets known after the block scan).  max_shift <= 1023: a tile is dense -- left to the window kernels -- when its run
+// edges alone exceed EV_CAPE_SMALL, or when reads + edges together exceed the pool: on an ordinary track (~60 edges) the
+// reads may fill all of it, ~2.4 % per strand, where the window kernel costs 2.4x the event kernel; on a track with edges
+// every 50 bases the reads get what the edges leave.  BIG (the LDS is spent on histograms): fixed shares, 768 / 1000 / 384.
+#define EV_CAPF 768u
+#define EV_CAPR 1000u
 #ifndef EV_CAPE_SMALL
-#define EV_CAPE_SMALL 1536u               // run edges of everything staged, max_shift <= 1023 (EV_CAPE(BIG): the LDS of the BIG
-#endif                                    // instantiations is spent on histograms, their edge list stays at 384)
+#define EV_CAPE_SMALL 1536u
+#endif
 #define EV_CAPE(BIG) ((BIG) ? 384u : EV_CAPE_SMALL)
+#define EV_POOL_ENTRIES(HAS_M, BIG) (EV_CAPF + EV_CAPR + ((BIG) ? ((HAS_M) ? 384u : 0u) : EV_CAPE_SMALL))
+#define EV_RANK_BITS 12u                  // rank field of a forward entry (bits 17..28): index into the reverse list
 #define EV_POS 0x1ffffu                   // 17 bits of biased position (BIG: 16384 + 65536 + 8192 + 1152 staged bits at most)
 #define EV_PAD 12u                        // sentinel entries behind the read lists
 #define EV_RSENT 0x3fffffffu              // reverse-list sentinel: beyond every range, and (sentinel - lo) stays positive as
@@ -98,10 +106,10 @@
 template <bool HAS_M, bool BIG>
 struct EvLds {
     // per sub-group block
-    static constexpr u32 LF = 0;                                    // (+EV_PAD: sentinels; the loops read ahead of their entry)
-    static constexpr u32 LR = LF + EV_CAPF + EV_PAD;
-    static constexpr u32 LE = LR + EV_CAPR + EV_PAD;
-    static constexpr u32 WT = LE + (HAS_M ? EV_CAPE(BIG) + 4 : 0u);   // WT: [5][4 waves] scan totals
+    static constexpr u32 LF = 0;                                    // the pool (+EV_PAD behind every list: sentinels; the
+    static constexpr u32 POOL = EV_POOL_ENTRIES(HAS_M, BIG);        // loops read ahead of their entry)
+    static_assert(POOL + 3 * EV_PAD < (1u << EV_RANK_BITS), "rank field of the forward entries");
+    static constexpr u32 WT = LF + POOL + 3 * EV_PAD;               // WT: [5][4 waves] scan totals
     static constexpr u32 MISC = WT + 32;
     static constexpr u32 IDXF = MISC + 16;                          // u16 per 512-bit block of the tile (+ end): list index of
     static constexpr u32 IDXR = IDXF + (HAS_M ? 66u : 0u);          // its first forward / reverse read
@@ -193,7 +201,7 @@ __device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u3
         ev_fetch<HAS_M, true, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads);
 }
 
-// forward list entry: bits 0..16 biased position, 17..26 index of the first reverse read at or above it, 31 = M[x]
+// forward list entry: bits 0..16 biased position, 17..28 index of the first reverse read at or above it, 31 = M[x]
 __device__ __forceinline__ void ev_emit_f(const uint4 f, const uint4 r, const uint4 m, u32 idx, u32 rank0, u32 base_bit,
                                           u32 *list)
 {
@@ -207,14 +215,13 @@ __device__ __forceinline__ void ev_emit_f(const uint4 f, const uint4 r, const ui
         while (ww) {
             const u32 b = (u32)__builtin_ctzll(ww);
             ww &= ww - 1;
-            const u64 below = (rs[k] << (63u - b)) << 1;   // the reverse reads of this word strictly below bit b
+            const u64 below = (rs[k] << (63u - b)) << 1;
             list[idx] = (base_bit + 64u * k + b) | ((rk + (u32)__popcll(below)) << 17) | ((u32)((ms[k] >> b) & 1ull) << 31);
             idx++;
         }
         rk += (u32)__popcll(rs[k]);
     }
 }
-
 __device__ __forceinline__ void ev_emit_pos(const uint4 v, u32 idx, u32 base_bit, u32 *list)
 {
     const u64 vs[2] = {(u64)v.x | ((u64)v.y << 32), (u64)v.z | ((u64)v.w << 32)};
@@ -281,8 +288,6 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
     unsigned short *const idxF = reinterpret_cast<unsigned short *>(sgb + L::IDXF);
     unsigned short *const idxR = reinterpret_cast<unsigned short *>(sgb + L::IDXR);
     u32 *const LF = sgb + L::LF;
-    u32 *const LR = sgb + L::LR;
-    u32 *const LE = sgb + L::LE;
     u32 *const wt = sgb + L::WT;
 
     const u32 gt = threadIdx.x;              // thread of the workgroup (histogram clears / flushes)
@@ -404,6 +409,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         EV_STAMP(2)
         u32 nF = 0, nRt = 0, nR = 0, nE = 0, TXb = 0, TE0 = 0, TE1 = 0;
         bool dense = false, do_edges = false;
+        u32 *LR = LF, *LE = LF;
         u32 gnext = g + NSG;
         if (act) {
             u32 bF = 0, bR = 0, bH = 0, bE = 0, bX = 0, tF = 0, tR = 0, tH = 0, tE = 0, tX = 0;
@@ -436,9 +442,12 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
             // edge pairs of the mappable-length pass (DO_MLEN), so that deep data on an ordinary track does not push that pass onto
             // its window kernel as well.
             const bool dense_e = HAS_M && nE > EV_CAPE(BIG);
-            const bool dense_r = cur_skip || nF > EV_CAPF || nR > EV_CAPR;
+            const bool dense_r = cur_skip || (BIG ? (nF > EV_CAPF || nR > EV_CAPR)
+                                                  : nF + nR + ((HAS_M && !dense_e) ? nE : 0u) > L::POOL);
             dense = dense_e || dense_r;
             do_edges = HAS_M && !dense_e && (!dense || DO_MLEN);
+            LR = LF + (dense ? 0u : nF) + EV_PAD;   // (uniform) this tile's share of the pool
+            LE = LR + (dense ? 0u : nR) + EV_PAD;
             const u32 my_tile = g + sg;
             if (!dense) {
                 const u32 eF = bF + sF - pF, eR = bR + sR - pR;   // exclusive, per row
@@ -597,7 +606,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                 const u32 x = ent & EV_POS, xc = x + c;
                 const u32 flm = HAS_M ? (ent >> 31) << 16 : 0u;   // mappable: the increment of the cc half
                 if (HAS_M && flm) cntB += ev_mbit(MT, xc);   // Bf = sum of M[x + c]
-                u32 r = (ent >> 17) & 0x3ffu;
+                u32 r = (ent >> 17) & ((1u << EV_RANK_BITS) - 1u);
                 u32 y0 = LR[r], y1 = LR[r + 1];
                 for (;;) {
                     const u32 d0 = y0 - x, d1 = y1 - x;
@@ -750,7 +759,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         const bool leaving = jn != ji || gnext >= g1;
         // another iteration could overflow a 16-bit cell (bounds in the comment of EvLds): flush now
         const bool risk = HAS_M && (BIG ? (accF + NSG * EV_CAPF > 32767u || 3u * (accR + NSG * EV_CAPR) > 32767u)
-                                        : accF + EV_CAPF > 65535u);
+                                        : accF + L::POOL > 65535u);
         if (NSG == 1 && leaving && tid == 0) {
             // tiles flagged in this job: one atomic per workgroup and job, not per tile (47 k adds to one word serialise in L2
             // when every tile is dense)

@@ -226,9 +226,8 @@ def test_bits_builders_match_oracle(ctx):
 
 # ---- the event kernel (sparse tiles) and its hand-over to the window kernel (dense tiles) ----------------------------
 EVENT_TILE = 65536      # kernels_events.h: EV_TB
-EVENT_CAP_F = 768       # EV_CAPF: forward reads of one tile
-EVENT_CAP_R = 1000      # EV_CAPR: reverse reads of the tile + of the max_shift bits above it
-EVENT_CAP_E = 1024      # EV_CAPE_SMALL: run edges of everything staged for the tile (max_shift <= 1023)
+EVENT_CAP_E = 1536      # EV_CAPE_SMALL: run edges of everything staged for the tile (max_shift <= 1023)
+EVENT_POOL = 768 + 1000 + EVENT_CAP_E   # EV_POOL_ENTRIES: forward reads + reverse reads (tile + max_shift bits above) + run edges
 
 
 def _exact_count_bits(rng, nbits, lo, hi, k):
@@ -238,27 +237,37 @@ def _exact_count_bits(rng, nbits, lo, hi, k):
     return w
 
 
-@pytest.mark.parametrize("with_m", [True, False])
-@pytest.mark.parametrize("which,count", [("F", EVENT_CAP_F), ("F", EVENT_CAP_F + 1), ("R", EVENT_CAP_R), ("R", EVENT_CAP_R + 1)])
-def test_event_lists_exactly_full_and_one_over(ctx, which, count, with_m):
-    """Tile 1 of three holds exactly the list capacity (stays on the event kernel) or one entry more (flagged, summed by
-    the window kernel and ADDED to what the event kernel wrote for tiles 0 and 2)."""
+@pytest.mark.parametrize("n_edges", [None, 0, 300])
+@pytest.mark.parametrize("n_f,over", [(1200, 0), (1200, 1), (3000, 0), (3000, 1), (40, 0), (40, 1)])
+def test_event_lists_exactly_full_and_one_over(ctx, n_f, over, n_edges):
+    """The three lists of a tile share one pool.  Tile 1 of three holds n_f forward reads, n_edges run edges (None: no
+    mappability track) and as many reverse reads as fill the pool exactly (stays on the event kernel) or one more
+    (flagged, summed by the window kernel and ADDED to what the event kernel wrote for tiles 0 and 2)."""
     S, L = 700, 36
-    rng = np.random.default_rng(700 + count + (1 if with_m else 0))
+    rng = np.random.default_rng(700 + n_f + over + (n_edges or 7))
     nbits = 3 * EVENT_TILE - 1000
     sparse = lambda: synth.random_bits(rng, nbits, 0.003, 1, nbits - 200)
     F, R = sparse(), sparse()
     lo, hi = EVENT_TILE, 2 * EVENT_TILE
-    target = F if which == "F" else R
-    # clear tile 1 (and, for R, the max_shift bits above it, which count towards its list), then place `count` bits in it
-    clear_hi = hi if which == "F" else hi + 1024
-    for wd in range(lo // 64, clear_hi // 64):
-        target[wd] = 0
-    target |= _exact_count_bits(rng, nbits, lo, hi, count)
-    M = synth.run_bits(rng, nbits, 3000, 900, 1, nbits - 300) if with_m else None
+    # clear tile 1 (and, for R, the max_shift bits above it, which count towards its list), then place the bits in it
+    for target, clear_hi in ((F, hi), (R, hi + 1024)):
+        for wd in range(lo // 64, clear_hi // 64):
+            target[wd] = 0
+    n_r = EVENT_POOL - n_f - (n_edges or 0) + over
+    F |= _exact_count_bits(rng, nbits, lo, hi, n_f)
+    R |= _exact_count_bits(rng, nbits, lo, hi, n_r)
+    M = None
+    if n_edges is not None:
+        # mappable throughout what is staged for tile 1 (2048 bits below it, 1152 above) except n_edges / 2 holes inside it
+        bits = np.zeros(synth.nwords(nbits) * 64, dtype=np.uint8)
+        bits[:nbits] = np.unpackbits(synth.run_bits(rng, nbits, 3000, 900, 1, nbits - 300).view(np.uint8), bitorder="little")[:nbits]
+        bits[lo - 4096:hi + 4096] = 1
+        for i in range(n_edges // 2):
+            bits[lo + 50 + 200 * i:lo + 90 + 200 * i] = 0
+        M = np.packbits(bits, bitorder="little").view(np.uint64).copy()
     ref = oracle.calc_correlation(F, R, M, nbits, S, L)
     out = ctx.calc_correlation(F, R, M, nbits, S, L, ffi.PMX_FLAG_FORCE_SPARSE)
-    check_block(out, ref, S, with_m)
+    check_block(out, ref, S, M is not None)
 
 
 @pytest.mark.parametrize("n_edges", [EVENT_CAP_E - 2, EVENT_CAP_E, EVENT_CAP_E + 2])

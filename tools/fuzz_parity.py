@@ -36,8 +36,8 @@ def draw_case(rng):
     clen = int(rng.choice([1, 40, 900, 5000, 32768 - 200, 32768, 32768 + 7, 65536, 70001, 131072 + 31, 200003]))
     if kind == 2:
         clen = int(rng.integers(1, 250000))
-    fd = float(rng.choice([0.0, 0.0005, 0.005, 0.02, 0.1, 0.5, 1.0]))
-    rd = float(rng.choice([0.0, 0.0005, 0.005, 0.02, 0.1, 0.5, 1.0]))
+    fd = float(rng.choice([0.0, 0.0005, 0.005, 0.012, 0.02, 0.03, 0.1, 0.5, 1.0]))
+    rd = float(rng.choice([0.0, 0.0005, 0.005, 0.012, 0.02, 0.03, 0.1, 0.5, 1.0]))
     with_m = bool(rng.random() < 0.75)
     mean_on = float(rng.choice([1.5, 5, 30, 300, 3000, 1e6]))
     mean_off = float(rng.choice([1.5, 5, 80, 500, 1e6]))
