@@ -387,13 +387,15 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
             pR = cR[0] | (cR[1] << 16);
             pE = cE[0] | (cE[1] << 16);
             pH = h_below ? cEh : cEh << 16;   // below | above
-            sF = wave_inclusive_scan(pF);
-            sR = wave_inclusive_scan(pR);
-            sH = wave_inclusive_scan(cRh);
-            if (HAS_M) {
-                sE = wave_inclusive_scan(pE);
-                sX = wave_inclusive_scan(pH);
-            }
+            sF = pF;
+            sR = pR;
+            sH = cRh;
+            sE = pE;
+            sX = pH;
+            if (HAS_M)
+                wave_inclusive_scan5(sF, sR, sH, sE, sX);
+            else
+                wave_inclusive_scan3(sF, sR, sH);
             if (lane == 63) {
                 wt[0 + wave] = sF;
                 wt[4 + wave] = sR;
@@ -608,10 +610,11 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                 if (HAS_M && flm) cntB += ev_mbit(MT, xc);   // Bf = sum of M[x + c]
                 u32 r = (ent >> 17) & ((1u << EV_RANK_BITS) - 1u);
                 u32 y0 = LR[r], y1 = LR[r + 1];
-                for (;;) {
-                    const u32 d0 = y0 - x, d1 = y1 - x;
-                    const bool h0 = d0 <= S, h1 = d1 <= S;   // sorted: h1 implies h0
-                    if (!__ballot(h0)) break;
+                u32 d0 = y0 - x, d1 = y1 - x;
+                bool h0 = d0 <= S, h1 = d1 <= S;   // sorted: h1 implies h0
+                // (a bottom-tested loop: one compare + one branch per trip; with the test in the middle the structurizer
+                // spends six scalar instructions per trip on the exit flag)
+                if (__ballot(h0)) do {
                     r = h1 ? r + 2 : nR;
                     y0 = LR[r];
                     y1 = LR[r + 1];
@@ -626,7 +629,11 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                         atomicAdd(&hN[a0], 1u);
                         atomicAdd(&hN[a1], 1u);
                     }
-                }
+                    d0 = y0 - x;
+                    d1 = y1 - x;
+                    h0 = d0 <= S;
+                    h1 = d1 <= S;
+                } while (__ballot(h0));
             }
 #endif
             EV_STAMP(6)
@@ -668,17 +675,19 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                         bb = bb < 0 ? 0 : (bb > 128 ? 128 : bb);
                         u32 idx = (u32)idxF[bb] + wave;
                         u32 e0 = LF[idx], e1 = LF[idx + 4];
-                        for (;;) {
-                            const u32 u0 = (e0 & EV_POS) - (u32)lo, u1 = (e1 & EV_POS) - (u32)lo;
-                            const bool more = (int32_t)u0 < (int32_t)span;   // this lane's entry is still below the end of its range
-                            if (!__ballot(more)) break;
+                        u32 u0 = (e0 & EV_POS) - (u32)lo, u1 = (e1 & EV_POS) - (u32)lo;
+                        bool more = (int32_t)u0 < (int32_t)span;   // this lane's entry is still below the end of its range
+                        if (__ballot(more)) do {                   // (bottom-tested: see the pair loop)
                             const bool h0 = u0 < span && (e0 >> 31) != 0, h1 = u1 < span && (e1 >> 31) != 0;
                             ev_add_cell<BIG>(hGF, h0 ? u0 + 1 : dumpGF, sgn);
                             ev_add_cell<BIG>(hGF, h1 ? u1 + 1 : dumpGF, sgn);
                             idx = more ? idx + 8 : idx;
                             e0 = LF[idx];
                             e1 = LF[idx + 4];
-                        }
+                            u0 = (e0 & EV_POS) - (u32)lo;
+                            u1 = (e1 & EV_POS) - (u32)lo;
+                            more = (int32_t)u0 < (int32_t)span;
+                        } while (__ballot(more));
                     }
                     // -- reverse reads, type A and type B (the halo entries above the tile are not drivers: the span ends at the tile end) --
 #pragma unroll
@@ -692,10 +701,9 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                         bb = bb < 0 ? 0 : (bb > 128 ? 128 : bb);
                         u32 idx = (u32)idxR[bb] + wave;
                         u32 p0 = LR[idx], p1 = LR[idx + 4];
-                        for (;;) {
-                            const u32 u0 = p0 - (u32)lo, u1 = p1 - (u32)lo;
-                            const bool more = (int32_t)u0 < (int32_t)span;
-                            if (!__ballot(more)) break;
+                        u32 u0 = p0 - (u32)lo, u1 = p1 - (u32)lo;
+                        bool more = (int32_t)u0 < (int32_t)span;
+                        if (__ballot(more)) do {
                             const bool h0 = u0 < span, h1 = u1 < span;
                             const u32 d0 = kind == 0 ? u0 + 1 : (u0 + 2) >> 1, d1 = kind == 0 ? u1 + 1 : (u1 + 2) >> 1;
                             const u32 q0 = h0 ? (kind == 0 ? p0 + c - 2 * d0 : p0 - d0 + 1) : BIAS;
@@ -707,7 +715,10 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                             // -E[j] M[q]
                             ev_add_cell<BIG>(hGR, h0 ? d0 : dumpGR, (0u - sgn) * ((m0 >> (q0 & 31u)) & 1u));
                             ev_add_cell<BIG>(hGR, h1 ? d1 : dumpGR, (0u - sgn) * ((m1 >> (q1 & 31u)) & 1u));
-                        }
+                            u0 = p0 - (u32)lo;
+                            u1 = p1 - (u32)lo;
+                            more = (int32_t)u0 < (int32_t)span;
+                        } while (__ballot(more));
                     }
                 }
 #endif
@@ -725,16 +736,19 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                     const u32 pos = ent & EV_POS, hi = pos + max_lag;
                     u32 e = in ? TXb + i + 1 : nE;
                     u32 e0 = LE[e], e1 = LE[e + 1];
-                    for (;;) {
-                        const u32 p0 = e0 & EV_POS, p1 = e1 & EV_POS;
-                        const bool h0 = p0 <= hi, h1 = p1 <= hi;
-                        if (!__ballot(h0)) break;
+                    u32 p0 = e0 & EV_POS, p1 = e1 & EV_POS;
+                    bool h0 = p0 <= hi, h1 = p1 <= hi;
+                    if (__ballot(h0)) do {
                         atomicAdd(&hEE[h0 ? p0 - pos : dumpEE], (u32)(((int32_t)(e0 ^ ent) >> 31) | 1));   // E[j] E[j + k]
                         atomicAdd(&hEE[h1 ? p1 - pos : dumpEE], (u32)(((int32_t)(e1 ^ ent) >> 31) | 1));
                         e = h1 ? e + 2 : nE;
                         e0 = LE[e];
                         e1 = LE[e + 1];
-                    }
+                        p0 = e0 & EV_POS;
+                        p1 = e1 & EV_POS;
+                        h0 = p0 <= hi;
+                        h1 = p1 <= hi;
+                    } while (__ballot(h0));
                 }
             }
         }

@@ -1580,6 +1580,33 @@ __device__ __forceinline__ u32 wave_inclusive_scan(u32 v)
     return v;
 }
 
+// Several scans at once, one v_add_u32_dpp per step and scan (the compiler leaves mov_dpp + add pairs in the event kernel).
+// A DPP operand written by the previous VALU instruction needs two wait states: the steps of the other scans stand between
+// the dependent ones; the s_nop in front covers an input written (or EXEC changed) by the instruction just before the block.
+#define PMX_SCAN_STEP(ctl)                                                       \
+    "v_add_u32_dpp %0, %0, %0 " ctl "\n\tv_add_u32_dpp %1, %1, %1 " ctl "\n\tv_add_u32_dpp %2, %2, %2 " ctl "\n\t"
+#define PMX_SCAN_STEP2(ctl) "v_add_u32_dpp %3, %3, %3 " ctl "\n\tv_add_u32_dpp %4, %4, %4 " ctl "\n\t"
+__device__ __forceinline__ void wave_inclusive_scan3(u32 &a, u32 &b, u32 &c)
+{
+    asm volatile("s_nop 4\n\t" PMX_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 PMX_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 PMX_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 PMX_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 PMX_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 PMX_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void wave_inclusive_scan5(u32 &a, u32 &b, u32 &c, u32 &d, u32 &e)
+{
+    asm volatile("s_nop 4\n\t" PMX_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1") PMX_SCAN_STEP2("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 PMX_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1") PMX_SCAN_STEP2("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 PMX_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1") PMX_SCAN_STEP2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 PMX_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1") PMX_SCAN_STEP2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+                 PMX_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") PMX_SCAN_STEP2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 PMX_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") PMX_SCAN_STEP2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+}
+
 // list entry: bits 0..17 tile-relative position, bit 31 = falling edge (M is 0 at the edge position).  The four
 // edge words of a quad are walked as two 64-bit words: two loops per quad instead of four (on sparse-edge tiles
 // every loop costs its ~25 instructions of control flow whether or not one of the 64 lanes has a bit).
