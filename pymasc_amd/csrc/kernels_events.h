@@ -195,6 +195,8 @@ __device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u3
     const u32 above = (BIG && 4 * nhr > EV_HI) ? 4 * nhr : EV_HI;   // dwords read above the tile (M: EV_HI, R: 4 nhr)
     const uint64_t hi = (uint64_t)d0 + EV_TBW + above;
     const bool interior = jb.aligned16 && low >= 0 && hi + 2 <= jb.nbits / 32;
+    // (tried: raw buffer loads from a scalar resource + one 32-bit lane offset for the interior tile -- 67 fewer vector
+    // but 160 more scalar instructions in the kernel, 1.4 % slower with M, 9 % slower NCC-only: same-box A/B, round 3)
     if (interior)
         ev_fetch<HAS_M, false, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads);
     else

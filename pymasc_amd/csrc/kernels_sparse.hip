@@ -1157,11 +1157,40 @@ __device__ __forceinline__ void reduce_segments_chunk(const u32 *__restrict__ sl
     }
 }
 
+// A job that few workgroups touched (many short chromosomes, max_shift > 1023: two or three segments of 8192-entry rows):
+// every thread sums the segments of one element, a block takes blockDim.x consecutive elements per trip -- no LDS, no
+// barrier, every lane busy.  (The phased form below keeps 3 of 8 phases busy there: 147 us for config 5's 57 MB.)
+template <typename JT>
+__device__ __forceinline__ bool reduce_segments_row_wide(const u32 *__restrict__ slab, const JT &jobs, u32 seg_rows,
+                                                         const ReduceSpec &rs, u32 r)
+{
+    const u32 job = blockIdx.z;
+    const SpJobDev &jb = jobs.j[job];
+    if (r >= rs.nrows || rs.is_scalar[r] || jb.wg_last - jb.wg_first >= 8u) return false;   // (uniform over the block)
+    const u32 rowlen = rs_rowlen(rs);
+    const u32 n = rs.n_override ? rs.n_override : jb.d_n;
+    const size_t stride = (size_t)seg_rows * rowlen;
+    const u32 *p = slab + (size_t)rs.src_row[r] * rowlen;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        u64 sum = 0;
+        if (rs.is_signed[r])
+            for (u32 w = jb.wg_first; w <= jb.wg_last; w++) sum += (u64)(long long)(int32_t)p[(size_t)(w + job) * stride + i];
+        else
+            for (u32 w = jb.wg_first; w <= jb.wg_last; w++) sum += p[(size_t)(w + job) * stride + i];
+        u64 *dst = rs.use_out2 ? jb.out2 + (size_t)rs.dst_row[r] + jb.d_off + i
+                               : jb.out + (size_t)rs.dst_row[r] * rs.out_stride + jb.d_off + i;
+        *dst = rs.accumulate ? *dst + sum : sum;
+    }
+    return true;
+}
+
 template <typename JT>
 __device__ __forceinline__ void reduce_segments_row(const u32 *__restrict__ slab, const JT &jobs, u32 seg_rows,
                                                     const ReduceSpec &rs, const u32 *__restrict__ gate, u32 r)
 {
     __shared__ u64 part[32][32];   // (blocks of 256 or 1024 threads)
+    if (gate && *gate == 0 && rs.accumulate) return;   // the producing kernel did not run: nothing to add
+    if ((!gate || *gate != 0) && reduce_segments_row_wide(slab, jobs, seg_rows, rs, r)) return;
     for (u32 bx = blockIdx.x; bx < rs_rowlen(rs) / 32; bx += gridDim.x) {   // (uniform over the block)
         reduce_segments_chunk(slab, jobs, seg_rows, rs, gate, r, bx, part);
         __syncthreads();
@@ -2280,8 +2309,9 @@ static int launch_cc_window_chunks(pmx_ctx *ctx, const std::vector<VJob> &vjobs,
         PMX_CHECK_LAUNCH("k_cc_sparse");
         rc = pmx_prof_end(ctx, &tl);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_reduce_segments<SpJobTableRef>, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)wslab, ref,
-                           (u32)SP_SEG_ROWS, rs, d_nflagged);
+        // (behind the event pass the launch is gated: normally 25 k blocks that return at once, 34 us of dispatch at 32 per row)
+        hipLaunchKernelGGL(k_reduce_segments<SpJobTableRef>, dim3(behind_events ? 8 : 32, nr + nz, n), dim3(256), 0, ctx->stream,
+                           (const u32 *)wslab, ref, (u32)SP_SEG_ROWS, rs, d_nflagged);
         PMX_CHECK_LAUNCH("k_reduce_segments");
     }
     return PMX_OK;
