@@ -281,11 +281,10 @@ def main():
     ev_free = [torch.cuda.Event() for _ in range(2)]     # the exchange of the step has read d_rows[b]
     nstep = [0]
 
-    # the hint the calculator gives from the read counts it holds (pymasc_amd/calculator.py: DENSE_READS_PER_BP)
-    from pymasc_amd.calculator import DENSE_READS_PER_BP, DENSE_RUNS_PER_BP
-    dense_reads = bool(vecs) and max(max(v.n_forward, v.n_reverse) / max(v.length, 1) for v in vecs) > DENSE_READS_PER_BP
-    dense_runs = bool(vecs) and with_m and max(v.n_runs / max(v.length, 1) for v in vecs) > DENSE_RUNS_PER_BP
-    hinted = (dense_reads or dense_runs) and args.path == "auto" and not args.no_hint
+    # the hint the calculator gives from the read counts it holds (pymasc_amd/calculator.py: window_only_hint)
+    from pymasc_amd.calculator import window_only_hint
+    dense = any(window_only_hint(v.n_forward, v.n_reverse, v.n_runs if with_m else 0, v.length, S) for v in vecs)
+    hinted = dense and args.path == "auto" and not args.no_hint
     step_flags = flags | (ffi.PMX_FLAG_WINDOW_ONLY if hinted else 0)
 
     def step():

@@ -36,8 +36,21 @@ from .result import (BothChromResult, BothGenomeWideResult, EmptyMSCCResult, Emp
 logger = logging.getLogger(__name__)
 
 _CHUNK = 1 << 16
-DENSE_READS_PER_BP = 0.0105      # reads of one strand per position above which PMX_FLAG_WINDOW_ONLY is passed
-DENSE_RUNS_PER_BP = 0.0025       # mappable runs per position above which it is passed (the event kernel lists 384 edges per 64 Kbit)
+# The event kernel's list capacities per 64-Kbit tile (csrc/kernels_events.h: EV_CAPF, EV_CAPR, EV_CAPE_SMALL).  max_shift <=
+# 1023: forward reads + reverse reads + run edges share one pool, and run edges alone may fill EVENT_EDGES of it; above:
+# fixed shares.  A chromosome whose AVERAGE tile is beyond them goes to the window kernels unseen (PMX_FLAG_WINDOW_ONLY).
+EVENT_TILE_BITS = 65536
+EVENT_FORWARD, EVENT_REVERSE, EVENT_EDGES, EVENT_EDGES_BIG = 768, 1000, 1536, 384
+
+
+def window_only_hint(n_forward, n_reverse, n_runs, length, max_shift):
+    """True when the event kernel would find (nearly) every tile of this chromosome dense: the caller then skips it.
+    n_forward / n_reverse: reads kept per strand, n_runs: mappable runs (two edges each; 0 without a track)."""
+    per_tile = EVENT_TILE_BITS / float(max(length, 1))
+    f, r, e = n_forward * per_tile, n_reverse * per_tile, 2.0 * n_runs * per_tile
+    if max_shift <= 1023:
+        return e > EVENT_EDGES or f + r + e > EVENT_FORWARD + EVENT_REVERSE + EVENT_EDGES
+    return f > EVENT_FORWARD or r > EVENT_REVERSE or e > EVENT_EDGES_BIG
 
 
 class _ReadBuffer:
@@ -353,13 +366,12 @@ class CCHipCalculator:
 
         self._logging_info("Calculate cross-correlation for {}...".format(chrom))
         flags = self._kernel_flags | (ffi.PMX_FLAG_SKIP_NCC if self.skip_ncc else 0)
-        # deep data: above ~1 % read starts per position and strand every tile overflows the event kernel's lists
-        # (EV_CAPF / EV_CAPR per 64 Kbit) -- say so instead of letting it find out (same integers either way).  The
-        # strand split is not known on the host (the device walks the reads): half the reads fed stands for a strand.
-        if 0.5 * self._fed > DENSE_READS_PER_BP * max(glen, 1):
+        # deep data or a track of very short runs: the average tile overflows the event kernel's lists -- say so instead
+        # of letting it find out (same integers either way).  The strand split is not known on the host (the device walks
+        # the reads): half the reads fed stands for a strand.
+        if window_only_hint(0.5 * self._fed, 0.5 * self._fed, getattr(self, "_n_runs", 0) if d_m is not None else 0, glen,
+                            self.max_shift):
             flags |= ffi.PMX_FLAG_WINDOW_ONLY
-        if d_m is not None and getattr(self, "_n_runs", 0) > DENSE_RUNS_PER_BP * max(glen, 1):
-            flags |= ffi.PMX_FLAG_WINDOW_ONLY   # a track of short runs (> ~330 run edges per 64 Kbit on average)
         c = L - 1
         known = self._known_mlen.get(chrom) if d_m is not None else None
         if known is not None and len(known) <= max(c, S - c):      # cache too short for this run: recompute

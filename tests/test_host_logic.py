@@ -310,9 +310,12 @@ def test_dense_data_hint_from_the_counts_the_calculator_holds():
     names, lens = ["sparse", "deep", "shortruns"], [6000, 6000, 6000]
     rng = np.random.default_rng(5)
     tracks = {"sparse": [(100, 5000, 1.0)], "deep": [(100, 5000, 1.0)],
-              "shortruns": [(b, b + 20, 1.0) for b in range(100, 5900, 100)]}          # 58 runs / 6000 bp > DENSE_RUNS_PER_BP
+              "shortruns": [(b, b + 20, 1.0) for b in range(100, 5900, 50)]}           # 116 runs / 6000 bp: 2500 edges per 64 Kbit
+    assert not C.window_only_hint(30, 30, 1, 6000, 100) and C.window_only_hint(30, 30, 116, 6000, 100)
+    assert not C.window_only_hint(300, 300, 0, 65536, 100) and C.window_only_hint(1700, 1700, 0, 65536, 100)
+    assert C.window_only_hint(800, 300, 0, 65536, 5000) and C.window_only_hint(30, 30, 200, 65536, 5000)   # fixed shares above 1023
     reads = []
-    for chrom, n in (("sparse", 30), ("deep", int(6000 * C.DENSE_READS_PER_BP * 2)), ("shortruns", 30)):
+    for chrom, n in (("sparse", 30), ("deep", 170), ("shortruns", 30)):    # 170 reads per strand / 6000 bp: 3700 reads per tile
         pos = np.sort(rng.choice(np.arange(1, 5900), size=n, replace=False))
         reads += [(False, chrom, int(p), 36) for p in pos]
         reads += [(True, chrom, int(p), 36) for p in pos]
