@@ -81,3 +81,4 @@ for k, e in summ["kernels"].items():
                                                                      e["wave_cycles_issuing"], e["wave_cycles_waiting"]))
 print(json.dumps(traffic["kernels"]))
 PY
+rm -rf $out/stats $out/pmc[0-9]   # (raw rocprofv3 output: only the summaries travel back)
