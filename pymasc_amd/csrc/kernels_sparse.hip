@@ -1957,10 +1957,24 @@ __device__ __forceinline__ u32 plan_block_scan(u32 v, u32 *part, u32 tid, u32 *t
     return base;
 }
 
-__global__ void __launch_bounds__(1024)
-k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const unsigned char *__restrict__ flags, u32 raw_lo,
-               u32 raw_hi, const u32 *__restrict__ n_flagged, u32 flags_per_count, u32 *__restrict__ plan)
+// what the planner needs of a launch: three words per job + the launch's shape (two of these fit the kernel arguments of
+// ONE launch: block 0 plans the cross-correlation window launch, block 1 the autocorrelation one)
+struct PlanLaunch {
+    u32 flag0[SP_MAXJOBS], tile0[SP_MAXJOBS], ntiles[SP_MAXJOBS];
+    u32 njobs, total_tiles, nwg, raw_lo, raw_hi, flags_per_count;
+    const unsigned char *flags;
+    const u32 *n_flagged;
+    u32 *plan;   // nullptr: no such launch
+};
+
+__device__ __forceinline__ void plan_flagged(const PlanLaunch &pl)
 {
+    const u32 njobs = pl.njobs, total_tiles = pl.total_tiles, nwg = pl.nwg, raw_lo = pl.raw_lo, raw_hi = pl.raw_hi;
+    const u32 flags_per_count = pl.flags_per_count;
+    const unsigned char *__restrict__ flags = pl.flags;
+    const u32 *__restrict__ n_flagged = pl.n_flagged;
+    u32 *__restrict__ plan = pl.plan;
+    if (!plan) return;
     // [raw_lo, raw_hi): the flag entries of THIS launch's jobs (a batch of more than SP_MAXJOBS chromosomes is several
     // launches over one flag array; n_flagged is zeroed per launch)
     // flags set in the array: the producer counts ITS tiles, each of which sets flags_per_count entries (an event tile is two
@@ -1975,8 +1989,8 @@ k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const
     __shared__ u32 se[2048];       // ... and where their ranges end
     const u32 tid = threadIdx.x;
     if (tid < njobs) {
-        jflag0[tid] = jobs.j[tid].flag0;
-        jtile0[tid] = jobs.j[tid].tile0;
+        jflag0[tid] = pl.flag0[tid];
+        jtile0[tid] = pl.tile0[tid];
     }
     if (tid == 0) jflag0[njobs] = 0xffffffffu;
     for (u32 w = tid; w <= nwg; w += 1024) sb[w] = total_tiles;   // (a start nobody writes -- fewer flags set than counted -- is an empty range)
@@ -2067,7 +2081,7 @@ k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const
     __syncthreads();
     if (tid < njobs) {
         // list entries whose range meets the job's tiles [a, b): starts and ends increase along the list
-        const u32 a = jobs.j[tid].tile0, b = a + jobs.j[tid].ntiles;
+        const u32 a = pl.tile0[tid], b = a + pl.ntiles[tid];
         u32 lo = 0, hi = nlive;                 // first i with end_i > a
         while (lo < hi) {
             const u32 mid = (lo + hi) >> 1;
@@ -2084,6 +2098,12 @@ k_plan_flagged(const SpJobTable jobs, u32 njobs, u32 total_tiles, u32 nwg, const
         plan[PLAN_JOBWG + 2 * tid] = first;     // entries [first, end) of the list
         plan[PLAN_JOBWG + 2 * tid + 1] = lo;
     }
+}
+
+__global__ void __launch_bounds__(1024) k_plan_flagged(const PlanLaunch a, const PlanLaunch b)
+{
+    if (blockIdx.x == 0) plan_flagged(a);
+    else plan_flagged(b);
 }
 
 #include "kernels_events.h"
@@ -2113,6 +2133,18 @@ struct VJob {
     u32 d_off, d_n;
     u32 flag0;   // autocorrelation: index of the chromosome's first tile in the dense-tile flag array
 };
+
+static void fill_plan_launch(PlanLaunch &p, const SpJobTable &tab, u32 n, u32 total, u32 nwg, u32 raw_lo, u32 raw_hi,
+                             u32 flags_per_count, const unsigned char *flags, const u32 *n_flagged, u32 *plan)
+{
+    for (u32 i = 0; i < n; i++) {
+        p.flag0[i] = tab.j[i].flag0;
+        p.tile0[i] = tab.j[i].tile0;
+        p.ntiles[i] = tab.j[i].ntiles;
+    }
+    p.njobs = n; p.total_tiles = total; p.nwg = nwg; p.raw_lo = raw_lo; p.raw_hi = raw_hi;
+    p.flags_per_count = flags_per_count; p.flags = flags; p.n_flagged = n_flagged; p.plan = plan;
+}
 
 // Cuts the global tile sequence of a launch into per-workgroup ranges and fills the device job table.
 static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr, uint32_t wg_per_cu, SpJobDev *out,
@@ -2540,7 +2572,9 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         }
         // Pass 2 (window kernel): every tile, or -- behind the event pass -- only the tiles it flagged (the whole grid returns
         // at once when there are none).  Behind the event pass it writes a slab of its own and k_events_tail adds its sums.
-        SpJobTable tabW;
+        SpJobTable tabW, tabA;
+        std::vector<VJob> va(n);
+        uint32_t totalA = 0, tpwA = 0, nwgA = 0;
         memset(&tabW, 0, sizeof tabW);
         plan_launch(ctx, &vjobs[lo], n, false, chunked ? (has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (has_m ? SP_WAVES : SP_WAVES_NCC), &tabW, &total, &tpw, &nwg);
         const size_t wwords = (size_t)(nwg + n) * SP_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64;
@@ -2553,8 +2587,27 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
                 pmx_set_error("k_plan_flagged: %u workgroups exceed its tables", nwg);
                 return PMX_ERR_INVALID;
             }
-            hipLaunchKernelGGL(k_plan_flagged, dim3(1), dim3(1024), 0, ctx->stream, tabW, n, total, nwg, (const unsigned char *)d_flags,
-                               raw_lo, raw_hi, (const u32 *)d_nflagged, (u32)EV_NQ, d_plan_cc);
+            // (both window launches of this batch are planned in ONE launch: the autocorrelation launch's shape is known here)
+            PlanLaunch pcc, pac;
+            memset(&pcc, 0, sizeof pcc);
+            memset(&pac, 0, sizeof pac);
+            fill_plan_launch(pcc, tabW, n, total, nwg, raw_lo, raw_hi, (u32)EV_NQ, (const unsigned char *)d_flags, d_nflagged, d_plan_cc);
+            if (fuse_mlen) {
+                for (uint32_t i = 0; i < n; i++) {
+                    va[i].job = vjobs[lo + i].job;
+                    va[i].d_off = 0;
+                    va[i].d_n = fused_lag + 1;
+                    va[i].flag0 = vjobs[lo + i].flag0;
+                }
+                memset(&tabA, 0, sizeof tabA);
+                plan_launch(ctx, va.data(), n, true, AC_WAVES, &tabA, &totalA, &tpwA, &nwgA);
+                if (nwgA > 2048) {
+                    pmx_set_error("k_plan_flagged: %u workgroups exceed its tables", nwgA);
+                    return PMX_ERR_INVALID;
+                }
+                fill_plan_launch(pac, tabA, n, totalA, nwgA, raw_lo, raw_hi, 1u, (const unsigned char *)d_flags_ac, d_nflagged + 1, d_plan_ac);
+            }
+            hipLaunchKernelGGL(k_plan_flagged, dim3(fuse_mlen ? 2 : 1), dim3(1024), 0, ctx->stream, pcc, pac);
             PMX_CHECK_LAUNCH("k_plan_flagged");
         }
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, use_events);
@@ -2591,24 +2644,11 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         const u32 lagcap = (u32)(((size_t)(fuse_mlen ? fused_lag : 0) + 1 + 1023) / 1024 * 1024);
         if (fuse_mlen) {
             // the autocorrelation window kernel for the flagged tiles (its own slab), same gate
-            std::vector<VJob> va(n);
-            for (uint32_t i = 0; i < n; i++) {
-                va[i].job = vjobs[lo + i].job;
-                va[i].d_off = 0;
-                va[i].d_n = fused_lag + 1;
-                va[i].flag0 = vjobs[lo + i].flag0;
-            }
-            SpJobTable tabA;
-            memset(&tabA, 0, sizeof tabA);
-            plan_launch(ctx, va.data(), n, true, AC_WAVES, &tabA, &total, &tpw, &nwg);
-            rc = pmx_ensure_slab_ac(ctx, (size_t)(nwg + n) * AC_SEG_ROWS * 1024);
+            rc = pmx_ensure_slab_ac(ctx, (size_t)(nwgA + n) * AC_SEG_ROWS * 1024);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_plan_flagged, dim3(1), dim3(1024), 0, ctx->stream, tabA, n, total, nwg, (const unsigned char *)d_flags_ac,
-                               raw_lo, raw_hi, (const u32 *)(d_nflagged + 1), 1u, d_plan_ac);
-            PMX_CHECK_LAUNCH("k_plan_flagged");
             rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl, true);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwg), dim3(256), 0, ctx->stream, tabA, n, total, tpw,
+            hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwgA), dim3(256), 0, ctx->stream, tabA, n, totalA, tpwA,
                                lg_slot_lanes(fused_lag + 1), ctx->d_slab_ac, (const unsigned char *)d_flags_ac, (const u32 *)(d_nflagged + 1),
                                (const u32 *)d_plan_ac);
             PMX_CHECK_LAUNCH("k_autocorr_edges");
