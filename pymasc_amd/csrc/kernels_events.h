@@ -70,7 +70,7 @@
 #define EV_WAVES 4
 #endif
 #ifndef EV_WAVES_NCC
-#define EV_WAVES_NCC 6
+#define EV_WAVES_NCC 8
 #endif
 
 #ifdef EV_STAMPS   // diagnostic build: where does a tile's time go (never defined in the shipped library)
