@@ -396,10 +396,14 @@ def main():
             out = ctx.host_array(a.size, dt)
             out[:] = a
             return out
+        # one page-locked block per chromosome, the four arrays back to back (Context.host_packed): one copy per chromosome
         host = []
         for v in vecs:
-            host.append((pinned(v.h_fpos, np.uint32), pinned(v.h_rpos, np.uint32),
-                         pinned(v.h_first, np.uint32) if with_m else None, pinned(v.h_last, np.uint32) if with_m else None))
+            src = [v.h_fpos, v.h_rpos] + ([v.h_first, v.h_last] if with_m else [])
+            dst = ctx.host_packed([a.size for a in src], np.uint32)
+            for d_, a in zip(dst, src):
+                d_[:] = a
+            host.append(tuple(dst) + ((None, None) if not with_m else ()))
         build_jobs = [(v.F.data_ptr(), v.R.data_ptr(), v.M.data_ptr() if with_m else None, v.nbits, h[0], h[1], h[2], h[3])
                       for v, h in zip(vecs, host)]
 
@@ -427,7 +431,7 @@ def main():
         h2d = sum(h[0].nbytes + h[1].nbytes + ((h[2].nbytes + h[3].nbytes) if with_m else 0) for h in host)
         end_to_end = {"value": work_per_step / dt, "unit": "shifts*bp/s", "ms_per_step": dt * 1e3, "steps": n_e2e,
                       "h2d_bytes_this_rank": h2d, "d2h_bytes": int(host_rows.numel() * 8),
-                      "what": "uint32 bit positions + intervals in page-locked host memory -> pmx_bits_build_batch (one "
+                      "what": "uint32 bit positions + intervals in page-locked host memory (one block per chromosome) -> pmx_bits_build_batch (one "
                               "stream-ordered call per genome: H2D copies one chromosome ahead of the builder kernels, deferred "
                               "range check) -> k_cc_events (+ window kernels for dense tiles) -> exchange -> rows in host memory"}
 
@@ -456,8 +460,11 @@ def main():
                 # ... and the strand travels in the top bit of the position word (ffi.pack_strand): 4 bytes per read
                 reads[v.name] = (pinned(ffi.pack_strand(pos[order].astype(np.int32), rv[order]), np.int32),
                                  L if uniform else pinned(ln[order], np.uint16), None)
-                if with_m:      # BigWig (begin, end): set(begin + 1, end)
-                    tracks[v.name] = (pinned(v.h_first - 1, np.uint32), h[3], None)
+                if with_m:      # BigWig (begin, end): set(begin + 1, end); both arrays in one page-locked block
+                    b_, e_ = ctx.host_packed([v.h_first.size, v.h_last.size], np.uint32)
+                    b_[:] = v.h_first - 1
+                    e_[:] = v.h_last
+                    tracks[v.name] = (b_, e_, None)
             names = [v.name for v in vecs]
             lens = [v.length for v in vecs]
 
@@ -466,6 +473,7 @@ def main():
             def calc_step():
                 t0 = time.perf_counter()
                 calc = CCHipCalculator(S, L, names, lens, bwfeeder=TrackFeeder(tracks) if with_m else None, context=ctx)
+                tc = time.perf_counter()
                 for v in vecs:
                     calc.feed_reads(v.name, *reads[v.name])
                 t1 = time.perf_counter()
@@ -479,10 +487,11 @@ def main():
                     pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
                 else:
                     calc.finishup_calculation()
+                tf = time.perf_counter()
                 whole = calc.get_whole_result()
                 t2 = time.perf_counter()
                 calc.close()
-                stamps.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
+                stamps.append((tc - t0, t1 - tc, tf - t1, t2 - tf, time.perf_counter() - t2))
                 return whole
             calc_step()
             fence()
@@ -507,7 +516,7 @@ def main():
             fence()
             dtc = (time.perf_counter() - t1) / n_e2e
             gc.enable()
-            print("[calc leg] feed (host, paced by the copies) / finishup + results / close (ms), every call:",
+            print("[calc leg] construct / feed (host, paced by the copies) / finishup / get_whole_result / close (ms), every call:",
                   [[round(x * 1e3, 2) for x in st] for st in stamps], file=sys.stderr)
             # rows equal to the resident-vector run (job order = this rank's slot order at one rank)
             hr = rows.cpu().numpy()

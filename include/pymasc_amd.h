@@ -50,10 +50,11 @@ extern "C" {
 #define PMX_FLAG_SKIP_NCC     1u  /* skip_ncc=True (mscc.pyx:235,313): row 0 left zero (popcounts still reported) */
 #define PMX_FLAG_FORCE_DENSE  2u  /* use the dense word-parallel kernels (one lane per shift)          */
 #define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven kernels (error if unsupported)        */
-#define PMX_FLAG_WINDOW_ONLY 16u  /* hint: the caller knows the reads are dense (more than ~1 % of the positions of a
-                                   * strand hold a read start: > 60 M reads on hg38): go straight to the window
-                                   * kernel instead of letting the event kernel find that out tile by tile.  Same
-                                   * integers either way */
+#define PMX_FLAG_WINDOW_ONLY 16u  /* hint: the caller knows the vectors are dense -- per 65536 positions, forward reads +
+                                   * reverse reads + 2 x mappable runs above 3304, or 2 x runs above 1536 (max_shift <=
+                                   * 1023: ~2.4 % read starts per strand, ~150 M reads on hg38; above 1023: 768 forward /
+                                   * 1000 reverse reads / 384 run edges) --: go straight to the window kernels instead of
+                                   * letting the event kernel find that out tile by tile.  Same integers either way */
 #define PMX_FLAG_SKIP_MLEN    8u  /* the caller holds mappable_len already (the *_mappability.json cache,
                                    * handler/mappability.py:239-259): no autocorrelation pass; row 4 and
                                    * scalars[2] are written as zeros */
@@ -158,6 +159,9 @@ int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, c
  * clipped and recorded in d_state[PMX_FEED_FIRST_OUT_OF_RANGE] (d_state may be NULL).  Asynchronous. */
 int pmx_bits_set_regions_async(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
                                uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state);
+/* (The three feeders above and below stage their host arrays in one device slot, each array padded to 16 bytes.  Arrays
+ * that lie in host memory in that same layout -- back to back in argument order, each padded to 16 bytes, ideally in
+ * page-locked memory from pmx_host_alloc -- are copied in ONE piece; anything else array by array.) */
 /* A batch of chromosomes from bit positions and intervals in host memory -> cleared and rebuilt vectors, ONE call, no
  * synchronisation: for callers that hold bit positions already (any of d_F / d_R / d_M may be NULL).  Range errors of the
  * whole batch are reported by pmx_bits_build_status, which synchronises. */

@@ -116,6 +116,7 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     }
     ctx->jobtab_next = 0;
     ctx->copy_stream = nullptr;
+    ctx->copy_stream2 = nullptr;
     ctx->feed_copied = nullptr;
     ctx->d_build_err = nullptr;
     ctx->build_err_cap = 0;
@@ -137,6 +138,7 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
         ctx->own_stream = true;
     }
     bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->feed_copied, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < PMX_FEED_SLOTS; i++) ok = hipEventCreateWithFlags(&ctx->feed_done[i], hipEventDisableTiming) == hipSuccess;
     if (!ok || hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -165,12 +167,14 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->copy_stream2) (void)hipStreamSynchronize(ctx->copy_stream2);
     for (int i = 0; i < PMX_FEED_SLOTS; i++) {
         if (ctx->d_feed[i]) (void)hipFree(ctx->d_feed[i]);
         if (ctx->feed_done[i]) (void)hipEventDestroy(ctx->feed_done[i]);
     }
     if (ctx->feed_copied) (void)hipEventDestroy(ctx->feed_copied);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->copy_stream2) (void)hipStreamDestroy(ctx->copy_stream2);
     if (ctx->d_build_err) (void)hipFree(ctx->d_build_err);
     for (int i = 0; i < 2; i++)
         if (ctx->d_jobtab[i]) (void)hipFree(ctx->d_jobtab[i]);
@@ -691,6 +695,7 @@ int pmx_host_free(pmx_ctx *ctx, void *h)
     (void)hipSetDevice(ctx->device);
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->copy_stream));
+    PMX_HIP(hipStreamSynchronize(ctx->copy_stream2));
     PMX_HIP(hipHostFree(h));
     return PMX_OK;
 }
@@ -719,9 +724,9 @@ static int feed_acquire(pmx_ctx *ctx, size_t bytes, unsigned char **d, uint32_t 
 }
 
 // copies queued on the copy stream -> visible to the kernels queued on the context's stream after this
-static int feed_publish(pmx_ctx *ctx)
+static int feed_publish(pmx_ctx *ctx, hipStream_t cs = nullptr)
 {
-    PMX_HIP(hipEventRecord(ctx->feed_copied, ctx->copy_stream));
+    PMX_HIP(hipEventRecord(ctx->feed_copied, cs ? cs : ctx->copy_stream));
     PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->feed_copied, 0));
     return PMX_OK;
 }
@@ -734,6 +739,45 @@ static int feed_release(pmx_ctx *ctx, uint32_t slot)
 }
 
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// Host arrays -> one staging slot.  Arrays that lie in host memory at the offsets they take in the slot (back to back,
+// each padded to 16 bytes: ffi.Context.host_packed lays them out so) go in ONE copy: a 0.1-MB copy costs ~13 us of the
+// copy engine + the gap to the next one, whatever its size, and a genome is a hundred of them.
+struct FeedPart {
+    size_t off;        // byte offset in the slot
+    const void *src;   // host array (nullptr / 0 bytes: none)
+    size_t bytes;
+};
+static int feed_copy(pmx_ctx *ctx, unsigned char *d, const FeedPart *parts, uint32_t nparts, hipStream_t cs = nullptr)
+{
+    if (!cs) cs = ctx->copy_stream;
+
+    const unsigned char *base = nullptr;
+    size_t base_off = 0, end = 0;
+    bool packed = true;
+    uint32_t live = 0;
+    for (uint32_t i = 0; i < nparts; i++) {
+        if (!parts[i].src || parts[i].bytes == 0) continue;
+        const unsigned char *p = (const unsigned char *)parts[i].src;
+        if (!base) {
+            base = p;
+            base_off = parts[i].off;
+        } else if (p != base + (parts[i].off - base_off)) {
+            packed = false;
+        }
+        end = parts[i].off + parts[i].bytes;
+        live++;
+    }
+    if (live == 0) return PMX_OK;
+    if (packed && live > 1) {
+        PMX_HIP(hipMemcpyAsync(d + base_off, base, end - base_off, hipMemcpyHostToDevice, cs));
+        return PMX_OK;
+    }
+    for (uint32_t i = 0; i < nparts; i++)
+        if (parts[i].src && parts[i].bytes)
+            PMX_HIP(hipMemcpyAsync(d + parts[i].off, parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, cs));
+    return PMX_OK;
+}
 
 extern "C" {
 
@@ -754,9 +798,10 @@ int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, c
     uint32_t slot = 0;
     int rc = feed_acquire(ctx, o_rev + n, &d, &slot);
     if (rc) return rc;
-    PMX_HIP(hipMemcpyAsync(d, h_pos, (size_t)n * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-    if (len_bytes) PMX_HIP(hipMemcpyAsync(d + o_len, h_readlen, (size_t)n * len_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-    if (h_is_reverse) PMX_HIP(hipMemcpyAsync(d + o_rev, h_is_reverse, (size_t)n, hipMemcpyHostToDevice, ctx->copy_stream));
+    const FeedPart parts[3] = {{0, h_pos, (size_t)n * pos_bytes}, {o_len, len_bytes ? h_readlen : nullptr, (size_t)n * len_bytes},
+                               {o_rev, h_is_reverse, (size_t)n}};
+    rc = feed_copy(ctx, d, parts, 3);
+    if (rc) return rc;
     rc = feed_publish(ctx);
     if (rc) return rc;
     rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d, pos_bytes, d + o_len, len_bytes, uniform_len, h_is_reverse ? d + o_rev : nullptr,
@@ -777,9 +822,12 @@ int pmx_bits_set_regions_async(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, 
     uint32_t slot = 0;
     int rc = feed_acquire(ctx, 2 * o_last, &d, &slot);
     if (rc) return rc;
-    PMX_HIP(hipMemcpyAsync(d, h_first, (size_t)n * width_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-    PMX_HIP(hipMemcpyAsync(d + o_last, h_last, (size_t)n * width_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-    rc = feed_publish(ctx);
+    // (on the second copy stream: a chromosome's intervals are 0.1-0.2 MB between two 5-10 MB read copies -- in one queue
+    // they cost the copy engine 20 us + a gap either side, per chromosome)
+    const FeedPart parts[2] = {{0, h_first, (size_t)n * width_bytes}, {o_last, h_last, (size_t)n * width_bytes}};
+    rc = feed_copy(ctx, d, parts, 2, ctx->copy_stream2);
+    if (rc) return rc;
+    rc = feed_publish(ctx, ctx->copy_stream2);
     if (rc) return rc;
     rc = pmx_launch_set_regions_w(ctx, d_words, nbits, d, d + o_last, width_bytes, n, first_offset,
                                   d_state ? d_state + PMX_FEED_FIRST_OUT_OF_RANGE : nullptr);
@@ -826,12 +874,10 @@ int pmx_bits_build_batch(pmx_ctx *ctx, uint32_t njobs, const pmx_build_job *jobs
         uint32_t slot = 0;
         int rc = feed_acquire(ctx, total, &d, &slot);
         if (rc) return rc;
-        if (jb.n_f) PMX_HIP(hipMemcpyAsync(d, jb.h_fpos, (size_t)jb.n_f * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-        if (jb.n_r) PMX_HIP(hipMemcpyAsync(d + o_r, jb.h_rpos, (size_t)jb.n_r * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-        if (jb.n_iv) {
-            PMX_HIP(hipMemcpyAsync(d + o_a, jb.h_first, (size_t)jb.n_iv * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-            PMX_HIP(hipMemcpyAsync(d + o_b, jb.h_last, (size_t)jb.n_iv * pos_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-        }
+        const FeedPart parts[4] = {{0, jb.h_fpos, (size_t)jb.n_f * pos_bytes}, {o_r, jb.h_rpos, (size_t)jb.n_r * pos_bytes},
+                                   {o_a, jb.h_first, (size_t)jb.n_iv * pos_bytes}, {o_b, jb.h_last, (size_t)jb.n_iv * pos_bytes}};
+        rc = feed_copy(ctx, d, parts, 4);
+        if (rc) return rc;
         rc = feed_publish(ctx);
         if (rc) return rc;
         uint64_t *err = (uint64_t *)(ctx->d_build_err + ctx->build_err_jobs + i);

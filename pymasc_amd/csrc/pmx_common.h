@@ -38,7 +38,9 @@ struct pmx_timed_launch {
     hipEvent_t start, stop;
 };
 
+#ifndef PMX_FEED_SLOTS
 #define PMX_FEED_SLOTS 3
+#endif
 #define PMX_JOBTAB_SLOTS 8
 
 struct pmx_ctx {
@@ -85,6 +87,7 @@ struct pmx_ctx {
     bool feed_used[PMX_FEED_SLOTS];
     uint32_t feed_next;
     hipStream_t copy_stream;     // H2D copies of the feeders run here, one slot ahead of the kernels on `stream`
+    hipStream_t copy_stream2;    // ... the small interval copies of pmx_bits_set_regions_async here, beside the read copies
     hipEvent_t feed_copied;
     // job tables in device memory (kernels_sparse.hip: SpJobTableRef): one buffer per stream of the context (main / auxiliary),
     // filled from a ring of page-locked staging slots so that an upload never waits for the GPU

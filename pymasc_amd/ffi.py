@@ -279,6 +279,18 @@ class Context:
         self._pinned[arr.ctypes.data] = p.value
         return arr
 
+    def host_packed(self, sizes, dtype):
+        """Arrays of `dtype` over ONE page-locked block, back to back with every array padded to 16 bytes: the layout the
+        feeders give their staging slot, so feed_reads / bits_set_regions_async / bits_build_batch copy them in one piece
+        (sizes e.g. (n_forward, n_reverse, n_intervals, n_intervals)).  Released with the context (or host_free(first array))."""
+        dt = np.dtype(dtype)
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (int(n) * dt.itemsize + 15) & ~15
+        block = self.host_array(max(total, 16), np.uint8)
+        return [block[o:o + int(n) * dt.itemsize].view(dt) for o, n in zip(offs, sizes)]
+
     def host_free(self, arr: np.ndarray):
         p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
         if p is not None:

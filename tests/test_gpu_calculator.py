@@ -45,11 +45,14 @@ def test_golden_mscc(golden_calc):
 
 
 @pytest.mark.parametrize("flags", [0, ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE])
-@pytest.mark.parametrize("skip_ncc", [False, True])
-def test_multi_chromosome_vs_oracle_calculator(flags, skip_ncc):
+@pytest.mark.parametrize("skip_ncc,early_batch", [(False, 0), (True, 0), (False, 1), (False, 2)])
+def test_multi_chromosome_vs_oracle_calculator(flags, skip_ncc, early_batch):
+    """early_batch 1 / 2: the kernels of the chromosomes queued so far are launched at every (second) flush, the rest at
+    the fetch; 0 (the default): everything at the fetch."""
     names, lens, tracks, reads = _small_mscc_setup(seed=17)
     S, L = 200, 36
     calc = CCHipCalculator(S, L, names, lens, bwfeeder=DictFeeder(tracks), skip_ncc=skip_ncc, kernel_flags=flags)
+    calc.early_batch = early_batch
     ocalc = oracle.OracleCalculator(S, L, names, lens, mappability={
         c: [x for x in iv if np.float32(x[2]) >= 1] for c, iv in tracks.items()}, skip_ncc=skip_ncc)
     feed_all(calc, reads)

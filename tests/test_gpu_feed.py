@@ -206,6 +206,56 @@ def test_build_batch_matches_oracle_and_reports_range_errors(ctx, dt):
     del keep
 
 
+@pytest.mark.parametrize("dt", [np.uint32, np.int64])
+@pytest.mark.parametrize("with_m", [True, False])
+def test_packed_host_arrays_are_copied_in_one_piece_with_the_same_result(ctx, dt, with_m):
+    """Context.host_packed lays the arrays of a chromosome out as the staging slot does (back to back, 16-byte padded):
+    the feeders then issue ONE copy.  Sizes that are not multiples of 16 bytes exercise the padding."""
+    rng = np.random.default_rng(31 + (1 if with_m else 0))
+    jobs, want, ptrs = [], [], []
+    for nbits in (70001, 131072 + 13, 901):
+        fpos = np.sort(rng.integers(0, nbits, size=nbits // 50 + 1))
+        rpos = np.sort(rng.integers(0, nbits, size=nbits // 40 + 3))
+        starts = np.sort(rng.integers(0, max(nbits - 400, 1), size=max(nbits // 500, 1) + 2))
+        ends = np.minimum(starts + rng.integers(0, 300, size=starts.size), nbits - 1)
+        src = [fpos, rpos] + ([starts, ends] if with_m else [])
+        dst = ctx.host_packed([a.size for a in src], dt)
+        for d_, a in zip(dst, src):
+            d_[:] = a
+        assert all(int(b.ctypes.data - a.ctypes.data) == ((a.nbytes + 15) & ~15) for a, b in zip(dst, dst[1:]))
+        dF, dR, dM = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits), ctx.bits_alloc(nbits) if with_m else None
+        jobs.append((dF, dR, dM, nbits, dst[0], dst[1], dst[2] if with_m else None, dst[3] if with_m else None))
+        ptrs.append((dF, dR, dM))
+        want.append((oracle.bits_from_positions(fpos, nbits), oracle.bits_from_positions(rpos, nbits),
+                     oracle.bits_from_intervals([(int(s) - 1, int(e)) for s, e in zip(starts, ends)], nbits) if with_m else None, nbits))
+    keep = ctx.bits_build_batch(jobs, dt)
+    ctx.bits_build_status()
+    for (dF, dR, dM), (wF, wR, wM, nbits) in zip(ptrs, want):
+        np.testing.assert_array_equal(ctx.bits_download(dF, nbits), wF)
+        np.testing.assert_array_equal(ctx.bits_download(dR, nbits), wR)
+        if wM is not None:
+            np.testing.assert_array_equal(ctx.bits_download(dM, nbits), wM)
+    # the interval feeder alone, from a packed pair
+    if with_m:
+        nbits = 70001
+        starts = np.sort(rng.integers(0, nbits - 400, size=77))
+        ends = starts + rng.integers(1, 300, size=77)
+        b_, e_ = ctx.host_packed([77, 77], dt)
+        b_[:], e_[:] = starts, ends
+        d = ctx.bits_alloc(nbits)
+        keep2 = ctx.bits_set_regions_async(d, nbits, b_, e_, 1, None)
+        np.testing.assert_array_equal(ctx.bits_download(d, nbits),
+                                      oracle.bits_from_intervals([(int(s), int(e)) for s, e in zip(starts, ends)], nbits))
+        ctx.bits_free(d)
+        del keep2
+    for dF, dR, dM in ptrs:
+        ctx.bits_free(dF)
+        ctx.bits_free(dR)
+        if dM:
+            ctx.bits_free(dM)
+    del keep
+
+
 @pytest.mark.parametrize("max_shift", [300, 2000])
 def test_mappable_len_batch_matches_oracle(ctx, max_shift):
     rng = np.random.default_rng(5 + max_shift)

@@ -69,11 +69,15 @@ def _small_mscc_setup(seed=3, skip_ncc=False):
     return names, lens, tracks, reads
 
 
+@pytest.mark.parametrize("early_batch", [10, 1, 0])
 @pytest.mark.parametrize("skip_ncc", [False, True])
-def test_both_against_oracle_calculator(skip_ncc):
+def test_both_against_oracle_calculator(skip_ncc, early_batch):
+    """early_batch: chromosomes queued before their kernels are launched ahead of the fetch (1: every flush launches, 0: one
+    launch at the fetch) -- the same results whichever way."""
     names, lens, tracks, reads = _small_mscc_setup(skip_ncc=skip_ncc)
     S, L = 120, 36
     calc = CCHipCalculator(S, L, names, lens, bwfeeder=DictFeeder(tracks), skip_ncc=skip_ncc, context=FakeContext())
+    calc.early_batch = early_batch
     ocalc = oracle.OracleCalculator(S, L, names, lens, mappability={
         c: [x for x in iv if np.float32(x[2]) >= 1] for c, iv in tracks.items()}, skip_ncc=skip_ncc)
     feed_all(calc, reads)
