@@ -522,12 +522,12 @@ def main():
             hr = rows.cpu().numpy()
             for slot, j in enumerate(mine):
                 name = vecs[slot].name
-                assert whole.chroms[name].ccbins == hr[j, ffi.PMX_ROW_NCC_CCBINS].tolist(), "calculator ncc differs"
+                assert np.array_equal(whole.chroms[name].ccbins, hr[j, ffi.PMX_ROW_NCC_CCBINS]), "calculator ncc differs"
                 assert whole.chroms[name].forward_sum == int(hr[j, ffi.PMX_ROW_SCALARS, 0])
                 if with_m:
                     mc = whole.mappable_chroms[name]
-                    assert mc.ccbins == hr[j, ffi.PMX_ROW_MSCC_CCBINS].tolist(), "calculator mscc.ccbins differ"
-                    assert mc.forward_sum == hr[j, ffi.PMX_ROW_MSCC_FSUM].tolist() and mc.reverse_sum == hr[j, ffi.PMX_ROW_MSCC_RSUM].tolist()
+                    assert np.array_equal(mc.ccbins, hr[j, ffi.PMX_ROW_MSCC_CCBINS]), "calculator mscc.ccbins differ"
+                    assert np.array_equal(mc.forward_sum, hr[j, ffi.PMX_ROW_MSCC_FSUM]) and np.array_equal(mc.reverse_sum, hr[j, ffi.PMX_ROW_MSCC_RSUM])
             nreads = sum(r[0].size for r in reads.values())
             calc_leg = {"value": work_per_step / dtc, "unit": "shifts*bp/s", "ms_per_step": dtc * 1e3, "steps": n_e2e,
                         "reads": int(nreads), "reads_per_s": nreads / dtc,

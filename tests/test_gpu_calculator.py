@@ -28,7 +28,7 @@ def golden_calc():
 def test_golden_ncc(golden_calc):
     r = golden_calc.get_result("chr1").chrom
     assert (r.forward_sum, r.reverse_sum) == (622, 670)
-    assert r.ccbins[:5] == [28, 26, 19, 22, 26]
+    assert list(r.ccbins[:5]) == [28, 26, 19, 22, 26]
     _, cc = fx.load_cc_table("ENCFF000RMB-test_cc.tab")
     np.testing.assert_allclose(r.cc, cc["chr1"], rtol=0, atol=1e-15)
 
@@ -38,7 +38,7 @@ def test_golden_mscc(golden_calc):
     _, per = fx.load_nreads_table()
     np.testing.assert_array_equal(np.array(r.forward_sum), per["chr1"][0])
     np.testing.assert_array_equal(np.array(r.reverse_sum), per["chr1"][1])
-    assert r.ccbins[:4] == [16, 20, 14, 15]
+    assert list(r.ccbins[:4]) == [16, 20, 14, 15]
     assert list(r.mappable_len) == fx.load_mappability_json()["references"]["chr1"]
     _, cc = fx.load_cc_table("ENCFF000RMB-test_mscc.tab")
     np.testing.assert_allclose(r.cc, cc["chr1"], rtol=0, atol=1e-15)

@@ -96,7 +96,7 @@ def test_both_against_oracle_calculator(skip_ncc, early_batch):
     assert np.isnan(whole.mappable_chroms["d"].cc).all()
     # results must survive the worker -> parent queue (handler/worker.py:234)
     back = pickle.loads(pickle.dumps(calc.get_result("a")))
-    assert back.mappable_chrom.ccbins == calc.get_result("a").mappable_chrom.ccbins
+    assert list(back.mappable_chrom.ccbins) == list(calc.get_result("a").mappable_chrom.ccbins)
 
 
 def test_worker_style_flush_per_chromosome():
@@ -189,7 +189,7 @@ def test_bulk_feed_equals_per_read_feed():
     two.finishup_calculation()
     for c in names:
         a, b = one.get_result(c), two.get_result(c)
-        assert a.chrom.ccbins == b.chrom.ccbins and a.chrom.forward_read_len_sum == b.chrom.forward_read_len_sum
+        assert list(a.chrom.ccbins) == list(b.chrom.ccbins) and a.chrom.forward_read_len_sum == b.chrom.forward_read_len_sum
         assert list(a.mappable_chrom.ccbins) == list(b.mappable_chrom.ccbins)
 
 
@@ -248,7 +248,7 @@ def test_bulk_feed_with_packed_strand_and_scalar_read_length():
     two.finishup_calculation()
     for c in names:
         a, b = one.get_result(c).chrom, two.get_result(c).chrom
-        assert a.ccbins == b.ccbins and (a.forward_sum, a.reverse_sum) == (b.forward_sum, b.reverse_sum)
+        assert list(a.ccbins) == list(b.ccbins) and (a.forward_sum, a.reverse_sum) == (b.forward_sum, b.reverse_sum)
         assert (a.forward_read_len_sum, a.reverse_read_len_sum) == (b.forward_read_len_sum, b.reverse_read_len_sum)
 
 
