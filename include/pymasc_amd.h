@@ -51,8 +51,8 @@ extern "C" {
 #define PMX_FLAG_FORCE_DENSE  2u  /* use the dense word-parallel kernels (one lane per shift)          */
 #define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven kernels (error if unsupported)        */
 #define PMX_FLAG_WINDOW_ONLY 16u  /* hint: the caller knows the vectors are dense -- per 65536 positions, forward reads +
-                                   * reverse reads + 2 x mappable runs above 3304, or 2 x runs above 1536 (max_shift <=
-                                   * 1023: ~2.4 % read starts per strand, ~150 M reads on hg38; above 1023: 768 forward /
+                                   * reverse reads + 2 x mappable runs above 2416 (3304 without a track), or 2 x runs above 1536
+                                   * (max_shift <= 1023: ~1.8 % read starts per strand, ~110 M reads on hg38; above 1023: 768 forward /
                                    * 1000 reverse reads / 384 run edges) --: go straight to the window kernels instead of
                                    * letting the event kernel find that out tile by tile.  Same integers either way */
 #define PMX_FLAG_SKIP_MLEN    8u  /* the caller holds mappable_len already (the *_mappability.json cache,

@@ -37,10 +37,11 @@ logger = logging.getLogger(__name__)
 
 _CHUNK = 1 << 16
 # The event kernel's list capacities per 64-Kbit tile (csrc/kernels_events.h: EV_CAPF, EV_CAPR, EV_CAPE_SMALL).  max_shift <=
-# 1023: forward reads + reverse reads + run edges share one pool, and run edges alone may fill EVENT_EDGES of it; above:
+# 1023: forward reads + reverse reads + run edges share one pool (EVENT_POOL), and run edges alone may fill EVENT_EDGES of it; above:
 # fixed shares.  A chromosome whose AVERAGE tile is beyond them goes to the window kernels unseen (PMX_FLAG_WINDOW_ONLY).
 EVENT_TILE_BITS = 65536
 EVENT_FORWARD, EVENT_REVERSE, EVENT_EDGES, EVENT_EDGES_BIG = 768, 1000, 1536, 384
+EVENT_POOL, EVENT_POOL_NCC = 2416, 768 + 1000 + 1536      # EV_POOL_SMALL (with a track) / without
 
 
 def window_only_hint(n_forward, n_reverse, n_runs, length, max_shift):
@@ -49,7 +50,7 @@ def window_only_hint(n_forward, n_reverse, n_runs, length, max_shift):
     per_tile = EVENT_TILE_BITS / float(max(length, 1))
     f, r, e = n_forward * per_tile, n_reverse * per_tile, 2.0 * n_runs * per_tile
     if max_shift <= 1023:
-        return e > EVENT_EDGES or f + r + e > EVENT_FORWARD + EVENT_REVERSE + EVENT_EDGES
+        return e > EVENT_EDGES or f + r + e > (EVENT_POOL if n_runs else EVENT_POOL_NCC)
     return f > EVENT_FORWARD or r > EVENT_REVERSE or e > EVENT_EDGES_BIG
 
 

@@ -37,16 +37,25 @@
 // The three lists of a tile (forward reads, reverse reads of the tile + of the max_shift bits above it, run edges of
 // everything staged) share ONE pool of LDS: LF at its start, LR behind the forward reads, LE behind the reverse reads
 // (offsets known after the block scan).  max_shift <= 1023: a tile is dense -- left to the window kernels -- when its run
-// edges alone exceed EV_CAPE_SMALL, or when reads + edges together exceed the pool: on an ordinary track (~60 edges) the
-// reads may fill all of it, ~2.4 % per strand, where the window kernel costs 2.4x the event kernel; on a track with edges
-// every 50 bases the reads get what the edges leave.  BIG (the LDS is spent on histograms): fixed shares, 768 / 1000 / 384.
+// edges alone exceed EV_CAPE_SMALL, or when reads + edges together exceed the pool (2416 entries; 3304 without M): on an
+// ordinary track (~60 edges) the reads may fill all of it, ~1.8 % per strand, where the window kernel costs twice the event
+// kernel; on a track with edges every 50 bases the reads get what the edges leave.  BIG (the LDS is spent on
+// histograms): fixed shares, 768 / 1000 / 384.
+#ifndef EV_CAPF
 #define EV_CAPF 768u
+#endif
+#ifndef EV_CAPR
 #define EV_CAPR 1000u
+#endif
 #ifndef EV_CAPE_SMALL
 #define EV_CAPE_SMALL 1536u
 #endif
 #define EV_CAPE(BIG) ((BIG) ? 384u : EV_CAPE_SMALL)
-#define EV_POOL_ENTRIES(HAS_M, BIG) (EV_CAPF + EV_CAPR + ((BIG) ? ((HAS_M) ? 384u : 0u) : EV_CAPE_SMALL))
+#ifndef EV_POOL_SMALL
+#define EV_POOL_SMALL 2416u               // max_shift <= 1023 with M: what 31 KB of LDS per workgroup (FIVE per CU: 31744 B fit,
+                                          // 32256 B do not) leave the lists
+#endif
+#define EV_POOL_ENTRIES(HAS_M, BIG) ((BIG) ? EV_CAPF + EV_CAPR + ((HAS_M) ? 384u : 0u) : ((HAS_M) ? EV_POOL_SMALL : EV_CAPF + EV_CAPR + EV_CAPE_SMALL))
 #define EV_RANK_BITS 12u                  // rank field of a forward entry (bits 17..28): index into the reverse list
 #define EV_POS 0x1ffffu                   // 17 bits of biased position (BIG: 16384 + 65536 + 8192 + 1152 staged bits at most)
 #define EV_PAD 12u                        // sentinel entries behind the read lists
@@ -67,7 +76,7 @@
 #define EV_PRIO_EDGES EV_PRIO_EVENTS
 #endif
 #ifndef EV_WAVES
-#define EV_WAVES 4
+#define EV_WAVES 5
 #endif
 #ifndef EV_WAVES_NCC
 #define EV_WAVES_NCC 8
@@ -94,15 +103,17 @@
 //   NC [HN]      one cell per shift: ncc in the low half, mscc.ccbins in the high half -- ONE LDS atomic per pair
 //                (NCC-only: plain 32-bit ncc).  Both are counts of pairs of listed forward reads, at most one pair
 //                per forward read and shift: the row is flushed to the slab before 65535 listed forward reads.
-//   GF, GR, EE   signed.  !BIG: [HN] i32 each.  BIG: 16-bit cells, two per dword (cell k: dword k >> 1, half k & 1),
-//                added to with value << 16 (k & 1): the dword is lo + 65536 hi as an integer, recovered as
-//                lo = int16(w), hi = int16((w - lo) >> 16) while |lo|, |hi| < 32768; |GF[t]| <= listed forward reads,
-//                |GR[d]| <= 3 x listed reverse reads (type A: one edge per read and shift, type B: two), and the
-//                rows are flushed before those bounds reach 32767.
+//   GF, GR, EE   signed.  A dword that holds two 16-bit cells is lo + 65536 hi as an integer (the high cell is added to
+//                with value << 16) and is recovered as lo = int16(w), hi = int16((w - lo) >> 16) while |lo|, |hi| < 32768.
+//                !BIG: GF[t] (low) and EE[t] (high) share a row [HN] -- the cells of ONE index, like NC --, GR is [HN] i32.
+//                BIG: GF and GR rows of 16-bit cells, two per dword (cell k: dword k >> 1, half k & 1), no EE.
+//                |GF[t]| <= listed forward reads, |EE[k]| <= listed run edges, |GR[d]| <= 3 x listed reverse reads (type
+//                A: one edge per read and shift, type B: two): the rows are flushed before a 16-bit bound reaches 32767.
 //   DUMP [64]    an event that misses is not predicated away but added to a dump slot, one per lane (LDS atomics of a wave
 //                to ONE address are serialised); every row reaches the slots with a row-relative index.
-// 10 (BIG: 8, without EE) bytes of LDS per shift instead of round 2's 20: max_shift 2047 in the LDS of max_shift 1023,
-// and 8191 shifts + four sub-groups' lists (16 waves per CU) in 145 KB.
+// 12 (BIG: 8, without EE) bytes of LDS per shift instead of round 2's 20: max_shift 2047 in the LDS of max_shift 1023,
+// 8191 shifts + four sub-groups' lists (16 waves per CU) in 145 KB, and -- with the lists' pool at 2416 entries -- 31 KB
+// per workgroup below 1024 shifts: FIVE workgroups per CU at 96 VGPRs (same-box A/B: 0.463 -> 0.429 ms).
 template <bool HAS_M, bool BIG>
 struct EvLds {
     // per sub-group block
@@ -120,8 +131,8 @@ struct EvLds {
     __host__ __device__ static constexpr u32 row_words(u32 hn) { return BIG ? hn / 2 : hn; }
     __host__ __device__ static constexpr u32 o_gf(u32 hn) { return hn; }
     __host__ __device__ static constexpr u32 o_gr(u32 hn) { return o_gf(hn) + (HAS_M ? row_words(hn) : 0u); }
-    __host__ __device__ static constexpr u32 o_ee(u32 hn) { return o_gr(hn) + (HAS_M ? row_words(hn) : 0u); }
-    __host__ __device__ static constexpr u32 o_dump(u32 hn) { return o_ee(hn) + ((HAS_M && !BIG) ? hn : 0u); }
+    __host__ __device__ static constexpr u32 o_ee(u32 hn) { return o_gf(hn); }   // (!BIG: the high halves of the GF row)
+    __host__ __device__ static constexpr u32 o_dump(u32 hn) { return o_gr(hn) + (HAS_M ? row_words(hn) : 0u); }
     __host__ __device__ static constexpr u32 o_xch(u32 hn) { return o_dump(hn) + 64; }    // [0..7] sub-group counts, [8..13] scalars
     __host__ __device__ static constexpr u32 o_sg(u32 hn) { return o_xch(hn) + 16; }
     __host__ __device__ static constexpr u32 total(u32 hn, u32 lo, u32 nsg) { return o_sg(hn) + nsg * sg_words(lo); }
@@ -264,7 +275,7 @@ __device__ __forceinline__ void ev_add_cell(u32 *row, u32 cell, u32 val)
 // NSG sub-groups of 256 threads; BIG: max_shift up to EV_MAX_SHIFT, geometry in the arguments `hn_arg` (entries per
 // histogram row) and `lo_arg` (dwords of M staged below a tile), histograms in dynamic LDS; !BIG: max_shift <= 1023.
 template <bool HAS_M, bool DO_NCC, bool DO_MLEN, u32 NSG, bool BIG, typename JT = SpJobTable>
-__global__ void __launch_bounds__(256 * NSG, (HAS_M || BIG) ? EV_WAVES : EV_WAVES_NCC)
+__global__ void __launch_bounds__(256 * NSG, BIG ? 4 : (HAS_M ? EV_WAVES : EV_WAVES_NCC))
 k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr, u32 max_lag,
             u32 hn_arg, u32 lo_arg, u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags,
             unsigned char *__restrict__ tile_flags_ac, u32 *__restrict__ n_flagged, u32 *__restrict__ jobstat)
@@ -335,7 +346,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
     u32 cntB = 0, cnt0 = 0;                       // per-thread: Bf, R0 of the tiles taken here (|F|, |R|: uniform per tile, added
                                                   // to xch[8], xch[9] in LDS by one thread: no register lives across tiles for them)
     u32 cntM = 0, cntU = 0;                       // DO_MLEN: popcount(M), runs starting in them
-    u32 accF = 0, accR = 0;                       // (uniform) listed forward / reverse reads since the histograms' last flush
+    u32 accF = 0, accR = 0, accE = 0;             // (uniform) listed forward / reverse reads / run edges since the histograms' last flush
     bool seg_written = false;                     // (uniform) this (workgroup, job) segment already holds a flush
 #ifdef EV_STAMPS
     unsigned long long stamp_acc[EV_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -741,8 +752,9 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                     u32 p0 = e0 & EV_POS, p1 = e1 & EV_POS;
                     bool h0 = p0 <= hi, h1 = p1 <= hi;
                     if (__ballot(h0)) do {
-                        atomicAdd(&hEE[h0 ? p0 - pos : dumpEE], (u32)(((int32_t)(e0 ^ ent) >> 31) | 1));   // E[j] E[j + k]
-                        atomicAdd(&hEE[h1 ? p1 - pos : dumpEE], (u32)(((int32_t)(e1 ^ ent) >> 31) | 1));
+                        // E[j] E[j + k] into the HIGH half of cell k of the GF row
+                        atomicAdd(&hEE[h0 ? p0 - pos : dumpEE], (u32)(((int32_t)(e0 ^ ent) >> 31) | 1) << 16);
+                        atomicAdd(&hEE[h1 ? p1 - pos : dumpEE], (u32)(((int32_t)(e1 ^ ent) >> 31) | 1) << 16);
                         e = h1 ? e + 2 : nE;
                         e0 = LE[e];
                         e1 = LE[e + 1];
@@ -762,6 +774,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                 accF += nF;
                 accR += nRt;
             }
+            if (DO_MLEN && do_edges) accE += nE;
         } else {
 #pragma unroll
             for (u32 k = 0; k < NSG; k++) {
@@ -775,7 +788,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         const bool leaving = jn != ji || gnext >= g1;
         // another iteration could overflow a 16-bit cell (bounds in the comment of EvLds): flush now
         const bool risk = HAS_M && (BIG ? (accF + NSG * EV_CAPF > 32767u || 3u * (accR + NSG * EV_CAPR) > 32767u)
-                                        : accF + L::POOL > 65535u);
+                                        : (accF + L::POOL > 32767u || (DO_MLEN && accE + EV_CAPE(BIG) > 32767u)));
         if (NSG == 1 && leaving && tid == 0) {
             // tiles flagged in this job: one atomic per workgroup and job, not per tile (47 k adds to one word serialise in L2
             // when every tile is dense)
@@ -823,18 +836,29 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                     }
                 } else {
 #pragma nounroll
-                    for (u32 i = gt; i < (DO_MLEN ? 3u : 2u) * 1024u; i += NT) {
-                        // LDS rows GF, GR, EE -> segment rows 1, 3, 5
+                    for (u32 i = gt; i < 2u * 1024u; i += NT) {
+                        // LDS rows GF|EE, GR -> segment rows 1 (GF), 5 (EE), 3 (GR)
                         const u32 r = i >> 10, k = i & 1023u;
                         const u32 w = hGF[i];
                         hGF[i] = 0;
+                        u32 v = w;
+                        if (r == 0) {
+                            const int32_t lo16 = (int32_t)(short)(w & 0xffffu);
+                            v = (u32)lo16;
+                            if (DO_MLEN) {
+                                const u32 e = (u32)(int32_t)(short)((w - (u32)lo16) >> 16);
+                                u32 *de = seg + (size_t)5 * 1024 + k;
+                                *de = add ? *de + e : e;
+                            }
+                        }
                         u32 *dst = seg + (size_t)(2 * r + 1) * 1024 + k;
-                        *dst = add ? *dst + w : w;
+                        *dst = add ? *dst + v : v;
                     }
                 }
             }
             accF = 0;
             accR = 0;
+            accE = 0;
             seg_written = true;
             if (leaving) {
                 // scalars: |F|, |R|, Bf, R0, popcount(M), runs -> row 4 of the segment

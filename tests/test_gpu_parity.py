@@ -227,7 +227,8 @@ def test_bits_builders_match_oracle(ctx):
 # ---- the event kernel (sparse tiles) and its hand-over to the window kernel (dense tiles) ----------------------------
 EVENT_TILE = 65536      # kernels_events.h: EV_TB
 EVENT_CAP_E = 1536      # EV_CAPE_SMALL: run edges of everything staged for the tile (max_shift <= 1023)
-EVENT_POOL = 768 + 1000 + EVENT_CAP_E   # EV_POOL_ENTRIES: forward reads + reverse reads (tile + max_shift bits above) + run edges
+EVENT_POOL_M = 2416                     # EV_POOL_SMALL: forward reads + reverse reads (tile + max_shift bits above) + run edges, with a track
+EVENT_POOL_NCC = 768 + 1000 + EVENT_CAP_E   # ... NCC only (EV_POOL_ENTRIES)
 
 
 def _exact_count_bits(rng, nbits, lo, hi, k):
@@ -238,7 +239,7 @@ def _exact_count_bits(rng, nbits, lo, hi, k):
 
 
 @pytest.mark.parametrize("n_edges", [None, 0, 300])
-@pytest.mark.parametrize("n_f,over", [(1200, 0), (1200, 1), (3000, 0), (3000, 1), (40, 0), (40, 1)])
+@pytest.mark.parametrize("n_f,over", [(1200, 0), (1200, 1), (2050, 0), (2050, 1), (40, 0), (40, 1)])
 def test_event_lists_exactly_full_and_one_over(ctx, n_f, over, n_edges):
     """The three lists of a tile share one pool.  Tile 1 of three holds n_f forward reads, n_edges run edges (None: no
     mappability track) and as many reverse reads as fill the pool exactly (stays on the event kernel) or one more
@@ -253,7 +254,7 @@ def test_event_lists_exactly_full_and_one_over(ctx, n_f, over, n_edges):
     for target, clear_hi in ((F, hi), (R, hi + 1024)):
         for wd in range(lo // 64, clear_hi // 64):
             target[wd] = 0
-    n_r = EVENT_POOL - n_f - (n_edges or 0) + over
+    n_r = (EVENT_POOL_NCC if n_edges is None else EVENT_POOL_M) - n_f - (n_edges or 0) + over
     F |= _exact_count_bits(rng, nbits, lo, hi, n_f)
     R |= _exact_count_bits(rng, nbits, lo, hi, n_r)
     M = None
