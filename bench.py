@@ -282,10 +282,11 @@ def main():
     nstep = [0]
 
     # the hint the calculator gives from the read counts it holds (pymasc_amd/calculator.py: window_only_hint)
-    from pymasc_amd.calculator import window_only_hint
+    from pymasc_amd.calculator import window_only_hint, deep_lists_hint
     dense = any(window_only_hint(v.n_forward, v.n_reverse, v.n_runs if with_m else 0, v.length, S) for v in vecs)
-    hinted = dense and args.path == "auto" and not args.no_hint
-    step_flags = flags | (ffi.PMX_FLAG_WINDOW_ONLY if hinted else 0)
+    deep = not dense and any(deep_lists_hint(v.n_forward, v.n_reverse, v.n_runs if with_m else 0, v.length, S) for v in vecs)
+    hinted = (dense or deep) and args.path == "auto" and not args.no_hint
+    step_flags = flags | ((ffi.PMX_FLAG_WINDOW_ONLY if dense else ffi.PMX_FLAG_DEEP_LISTS) if hinted else 0)
 
     def step():
         # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev) on tstream, then the exchange
@@ -571,7 +572,8 @@ def main():
                             "; stands in for ENCFF000VPI.bam (configs 2-3), which is not available offline")),
             "mode": args.mode,
             "kernel_path": args.path,
-            "window_only_hint": bool(hinted),
+            "window_only_hint": bool(hinted and dense),
+            "deep_lists_hint": bool(hinted and deep),
             "run_edges_per_64kbit": (round(2 * 65536 * sum(v.n_runs for v in vecs) / max(sum(v.length for v in vecs), 1), 1)
                                      if with_m and vecs else None),
             "parallelism": f"chromosome jobs of {nsamples} genome(s) LPT-sharded over {world} GPU(s), one process per "

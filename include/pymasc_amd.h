@@ -55,6 +55,10 @@ extern "C" {
                                    * (max_shift <= 1023: ~1.8 % read starts per strand, ~110 M reads on hg38; above 1023: 768 forward /
                                    * 1000 reverse reads / 384 run edges) --: go straight to the window kernels instead of
                                    * letting the event kernel find that out tile by tile.  Same integers either way */
+#define PMX_FLAG_DEEP_LISTS  32u  /* hint: deep data, but not beyond the event kernel (max_shift <= 1023 with a track:
+                                   * between ~1.5 % and ~3.2 % read starts per strand): the instantiation with the larger
+                                   * list pool (4328 entries per 65536 positions, four workgroups per CU instead of
+                                   * five).  Same integers either way */
 #define PMX_FLAG_SKIP_MLEN    8u  /* the caller holds mappable_len already (the *_mappability.json cache,
                                    * handler/mappability.py:239-259): no autocorrelation pass; row 4 and
                                    * scalars[2] are written as zeros */

@@ -42,6 +42,7 @@ _CHUNK = 1 << 16
 EVENT_TILE_BITS = 65536
 EVENT_FORWARD, EVENT_REVERSE, EVENT_EDGES, EVENT_EDGES_BIG = 768, 1000, 1536, 384
 EVENT_POOL, EVENT_POOL_NCC = 2416, 768 + 1000 + 1536      # EV_POOL_SMALL (with a track) / without
+EVENT_POOL_DEEP = 4328                                    # EV_POOL_DEEP: the instantiation PMX_FLAG_DEEP_LISTS selects
 
 
 def window_only_hint(n_forward, n_reverse, n_runs, length, max_shift):
@@ -50,8 +51,17 @@ def window_only_hint(n_forward, n_reverse, n_runs, length, max_shift):
     per_tile = EVENT_TILE_BITS / float(max(length, 1))
     f, r, e = n_forward * per_tile, n_reverse * per_tile, 2.0 * n_runs * per_tile
     if max_shift <= 1023:
-        return e > EVENT_EDGES or f + r + e > (EVENT_POOL if n_runs else EVENT_POOL_NCC)
+        return e > EVENT_EDGES or f + r + e > (EVENT_POOL_DEEP if n_runs else EVENT_POOL_NCC)
     return f > EVENT_FORWARD or r > EVENT_REVERSE or e > EVENT_EDGES_BIG
+
+
+def deep_lists_hint(n_forward, n_reverse, n_runs, length, max_shift):
+    """True when the average tile comes close to the ordinary list pool (max_shift <= 1023, with a track) but stays within the
+    larger one: the caller then asks for the event kernel's DEEP instantiation (PMX_FLAG_DEEP_LISTS)."""
+    if max_shift > 1023 or not n_runs or window_only_hint(n_forward, n_reverse, n_runs, length, max_shift):
+        return False
+    per_tile = EVENT_TILE_BITS / float(max(length, 1))
+    return (n_forward + n_reverse + 2.0 * n_runs) * per_tile > 0.85 * EVENT_POOL
 
 
 class _ReadBuffer:
@@ -375,9 +385,11 @@ class CCHipCalculator:
         # deep data or a track of very short runs: the average tile overflows the event kernel's lists -- say so instead
         # of letting it find out (same integers either way).  The strand split is not known on the host (the device walks
         # the reads): half the reads fed stands for a strand.
-        if window_only_hint(0.5 * self._fed, 0.5 * self._fed, getattr(self, "_n_runs", 0) if d_m is not None else 0, glen,
-                            self.max_shift):
+        counts = (0.5 * self._fed, 0.5 * self._fed, getattr(self, "_n_runs", 0) if d_m is not None else 0, glen, self.max_shift)
+        if window_only_hint(*counts):
             flags |= ffi.PMX_FLAG_WINDOW_ONLY
+        elif deep_lists_hint(*counts):
+            flags |= ffi.PMX_FLAG_DEEP_LISTS     # deep, but within the event kernel's larger list pool
         c = L - 1
         known = self._known_mlen.get(chrom) if d_m is not None else None
         if known is not None and len(known) <= max(c, S - c):      # cache too short for this run: recompute

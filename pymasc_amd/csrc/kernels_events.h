@@ -56,7 +56,10 @@
                                           // 32256 B do not) leave the lists
 #endif
 #define EV_POOL_ENTRIES(HAS_M, BIG) ((BIG) ? EV_CAPF + EV_CAPR + ((HAS_M) ? 384u : 0u) : ((HAS_M) ? EV_POOL_SMALL : EV_CAPF + EV_CAPR + EV_CAPE_SMALL))
-#define EV_RANK_BITS 12u                  // rank field of a forward entry (bits 17..28): index into the reverse list
+#define EV_RANK_BITS 13u                  // rank field of a forward entry (bits 17..29): index into the reverse list
+#ifndef EV_POOL_DEEP
+#define EV_POOL_DEEP 4328u                // the DEEP instantiations (PMX_FLAG_DEEP_LISTS: four workgroups per CU, 39.4 KB): ~3.2 % per strand
+#endif
 #define EV_POS 0x1ffffu                   // 17 bits of biased position (BIG: 16384 + 65536 + 8192 + 1152 staged bits at most)
 #define EV_PAD 12u                        // sentinel entries behind the read lists
 #define EV_RSENT 0x3fffffffu              // reverse-list sentinel: beyond every range, and (sentinel - lo) stays positive as
@@ -114,11 +117,11 @@
 // 12 (BIG: 8, without EE) bytes of LDS per shift instead of round 2's 20: max_shift 2047 in the LDS of max_shift 1023,
 // 8191 shifts + four sub-groups' lists (16 waves per CU) in 145 KB, and -- with the lists' pool at 2416 entries -- 31 KB
 // per workgroup below 1024 shifts: FIVE workgroups per CU at 96 VGPRs (same-box A/B: 0.463 -> 0.429 ms).
-template <bool HAS_M, bool BIG>
+template <bool HAS_M, bool BIG, bool DEEP = false>
 struct EvLds {
     // per sub-group block
     static constexpr u32 LF = 0;                                    // the pool (+EV_PAD behind every list: sentinels; the
-    static constexpr u32 POOL = EV_POOL_ENTRIES(HAS_M, BIG);        // loops read ahead of their entry)
+    static constexpr u32 POOL = DEEP ? EV_POOL_DEEP : EV_POOL_ENTRIES(HAS_M, BIG);   // loops read ahead of their entry)
     static_assert(POOL + 3 * EV_PAD < (1u << EV_RANK_BITS), "rank field of the forward entries");
     static constexpr u32 WT = LF + POOL + 3 * EV_PAD;               // WT: [5][4 waves] scan totals
     static constexpr u32 MISC = WT + 32;
@@ -214,7 +217,7 @@ __device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u3
         ev_fetch<HAS_M, true, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads);
 }
 
-// forward list entry: bits 0..16 biased position, 17..28 index of the first reverse read at or above it, 31 = M[x]
+// forward list entry: bits 0..16 biased position, 17..29 index of the first reverse read at or above it, 31 = M[x]
 __device__ __forceinline__ void ev_emit_f(const uint4 f, const uint4 r, const uint4 m, u32 idx, u32 rank0, u32 base_bit,
                                           u32 *list)
 {
@@ -274,13 +277,17 @@ __device__ __forceinline__ void ev_add_cell(u32 *row, u32 cell, u32 val)
 // E[j] E[j + k] over the edges j of the tile, k = 1..max_lag, and popcount(M) / the runs starting in the tile.
 // NSG sub-groups of 256 threads; BIG: max_shift up to EV_MAX_SHIFT, geometry in the arguments `hn_arg` (entries per
 // histogram row) and `lo_arg` (dwords of M staged below a tile), histograms in dynamic LDS; !BIG: max_shift <= 1023.
-template <bool HAS_M, bool DO_NCC, bool DO_MLEN, u32 NSG, bool BIG, typename JT = SpJobTable>
-__global__ void __launch_bounds__(256 * NSG, BIG ? 4 : (HAS_M ? EV_WAVES : EV_WAVES_NCC))
+// DEEP (max_shift <= 1023 with M only): a pool of EV_POOL_DEEP entries at four workgroups per CU, for callers that know their
+// data is deep (PMX_FLAG_DEEP_LISTS): between ~1.5 % and ~3.2 % read starts per strand the event formulation is still twice
+// as fast as the window kernels, but the five-per-CU instantiation would hand most tiles over.
+template <bool HAS_M, bool DO_NCC, bool DO_MLEN, u32 NSG, bool BIG, typename JT = SpJobTable, bool DEEP = false>
+__global__ void __launch_bounds__(256 * NSG, BIG ? 4 : (HAS_M ? (DEEP ? 4 : EV_WAVES) : EV_WAVES_NCC))
 k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr, u32 max_lag,
             u32 hn_arg, u32 lo_arg, u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags,
             unsigned char *__restrict__ tile_flags_ac, u32 *__restrict__ n_flagged, u32 *__restrict__ jobstat)
 {
-    typedef EvLds<HAS_M, BIG> L;
+    typedef EvLds<HAS_M, BIG, DEEP> L;
+    static_assert(!DEEP || (HAS_M && !BIG), "DEEP: the max_shift <= 1023 instantiations with a track");
     static_assert(BIG || NSG == 1, "the max_shift <= 1023 instantiations are one sub-group per workgroup");
     static_assert(!(BIG && DO_MLEN), "the edge pairs of the mappable-length pass are not fused beyond 1023 lags");
     constexpr u32 NT = 256 * NSG;

@@ -2529,21 +2529,28 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             memset(&tab, 0, sizeof tab);
             // (the next 32 jobs: their own flagged-tile counters and job statistics)
             if (lo) PMX_HIP(hipMemsetAsync(d_nflagged, 0, 16 + 4 * SP_MAXJOBS * sizeof(u32), ctx->stream));
-            plan_launch(ctx, &vjobs[lo], n, false, has_m ? EV_WAVES : EV_WAVES_NCC, &tab, &total, &tpw, &nwg, EV_TB);
+            const bool deep = has_m && ctx->deep_lists;   // PMX_FLAG_DEEP_LISTS: the larger list pool at four workgroups per CU
+            plan_launch(ctx, &vjobs[lo], n, false, has_m ? (deep ? 4 : EV_WAVES) : EV_WAVES_NCC, &tab, &total, &tpw, &nwg, EV_TB);
             rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * EV_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
             if (rc) return rc;
             rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_EVENTS, &tl);
             if (rc) return rc;
             const u32 nhr = (max_shift + 1 + 127) / 128;   // quads of R above a tile that hold partners of its forward reads
-#define EV_LAUNCH(HM, NC, ML)                                                                                          \
-    hipLaunchKernelGGL((k_cc_events<HM, NC, ML, 1, false>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, (u32)c, \
-                       max_shift, nhr, fused_lag, 1024u, (u32)EV_LO, ctx->d_slab, d_flags, d_flags_ac, d_nflagged, d_jobstat)
+#define EV_LAUNCH_(HM, NC, ML, DP)                                                                                     \
+    hipLaunchKernelGGL((k_cc_events<HM, NC, ML, 1, false, SpJobTable, DP>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, \
+                       (u32)c, max_shift, nhr, fused_lag, 1024u, (u32)EV_LO, ctx->d_slab, d_flags, d_flags_ac, d_nflagged, d_jobstat)
+#define EV_LAUNCH(HM, NC, ML)                \
+    do {                                     \
+        if (deep) EV_LAUNCH_(HM, NC, ML, HM); \
+        else EV_LAUNCH_(HM, NC, ML, false);  \
+    } while (0)
             if (has_m && do_ncc && fuse_mlen) EV_LAUNCH(true, true, true);
             else if (has_m && do_ncc) EV_LAUNCH(true, true, false);
             else if (has_m && fuse_mlen) EV_LAUNCH(true, false, true);
             else if (has_m) EV_LAUNCH(true, false, false);
-            else EV_LAUNCH(false, true, false);
+            else EV_LAUNCH_(false, true, false, false);
 #undef EV_LAUNCH
+#undef EV_LAUNCH_
             PMX_CHECK_LAUNCH("k_cc_events");
             rc = pmx_prof_end(ctx, &tl);
             if (rc) return rc;

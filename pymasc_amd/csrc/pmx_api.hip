@@ -71,6 +71,7 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->profiling = 0;
     ctx->window_only = false;
+    ctx->deep_lists = false;
     ctx->debug_max_wg = 0;
     ctx->d_scratch = nullptr;
     ctx->scratch_words = 0;
@@ -1108,6 +1109,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
         // row MLEN and scalar [2] belong to the autocorrelation, everything else to the cross-correlation)
         // PMX_AUTOCORR_FORK=0 in the environment keeps everything on the caller's stream (per-kernel profiling)
         ctx->window_only = (flags & PMX_FLAG_WINDOW_ONLY) != 0;
+        ctx->deep_lists = (flags & PMX_FLAG_DEEP_LISTS) != 0;
         static const bool fork_enabled = [] {
             const char *e = getenv("PMX_AUTOCORR_FORK");
             return !(e && e[0] == '0');

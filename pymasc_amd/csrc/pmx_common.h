@@ -53,6 +53,7 @@ struct pmx_ctx {
     hipEvent_t ev_fork, ev_join;
     int num_cus;
     bool window_only;            // PMX_FLAG_WINDOW_ONLY of the call in progress (pmx_cc_batch_dev)
+    bool deep_lists;             // PMX_FLAG_DEEP_LISTS of the call in progress
     uint32_t debug_max_wg;       // 0: off; tests: cap on the persistent workgroups of a launch (many tiles per workgroup on small inputs)
     int profiling;               // 0 off; 1: kernels that do work; 2: also the (usually empty) fallback launches behind the event kernel
     std::vector<pmx_timed_launch> timed;       // launches not yet folded into the totals

@@ -56,7 +56,7 @@ def test_header_constants_match_binding():
     consts = dict(re.findall(r"#define\s+(PMX_[A-Z_0-9]+)\s+(-?\d+)u?\b", text))
     for name in ("PMX_ROW_NCC_CCBINS", "PMX_ROW_MSCC_FSUM", "PMX_ROW_MSCC_RSUM", "PMX_ROW_MSCC_CCBINS",
                  "PMX_ROW_MLEN", "PMX_ROW_SCALARS", "PMX_NROWS", "PMX_FLAG_SKIP_NCC", "PMX_FLAG_FORCE_DENSE", "PMX_FLAG_SKIP_MLEN",
-                 "PMX_FLAG_FORCE_SPARSE", "PMX_FLAG_WINDOW_ONLY", "PMX_PATH_DENSE", "PMX_PATH_SPARSE", "PMX_KERNEL_CC_DENSE",
+                 "PMX_FLAG_FORCE_SPARSE", "PMX_FLAG_WINDOW_ONLY", "PMX_FLAG_DEEP_LISTS", "PMX_PATH_DENSE", "PMX_PATH_SPARSE", "PMX_KERNEL_CC_DENSE",
                  "PMX_KERNEL_CC_SPARSE", "PMX_KERNEL_AUTOCORR", "PMX_KERNEL_CC_EVENTS"):
         assert int(consts[name]) == getattr(ffi, name), name
 

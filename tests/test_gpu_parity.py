@@ -229,6 +229,7 @@ EVENT_TILE = 65536      # kernels_events.h: EV_TB
 EVENT_CAP_E = 1536      # EV_CAPE_SMALL: run edges of everything staged for the tile (max_shift <= 1023)
 EVENT_POOL_M = 2416                     # EV_POOL_SMALL: forward reads + reverse reads (tile + max_shift bits above) + run edges, with a track
 EVENT_POOL_NCC = 768 + 1000 + EVENT_CAP_E   # ... NCC only (EV_POOL_ENTRIES)
+EVENT_POOL_DEEP = 4328                  # EV_POOL_DEEP: with a track and PMX_FLAG_DEEP_LISTS
 
 
 def _exact_count_bits(rng, nbits, lo, hi, k):
@@ -238,9 +239,10 @@ def _exact_count_bits(rng, nbits, lo, hi, k):
     return w
 
 
+@pytest.mark.parametrize("deep", [False, True])
 @pytest.mark.parametrize("n_edges", [None, 0, 300])
 @pytest.mark.parametrize("n_f,over", [(1200, 0), (1200, 1), (2050, 0), (2050, 1), (40, 0), (40, 1)])
-def test_event_lists_exactly_full_and_one_over(ctx, n_f, over, n_edges):
+def test_event_lists_exactly_full_and_one_over(ctx, n_f, over, n_edges, deep):
     """The three lists of a tile share one pool.  Tile 1 of three holds n_f forward reads, n_edges run edges (None: no
     mappability track) and as many reverse reads as fill the pool exactly (stays on the event kernel) or one more
     (flagged, summed by the window kernel and ADDED to what the event kernel wrote for tiles 0 and 2)."""
@@ -254,7 +256,10 @@ def test_event_lists_exactly_full_and_one_over(ctx, n_f, over, n_edges):
     for target, clear_hi in ((F, hi), (R, hi + 1024)):
         for wd in range(lo // 64, clear_hi // 64):
             target[wd] = 0
-    n_r = (EVENT_POOL_NCC if n_edges is None else EVENT_POOL_M) - n_f - (n_edges or 0) + over
+    if deep and n_edges is None:
+        pytest.skip("PMX_FLAG_DEEP_LISTS selects an instantiation of the kernel with a track only")
+    pool = EVENT_POOL_NCC if n_edges is None else (EVENT_POOL_DEEP if deep else EVENT_POOL_M)
+    n_r = pool - n_f - (n_edges or 0) + over
     F |= _exact_count_bits(rng, nbits, lo, hi, n_f)
     R |= _exact_count_bits(rng, nbits, lo, hi, n_r)
     M = None
@@ -267,7 +272,7 @@ def test_event_lists_exactly_full_and_one_over(ctx, n_f, over, n_edges):
             bits[lo + 50 + 200 * i:lo + 90 + 200 * i] = 0
         M = np.packbits(bits, bitorder="little").view(np.uint64).copy()
     ref = oracle.calc_correlation(F, R, M, nbits, S, L)
-    out = ctx.calc_correlation(F, R, M, nbits, S, L, ffi.PMX_FLAG_FORCE_SPARSE)
+    out = ctx.calc_correlation(F, R, M, nbits, S, L, ffi.PMX_FLAG_FORCE_SPARSE | (ffi.PMX_FLAG_DEEP_LISTS if deep else 0))
     check_block(out, ref, S, M is not None)
 
 
@@ -293,8 +298,8 @@ def test_event_edge_list_around_its_capacity(ctx, n_edges):
     check_block(out, ref, S, True)
 
 
-@pytest.mark.parametrize("skip_ncc", [False, True])
-def test_dense_and_sparse_tiles_in_one_chromosome(ctx, skip_ncc):
+@pytest.mark.parametrize("skip_ncc,deep", [(False, False), (True, False), (False, True)])
+def test_dense_and_sparse_tiles_in_one_chromosome(ctx, skip_ncc, deep):
     """Read density 0.05 in the middle tiles, 0.004 elsewhere; mappability edges dense in another region: both kernels
     contribute to every output row of the same result block."""
     S, L = 1000, 36
@@ -306,7 +311,7 @@ def test_dense_and_sparse_tiles_in_one_chromosome(ctx, skip_ncc):
     R |= synth.random_bits(rng, nbits, 0.05, 3 * EVENT_TILE - 5000, 4 * EVENT_TILE)
     M = synth.run_bits(rng, nbits, 2500, 700, 1, 4 * EVENT_TILE)
     M |= synth.run_bits(rng, nbits, 30, 20, 4 * EVENT_TILE + 100, 5 * EVENT_TILE)
-    flags = ffi.PMX_FLAG_FORCE_SPARSE | (ffi.PMX_FLAG_SKIP_NCC if skip_ncc else 0)
+    flags = ffi.PMX_FLAG_FORCE_SPARSE | (ffi.PMX_FLAG_SKIP_NCC if skip_ncc else 0) | (ffi.PMX_FLAG_DEEP_LISTS if deep else 0)
     ref = oracle.calc_correlation(F, R, M, nbits, S, L)
     out = ctx.calc_correlation(F, R, M, nbits, S, L, flags)
     check_block(out, ref, S, True, skip_ncc=skip_ncc)

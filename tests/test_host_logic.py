@@ -311,15 +311,20 @@ def test_dense_data_hint_from_the_counts_the_calculator_holds():
             self.flags.append(int(flags))
             return super().cc_dev(d_F, d_R, d_M, nbits, max_shift, read_len, flags, d_out)
 
-    names, lens = ["sparse", "deep", "shortruns"], [6000, 6000, 6000]
+    names, lens = ["sparse", "deep", "deeper", "shortruns"], [6000, 6000, 6000, 6000]
     rng = np.random.default_rng(5)
-    tracks = {"sparse": [(100, 5000, 1.0)], "deep": [(100, 5000, 1.0)],
+    tracks = {"sparse": [(100, 5000, 1.0)], "deep": [(100, 5000, 1.0)], "deeper": [(100, 5000, 1.0)],
               "shortruns": [(b, b + 20, 1.0) for b in range(100, 5900, 50)]}           # 116 runs / 6000 bp: 2500 edges per 64 Kbit
     assert not C.window_only_hint(30, 30, 1, 6000, 100) and C.window_only_hint(30, 30, 116, 6000, 100)
     assert not C.window_only_hint(300, 300, 0, 65536, 100) and C.window_only_hint(1700, 1700, 0, 65536, 100)
+    # with a track: the ordinary pool (2416 entries per 64 Kbit) -> the DEEP instantiation (4328) -> the window kernels
+    assert not C.deep_lists_hint(900, 900, 30, 65536, 100) and C.deep_lists_hint(1100, 1100, 30, 65536, 100)
+    assert C.deep_lists_hint(2000, 2000, 30, 65536, 100) and not C.window_only_hint(2000, 2000, 30, 65536, 100)
+    assert C.window_only_hint(2200, 2200, 30, 65536, 100) and not C.deep_lists_hint(2200, 2200, 30, 65536, 100)
+    assert not C.deep_lists_hint(1100, 1100, 0, 65536, 100) and not C.deep_lists_hint(1100, 1100, 30, 65536, 5000)
     assert C.window_only_hint(800, 300, 0, 65536, 5000) and C.window_only_hint(30, 30, 200, 65536, 5000)   # fixed shares above 1023
     reads = []
-    for chrom, n in (("sparse", 30), ("deep", 170), ("shortruns", 30)):    # 170 reads per strand / 6000 bp: 3700 reads per tile
+    for chrom, n in (("sparse", 30), ("deep", 170), ("deeper", 240), ("shortruns", 30)):    # 170 / 240 reads per strand / 6000 bp: 3700 / 5200 per tile
         pos = np.sort(rng.choice(np.arange(1, 5900), size=n, replace=False))
         reads += [(False, chrom, int(p), 36) for p in pos]
         reads += [(True, chrom, int(p), 36) for p in pos]
@@ -332,5 +337,5 @@ def test_dense_data_hint_from_the_counts_the_calculator_holds():
     calc.finishup_calculation()
     ocalc.finishup_calculation()
     assert_matches_oracle(calc, ocalc, names)
-    hinted = [bool(f & ffi.PMX_FLAG_WINDOW_ONLY) for f in ctx.flags]
-    assert hinted == [False, True, True]
+    assert [bool(f & ffi.PMX_FLAG_WINDOW_ONLY) for f in ctx.flags] == [False, False, True, True]
+    assert [bool(f & ffi.PMX_FLAG_DEEP_LISTS) for f in ctx.flags] == [False, True, False, False]

@@ -134,7 +134,7 @@ def main():
                                              full_range=full)
             skip_ncc = with_m and rng.random() < 0.2
             ref = oracle.calc_correlation(F, R, M, nbits, S, L, skip_ncc=skip_ncc)
-            for flags in (0, ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE):
+            for flags in (0, ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE, ffi.PMX_FLAG_DEEP_LISTS):
                 if flags == ffi.PMX_FLAG_FORCE_DENSE and (S + 1) * nbits > 3e8:
                     continue
                 if flags == ffi.PMX_FLAG_FORCE_SPARSE and L > 1024:
