@@ -2443,6 +2443,17 @@ int pmx_events_take_big(uint32_t max_shift)
     return max_shift > 1023 && max_shift <= EV_MAX_SHIFT && events_enabled() && events_big_enabled();
 }
 
+// The sub-group count the BIG launch of this shift range will use (0: none).  With ONE sub-group per workgroup (max_shift <=
+// 2047: 35 KB of LDS, four workgroups per CU) a CU has LDS to spare and the mappable-length pair pass runs beside the event
+// kernel on the auxiliary stream (hg38, -d 1024: 0.74 -> 0.68 ms; -d 2047: 0.85 -> 0.80); with 2 or 4 sub-groups it loses.
+int pmx_events_big_subgroups(uint32_t max_shift, int has_m)
+{
+    if (!pmx_events_take_big(max_shift)) return 0;
+    EvBigPlan pl;
+    if (!(has_m ? ev_big_plan<true>(max_shift, &pl) : ev_big_plan<false>(max_shift, &pl))) return 0;
+    return (int)pl.nsg;
+}
+
 int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
                                uint32_t read_len, bool do_ncc, uint32_t out_stride, bool zero_mlen,
                                uint32_t fused_lag, pmx_fused_mlen *fused)

@@ -1120,7 +1120,8 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             const char *e = getenv("PMX_AUTOCORR_FORK_BIG");
             return e && e[0] == '1';
         }();
-        const bool fork = fork_enabled && (max_shift <= 1023 || (fork_big && pmx_events_take_big(max_shift) && !ctx->window_only));
+        const bool fork = fork_enabled && (max_shift <= 1023 || (pmx_events_take_big(max_shift) && !ctx->window_only &&
+                                                                 (fork_big || pmx_events_big_subgroups(max_shift, has_m ? 1 : 0) == 1)));
         int rc;
         if (do_mlen && !ctx->window_only && pmx_events_can_fuse_mlen(max_shift, max_lag)) {
             // the event kernel stages M and lists its run edges anyway: it takes the edge pairs of the mappable-length pass

@@ -156,6 +156,7 @@ int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len);
 int pmx_events_can_fuse_mlen(uint32_t max_shift, uint32_t max_lag);
 // the event kernel (not the window kernel in shift chunks) takes this max_shift > 1023
 int pmx_events_take_big(uint32_t max_shift);
+int pmx_events_big_subgroups(uint32_t max_shift, int has_m);
 uint32_t pmx_sparse_max_jobs(void);
 uint32_t pmx_cc_batch_jobs(uint32_t max_shift);   // jobs per call of pmx_launch_cc_sparse_batch (device-side job tables beyond 1023 shifts)
 uint32_t pmx_autocorr_batch_jobs(void);           // ... of pmx_launch_autocorr_edges_batch
