@@ -2290,6 +2290,23 @@ static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p)
     return best_waves != 0;
 }
 
+// resident workgroups per CU of a max_shift <= 1023 instantiation on this device, at most `built_for` (asked once per instantiation)
+template <bool HAS_M, bool DO_NCC, bool DO_MLEN, bool DEEP>
+static u32 ev_resident_per_cu(u32 built_for)
+{
+    static int cached = -1;
+    if (cached < 0) {
+        int n = 0;
+        auto kern = k_cc_events<HAS_M, DO_NCC, DO_MLEN, 1, false, SpJobTable, DEEP>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(kern), 256, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = (int)built_for;
+        }
+        cached = n;
+    }
+    return (u32)cached < built_for ? (u32)cached : built_for;
+}
+
 template <bool HAS_M, bool DO_NCC, u32 NSG>
 static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTableRef &tab, u32 n, u32 total, u32 tpw, u32 nwg, u32 c,
                          u32 max_shift, u32 nhr, unsigned char *d_flags, u32 *d_nflagged, u32 *d_jobstat)
@@ -2541,7 +2558,19 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             // (the next 32 jobs: their own flagged-tile counters and job statistics)
             if (lo) PMX_HIP(hipMemsetAsync(d_nflagged, 0, 16 + 4 * SP_MAXJOBS * sizeof(u32), ctx->stream));
             const bool deep = has_m && ctx->deep_lists;   // PMX_FLAG_DEEP_LISTS: the larger list pool at four workgroups per CU
-            plan_launch(ctx, &vjobs[lo], n, false, has_m ? (deep ? 4 : EV_WAVES) : EV_WAVES_NCC, &tab, &total, &tpw, &nwg, EV_TB);
+            // workgroups per CU: what the instantiation was built for (5 / 4 / 8), or fewer if this device takes fewer (the
+            // grid is one round of resident workgroups: a sixth that does not fit would run as a tail behind the others)
+            u32 per_cu = has_m ? (deep ? 4 : EV_WAVES) : EV_WAVES_NCC;
+            {
+#define EV_OCC(HM, NC, ML, DP) ev_resident_per_cu<HM, NC, ML, DP>(per_cu)
+                if (has_m && do_ncc && fuse_mlen) per_cu = deep ? EV_OCC(true, true, true, true) : EV_OCC(true, true, true, false);
+                else if (has_m && do_ncc) per_cu = deep ? EV_OCC(true, true, false, true) : EV_OCC(true, true, false, false);
+                else if (has_m && fuse_mlen) per_cu = deep ? EV_OCC(true, false, true, true) : EV_OCC(true, false, true, false);
+                else if (has_m) per_cu = deep ? EV_OCC(true, false, false, true) : EV_OCC(true, false, false, false);
+                else per_cu = EV_OCC(false, true, false, false);
+#undef EV_OCC
+            }
+            plan_launch(ctx, &vjobs[lo], n, false, per_cu, &tab, &total, &tpw, &nwg, EV_TB);
             rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * EV_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
             if (rc) return rc;
             rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_EVENTS, &tl);
