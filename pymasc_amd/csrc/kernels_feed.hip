@@ -71,7 +71,10 @@ __global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, 
 {
     const int64_t prev_last = base ? (int64_t)state[PMX_FEED_LAST_POS] : 0;            // _last_pos (0 at a chromosome's start)
     const int64_t prev_fwd = (int64_t)state[PMX_FEED_LAST_FORWARD_POS];                 // _last_forward_pos (0 likewise)
-    const int64_t maxlen = (int64_t)state[PMX_FEED_MAX_REVERSE_LEN];
+    // (one length for every read of the run: no k_feed_maxlen launch, the bound is that length or an earlier run's;
+    // k_feed_finish records it for the runs that follow)
+    int64_t maxlen = (int64_t)state[PMX_FEED_MAX_REVERSE_LEN];
+    if (!rlen && ulen > maxlen) maxlen = ulen;
     const bool packed = rev == nullptr;
     u64 fsum = 0, rsum = 0, nf = 0, nr = 0, maxf = 0, e_sort = 0, e_range = 0;
     bool any_f = false;
@@ -173,6 +176,7 @@ __global__ void __launch_bounds__(256) k_feed_finish(const PT *__restrict__ pos,
         if (cf) state[PMX_FEED_LAST_FORWARD_POS] = cf - 1;
         state[PMX_FEED_CHUNK_FORWARD_POS] = 0;
         state[PMX_FEED_READS] += n;
+        if (!rlen && ulen > 0 && (u64)ulen > state[PMX_FEED_MAX_REVERSE_LEN]) state[PMX_FEED_MAX_REVERSE_LEN] = (u64)ulen;
     }
 }
 
@@ -236,8 +240,10 @@ static int launch_feed(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbit
                        int64_t ulen, const unsigned char *d_rev, uint64_t n, uint64_t base, u64 *d_state)
 {
     const int g = feed_grid(ctx, n, 1024, 4);   // (every block ends in a few atomics on the state words)
-    hipLaunchKernelGGL(k_feed_maxlen<LT>, dim3(g), dim3(256), 0, ctx->stream, (const LT *)d_len, ulen, d_rev, n, d_state);
-    PMX_CHECK_LAUNCH("k_feed_maxlen");
+    if (d_len) {   // (a run of one read length carries its bound in `ulen`)
+        hipLaunchKernelGGL(k_feed_maxlen<LT>, dim3(g), dim3(256), 0, ctx->stream, (const LT *)d_len, ulen, d_rev, n, d_state);
+        PMX_CHECK_LAUNCH("k_feed_maxlen");
+    }
     hipLaunchKernelGGL((k_feed_reads<PT, LT>), dim3(g), dim3(256), 0, ctx->stream, (const PT *)d_pos, (const LT *)d_len, ulen, d_rev, n,
                        base, nbits, (u64 *)d_F, (const u64 *)d_R, d_state);
     PMX_CHECK_LAUNCH("k_feed_reads");
