@@ -471,7 +471,17 @@ class CCHipCalculator:
         hi = max(p.slot for p in pending) + 1
         raw = self._ctx.bits_download(self._arena, hi * self._slot_words * 64)     # synchronises
         self._free_slots.extend(p.slot for p in pending)
-        self._ctx.bits_clear(self._arena, hi * self._slot_words * 64)      # one clear for every slot handed out again
+        # cleared before they are handed out again -- ONLY the slots fetched: a chromosome that is in the middle of its bulk
+        # feed may hold a recycled slot below `hi`, and its feed state (read-length sums, last forward position, look-back
+        # bound, first-error words) lives there.  Runs of neighbouring slots share a clear (normally one for everything).
+        fetched = sorted(p.slot for p in pending)
+        run0 = prev = fetched[0]
+        for s in fetched[1:] + [None]:
+            if s is not None and s == prev + 1:
+                prev = s
+                continue
+            self._ctx.bits_clear(self._slot_ptr(run0), (prev - run0 + 1) * self._slot_words * 64)
+            run0 = prev = s
         self._inflight = []
         for p in pending:                            # (the synchronising copy above is behind every kernel that read them)
             for ptr, cap in p.vecs:

@@ -339,3 +339,41 @@ def test_dense_data_hint_from_the_counts_the_calculator_holds():
     assert_matches_oracle(calc, ocalc, names)
     assert [bool(f & ffi.PMX_FLAG_WINDOW_ONLY) for f in ctx.flags] == [False, False, True, True]
     assert [bool(f & ffi.PMX_FLAG_DEEP_LISTS) for f in ctx.flags] == [False, True, False, False]
+
+
+def test_fetching_results_between_two_bulk_chunks_keeps_the_feed_state_of_the_chromosome_being_fed():
+    """A chromosome in the middle of its bulk feed may hold a RECYCLED arena slot below slots that are being fetched: the
+    fetch must clear only the slots it returns (round-3 advisor finding: it cleared the whole arena prefix, and the read-
+    length sums / duplicate rule / look-back bound of the chromosome being fed were lost without an error)."""
+    rng = np.random.default_rng(11)
+    names, lens = ["a", "b", "c"], [20000, 15000, 12000]
+    chunks = {}
+    for chrom, glen in zip(names, lens):
+        pos = np.sort(rng.integers(1, glen, size=600)).astype(np.int64)
+        pos[300] = pos[299]                       # a duplicate position across the chunk boundary
+        rev = rng.random(600) < 0.5
+        rev[299] = rev[300] = False               # ... both forward: the second is a duplicate (mscc.pyx:388-392)
+        rl = rng.integers(30, 60, size=600)       # mixed read lengths: the reverse look-back bound matters
+        chunks[chrom] = (pos, rl, rev)
+    one = CCHipCalculator(60, 36, names, lens, context=FakeContext())
+    for chrom in names:
+        pos, rl, rev = chunks[chrom]
+        for p, l, r in zip(pos.tolist(), rl.tolist(), rev.tolist()):
+            (one.feed_reverse_read if r else one.feed_forward_read)(chrom, p, l)
+    one.finishup_calculation()
+
+    two = CCHipCalculator(60, 36, names, lens, context=FakeContext())
+    prev = None
+    for chrom in names:
+        pos, rl, rev = chunks[chrom]
+        two.feed_reads(chrom, pos[:300], rl[:300], rev[:300])
+        if prev is not None:
+            two.get_result(prev)                  # fetch the finished chromosome: its slot is recycled by the next one
+        two.feed_reads(chrom, pos[300:], rl[300:], rev[300:])
+        prev = chrom
+    two.finishup_calculation()
+    for c in names:
+        a, b = one.get_result(c).chrom, two.get_result(c).chrom
+        assert list(a.ccbins) == list(b.ccbins) and (a.forward_sum, a.reverse_sum) == (b.forward_sum, b.reverse_sum)
+        assert (a.forward_read_len_sum, a.reverse_read_len_sum) == (b.forward_read_len_sum, b.reverse_read_len_sum), c
+    assert (one.forward_read_len_sum, one.reverse_read_len_sum) == (two.forward_read_len_sum, two.reverse_read_len_sum)
