@@ -64,6 +64,8 @@
 #define EV_PAD 12u                        // sentinel entries behind the read lists
 #define EV_RSENT 0x3fffffffu              // reverse-list sentinel: beyond every range, and (sentinel - lo) stays positive as
                                           // an int32 for range starts lo >= -1023 (an edge below the tile minus read_len - 1)
+#define EV_JOBSUM(jobstat) (reinterpret_cast<unsigned long long *>((jobstat) + 4 * SP_MAXJOBS))   // [6 per job] behind the statistics words (max_shift <= 1023)
+#define EV_STAT_BYTES (4 * SP_MAXJOBS * sizeof(u32) + 6 * SP_MAXJOBS * sizeof(unsigned long long))
 #define EV_SEG_ROWS 6u                    // slab segment rows of `rowlen` u32: ncc, GF, cc, GR, scalars, EE
 #define EV_MAX_SHIFT 8191u                // largest max_shift of the event formulation (BIG instantiations)
 // s_setprio per phase (as in k_cc_sparse): with equal priorities the SIMD arbitrates by age and the co-resident workgroups
@@ -881,7 +883,11 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
 
                 __syncthreads();
                 if (gt < 6) {
-                    seg[4 * HN + gt] = xch[8 + gt];
+                    const u32 v = xch[8 + gt];
+                    seg[4 * HN + gt] = v;
+                    // max_shift <= 1023: the chromosome's totals are added up here (k_events_finish reads six words per job
+                    // instead of six words per segment)
+                    if (!BIG && v) atomicAdd(EV_JOBSUM(jobstat) + 6 * ji + gt, (unsigned long long)v);
                     xch[8 + gt] = 0;
                 }
                 cntB = 0;
@@ -912,6 +918,170 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
 #endif
 }
 
+// ---- k_events_finish: everything between the event kernel and the (normally empty) window launches, in ONE launch ----
+// Round 4.  Until round 3 the step behind k_cc_events was k_reduce_segments2 (16 us), k_plan_flagged (6 us), two window
+// launches that return at once (2 x 6 us), k_events_tail (8 us) and a memset in front (5 us): 0.057 ms of a 0.49-ms step,
+// and as much as a rank's whole share of the kernel at 8 GPUs.  (Folding the sums into the event kernel's epilogue -- the
+// last workgroup of a chromosome -- was priced and not built: ONE workgroup reads another CU's fresh data at 40-70 GB/s,
+// chromosome 1's 103 segments of 24 KB would take 35-60 us at the end of the kernel, where every workgroup finishes at the
+// same time; a launch of its own spreads the same bytes over 150 workgroups of 1024 threads.)
+// grid (EVF_TASKS, njobs + 1), 1024 threads; block (task, job):
+//   task 0  scalar row: |F|, |R|, path marker, zero fill (popcount(M) belongs to task 5 / to a separate pass)
+//   task 1  ncc           row 0 of the segments, summed over the workgroups of the chromosome
+//   task 2  mscc.ccbins   row 2
+//   task 3  mscc.fsum     Bf - inclusive prefix of the signed sums of row 1 (GF)
+//   task 4  mscc.rsum     R0 + inclusive prefix of the signed sums of row 3 (GR)
+//   task 5  mappable_len  (fused pass) EE = row 5, popcount(M), runs -> the recurrence of k_autocorr_finish -> row MLEN and
+//                         scalar [2]; P / N / scalars are also left in the job's scratch, where the slow path of k_events_tail
+//                         (tiles flagged for the autocorrelation window kernel) adds to them and redoes the recurrence
+//   rows the batch does not produce are written as zeros by the block of their task.
+// row njobs of the grid: block 0 / 1 plan the two window launches (k_plan_flagged's work: returns at once when nothing
+// was flagged); the other blocks clear the OTHER flag area of the context for the next call (see ev_flag_area).
+#define EVF_TASKS 6u
+struct EvFinishArgs {
+    const u32 *slab;
+    const unsigned long long *jobsum;   // [6 per job] |F|, |R|, Bf, R0, popcount(M), runs: added up by k_cc_events (EV_JOBSUM)
+    u32 S, out_stride, has_m, do_ncc, fused_mlen, zero_mlen, keep_scalar2, max_lag, lagcap;
+    int32_t c;
+    uint4 *zero_area;     // the other flag area (16-byte units), cleared for the next call
+    u32 zero_quads;
+};
+
+__device__ __forceinline__ void evf_zero_row(u64 *dst, u32 n, u32 tid)
+{
+    for (u32 k = tid; k < n; k += 1024) dst[k] = 0;
+}
+
+// sum over the workgroups [w0, w1] of row `row` of their segments for this job, columns 4 t4 .. 4 t4 + 3 (four groups of 256
+// threads take every fourth segment with 16-byte loads, SIXTEEN in flight per thread: a block that reads another CU's fresh
+// data is bound by round trips, chromosome 1 has 103 segments), combined in `acc[1024]` (LDS, zeroed here)
+template <bool SIGNED>
+__device__ __forceinline__ void evf_sum_row(const u32 *__restrict__ slab, u32 job, u32 w0, u32 w1, u32 row, unsigned long long *acc,
+                                            u32 tid)
+{
+    acc[tid] = 0;
+    const u32 g = tid >> 8, t4 = tid & 255u;
+    const size_t stride = (size_t)EV_SEG_ROWS * 1024;
+    const u32 *p = slab + (size_t)job * stride + (size_t)row * 1024 + 4 * t4;
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (u32 wb = w0 + g; wb <= w1; wb += 64) {
+        uint4 v[16];
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) {
+            const u32 w = wb + 4 * k;
+            v[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(w <= w1 ? w : w1) * stride);   // (clamped: no branch between the loads)
+        }
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) {
+            const bool in = wb + 4 * k <= w1;
+            if (SIGNED) {
+                s0 += in ? (unsigned long long)(long long)(int32_t)v[k].x : 0ull;
+                s1 += in ? (unsigned long long)(long long)(int32_t)v[k].y : 0ull;
+                s2 += in ? (unsigned long long)(long long)(int32_t)v[k].z : 0ull;
+                s3 += in ? (unsigned long long)(long long)(int32_t)v[k].w : 0ull;
+            } else {
+                s0 += in ? v[k].x : 0u;
+                s1 += in ? v[k].y : 0u;
+                s2 += in ? v[k].z : 0u;
+                s3 += in ? v[k].w : 0u;
+            }
+        }
+    }
+    __syncthreads();
+    atomicAdd(&acc[4 * t4 + 0], s0);
+    atomicAdd(&acc[4 * t4 + 1], s1);
+    atomicAdd(&acc[4 * t4 + 2], s2);
+    atomicAdd(&acc[4 * t4 + 3], s3);
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024)
+k_events_finish(const SpJobTable jobs, u32 njobs, const EvFinishArgs a, const PlanLaunch pcc, const PlanLaunch pac)
+{
+    __shared__ unsigned long long acc[1024];
+    __shared__ long long part[256];
+    __shared__ unsigned long long sc[8];
+    const u32 tid = threadIdx.x, task = blockIdx.x, job = blockIdx.y;
+    if (job == njobs) {
+        if (task == 0) plan_flagged(pcc);
+        else if (task == 1) plan_flagged(pac);
+        else
+            for (u32 i = (task - 2) * 1024 + tid; i < a.zero_quads; i += (EVF_TASKS - 2) * 1024) a.zero_area[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const SpJobDev &jb = jobs.j[job];
+    const u32 w0 = jb.wg_first, w1 = jb.wg_last, S = a.S, n = S + 1;
+    u64 *const out = jb.out;
+    const size_t os = a.out_stride;
+    if (tid < 6) sc[tid] = a.jobsum[6 * job + tid];   // |F|, |R|, Bf, R0, popcount(M), runs of the chromosome (k_cc_events)
+    __syncthreads();
+    if (task == 0) {
+        u64 *dst = out + (size_t)PMX_ROW_SCALARS * os;
+        for (u32 k = tid; k < a.out_stride; k += 1024) {
+            if (k == 2 && (a.keep_scalar2 || a.fused_mlen)) continue;   // (popcount(M): task 5 / the autocorrelation pass)
+            dst[k] = k < 2 ? sc[k] : (k == 3 ? (u64)PMX_PATH_SPARSE : 0ull);
+        }
+        return;
+    }
+    if (task == 1 || task == 2) {
+        const u32 dst_row = task == 1 ? PMX_ROW_NCC_CCBINS : PMX_ROW_MSCC_CCBINS;
+        u64 *dst = out + (size_t)dst_row * os;
+        if (task == 1 ? !a.do_ncc : !a.has_m) {
+            evf_zero_row(dst, a.out_stride, tid);
+            return;
+        }
+        evf_sum_row<false>(a.slab, job, w0, w1, task == 1 ? 0u : 2u, acc, tid);
+        if (tid < n) dst[tid] = acc[tid];
+        return;
+    }
+    if (task == 3 || task == 4) {
+        u64 *dst = out + (size_t)(task == 3 ? PMX_ROW_MSCC_FSUM : PMX_ROW_MSCC_RSUM) * os;
+        if (!a.has_m) {
+            evf_zero_row(dst, a.out_stride, tid);
+            return;
+        }
+        evf_sum_row<true>(a.slab, job, w0, w1, task == 3 ? 1u : 3u, acc, tid);
+        const long long x = (long long)acc[tid];
+        const long long incl = block_exclusive_offset(x, part, tid) + x;
+        if (tid < n) dst[tid] = (u64)(task == 3 ? (long long)sc[2] - incl : (long long)sc[3] + incl);
+        return;
+    }
+    // task 5: the mappable-length row
+    u64 *dst = out + (size_t)PMX_ROW_MLEN * os;
+    if (!a.fused_mlen) {
+        if (!a.has_m || a.zero_mlen) evf_zero_row(dst, a.out_stride, tid);   // (else: a pass of its own writes the row)
+        return;
+    }
+    evf_sum_row<true>(a.slab, job, w0, w1, 5u, acc, tid);
+    const long long a0 = (long long)sc[4], runs = (long long)sc[5];
+    const long long ee = (long long)acc[tid];
+    {
+        // what k_autocorr_pairs + k_reduce_pairs leave in the job's scratch: P = EE (signed), N = 0, popcount(M), runs
+        u64 *P = jb.out2, *N = jb.out2 + a.lagcap, *scal = jb.out2 + 2 * (size_t)a.lagcap;
+        if (tid <= a.max_lag) {
+            P[tid] = (u64)ee;
+            N[tid] = 0;
+        }
+        if (tid == 0) {
+            scal[0] = (u64)a0;
+            scal[1] = (u64)runs;
+        }
+    }
+    // A(k+1) = 2 A(k) - A(k-1) - EE(k): Delta(k) = inclusive prefix of x, x(0) = -runs, x(k) = -EE(k); A(k) = a0 + exclusive
+    // prefix of Delta (autocorr_finish_job)
+    const long long x = tid == 0 ? -runs : (tid <= a.max_lag ? -ee : 0ll);
+    const long long delta = block_exclusive_offset(x, part, tid) + x;
+    const long long A = a0 + block_exclusive_offset(delta, part, tid);
+    __syncthreads();
+    acc[tid] = (unsigned long long)A;
+    __syncthreads();
+    if (tid == 0) out[(size_t)PMX_ROW_SCALARS * os + 2] = (u64)a0;
+    if (tid < n) {
+        const int32_t k = a.c - (int32_t)tid;
+        dst[tid] = acc[k < 0 ? -k : k];
+    }
+}
+
 // The tail of the event pass, ONE launch per batch (grid: jobs x 4; y = 1 only with the mappable-length fusion, y = 2, 3 take
 // the ncc / cc rows of the slow path and return at once when nothing was flagged):
 //   y = 0: fsum[d] = Bf - sum_{t<=d} GF[t], rsum[d] = R0 + sum_{t<=d} GR[t] (k_reduce_segments left the signed sums of GF /
@@ -933,7 +1103,7 @@ __global__ void __launch_bounds__(EV_TAIL_THREADS)
 k_events_tail(const u32 *__restrict__ slab, const JT jobs, const EvTailPlan plan, const u32 *__restrict__ slab_cc,
               const u32 *__restrict__ slab_ac, const u32 *__restrict__ n_flagged, u32 S, u32 out_stride, u32 has_m, u32 do_ncc,
               u32 max_lag, u32 lagcap, int32_t c, u32 fused, u32 rowlen, u32 slow_path, const u32 *__restrict__ plan_cc,
-              const u32 *__restrict__ plan_ac)
+              const u32 *__restrict__ plan_ac, u32 prefix_done)
 {
     __shared__ long long part[256];
     __shared__ long long tot[2];
@@ -943,6 +1113,9 @@ k_events_tail(const u32 *__restrict__ slab, const JT jobs, const EvTailPlan plan
     // (slow_path == 0: max_shift > 1023, the window kernel runs in shift chunks behind this kernel and a gated reduce adds its sums)
     const bool flagged = slow_path && n_flagged[blockIdx.y == 1 ? 1 : 0] != 0;   // [0]: tiles flagged for k_cc_sparse, [1]: for k_autocorr_edges
     if ((blockIdx.y >= 2 && !flagged) || (blockIdx.y == 1 && !fused)) return;
+    // prefix_done (max_shift <= 1023, round 4): k_events_finish has taken the prefix sums and the recurrence already; only the
+    // additions of the window kernels' sums remain here, and the whole launch returns at once when nothing was flagged
+    if (prefix_done && !flagged) return;
     if (blockIdx.y == 1) {
         if (flagged) {
             u64 *P = jb.out2, *N = jb.out2 + lagcap, *scal = jb.out2 + 2 * (size_t)lagcap;
@@ -977,7 +1150,7 @@ k_events_tail(const u32 *__restrict__ slab, const JT jobs, const EvTailPlan plan
         autocorr_finish_job(jb, part, max_lag, lagcap, 1u, c, S, out_stride, EV_TAIL_THREADS);
         return;
     }
-    if (has_m && blockIdx.y == 0) {
+    if (has_m && blockIdx.y == 0 && !prefix_done) {
         long long bf = 0, r0 = 0;
         for (u32 w = jb.wg_first + tid; w <= jb.wg_last; w += EV_TAIL_THREADS) {
             const u32 *sc = slab + ((size_t)(w + job) * EV_SEG_ROWS + 4) * rowlen;

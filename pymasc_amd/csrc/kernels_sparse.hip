@@ -2394,6 +2394,7 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
     u32 *d_nflagged = (u32 *)(ctx->d_flags_cc + flag_bytes);
     u32 *d_jobstat = d_nflagged + 4;     // per job: tiles seen / read-dense / edge-dense (k_cc_events, one sub-group)
     PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, flag_bytes + 16 + stat_bytes, ctx->stream));
+    ctx->flags_cc_zeroed[0] = ctx->flags_cc_zeroed[1] = ctx->flags_cc_dirty[0] = ctx->flags_cc_dirty[1] = 0;   // (see ev_flag_area)
 
     ReduceSpec rs_ev = rs;
     for (u32 i = 0; i < nr; i++)
@@ -2439,7 +2440,7 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
             memset(&tp, 0, sizeof tp);
             hipLaunchKernelGGL(k_events_tail<SpJobTableRef>, dim3(n, 1), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab,
                                ref, tp, (const u32 *)nullptr, (const u32 *)nullptr, (const u32 *)d_nflagged, max_shift, out_stride, 1u,
-                               do_ncc ? 1u : 0u, 0u, 1024u, (int32_t)c, 0u, pl.hn, 0u, (const u32 *)nullptr, (const u32 *)nullptr);
+                               do_ncc ? 1u : 0u, 0u, 1024u, (int32_t)c, 0u, pl.hn, 0u, (const u32 *)nullptr, (const u32 *)nullptr, 0u);
             PMX_CHECK_LAUNCH("k_events_tail");
         }
     }
@@ -2469,6 +2470,38 @@ int pmx_events_big_subgroups(uint32_t max_shift, int has_m)
     EvBigPlan pl;
     if (!(has_m ? ev_big_plan<true>(max_shift, &pl) : ev_big_plan<false>(max_shift, &pl))) return 0;
     return (int)pl.nsg;
+}
+
+// The dense-tile flags, the flagged-tile counters and the job statistics of the event pass must be ZERO when k_cc_events
+// starts.  Until round 3 a memset in front of every pass did that (5 us of stream time per step); now the context keeps TWO
+// areas and uses them in turn: the pass in area A has its k_events_finish launch clear what the previous pass dirtied in area B
+// (nothing of the running pass touches B), so a pass finds its area clean without a launch of its own.  zeroed[]: prefix of
+// an idle area known to be zero; dirty[]: prefix a pass has used and nobody has cleared yet (cleared here if the pass that
+// should have done it never launched its k_events_finish: an error exit).
+static int ev_flag_area(pmx_ctx *ctx, size_t area_bytes, size_t zero_bytes, unsigned char **cur, unsigned char **other,
+                        size_t *other_dirty)
+{
+    const size_t half = (area_bytes + 255) & ~(size_t)255;
+    const size_t before = ctx->flags_cc_bytes;
+    int rc = pmx_ensure_flags_cc(ctx, 2 * half);
+    if (rc) return rc;
+    if (ctx->flags_cc_bytes != before) ctx->flags_cc_zeroed[0] = ctx->flags_cc_zeroed[1] = ctx->flags_cc_dirty[0] = ctx->flags_cc_dirty[1] = 0;
+    const size_t stride = (ctx->flags_cc_bytes / 2) & ~(size_t)255;
+    const u32 a = ctx->flags_cc_area & 1u;
+    ctx->flags_cc_area = a ^ 1u;
+    *cur = ctx->d_flags_cc + a * stride;
+    *other = ctx->d_flags_cc + (a ^ 1u) * stride;
+    if (ctx->flags_cc_dirty[a]) {
+        PMX_HIP(hipMemsetAsync(*cur, 0, ctx->flags_cc_dirty[a], ctx->stream));
+        ctx->flags_cc_dirty[a] = 0;
+    }
+    if (ctx->flags_cc_zeroed[a] < zero_bytes) {
+        PMX_HIP(hipMemsetAsync(*cur, 0, zero_bytes, ctx->stream));
+        ctx->flags_cc_zeroed[a] = zero_bytes;
+    }
+    ctx->flags_cc_dirty[a] = zero_bytes;
+    *other_dirty = ctx->flags_cc_dirty[a ^ 1u];
+    return PMX_OK;
 }
 
 int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift,
@@ -2520,6 +2553,8 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     unsigned char *d_flags = nullptr, *d_flags_ac = nullptr;
     u32 *d_nflagged = nullptr, *d_plan_cc = nullptr, *d_plan_ac = nullptr, *d_jobstat = nullptr;
     size_t flag_bytes_all = 0;     // raw length of a flag array (multiple of 16)
+    unsigned char *d_other_area = nullptr;   // the context's other flag area: cleared by this pass's k_events_finish
+    size_t other_dirty = 0;
     if (use_events) {
         uint64_t total_flags = 0;
         for (size_t i = 0; i < vjobs.size(); i++) {
@@ -2527,18 +2562,19 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             total_flags += (vjobs[i].job->nbits + SP_TB - 1) / SP_TB + EV_NQ;   // padding: an event tile flags EV_NQ window tiles
         }
         const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
-        const size_t stat_bytes = 4 * SP_MAXJOBS * sizeof(u32);
-        int rc = pmx_ensure_flags_cc(ctx, 2 * flag_bytes + 16 + stat_bytes + 2 * PLAN_WORDS * sizeof(u32));
+        const size_t stat_bytes = EV_STAT_BYTES;   // job statistics + the chromosomes' scalar totals
+        const size_t zero_bytes = 2 * flag_bytes + 16 + stat_bytes;   // (a multiple of 16)
+        unsigned char *area = nullptr;
+        int rc = ev_flag_area(ctx, zero_bytes + 2 * PLAN_WORDS * sizeof(u32), zero_bytes, &area, &d_other_area, &other_dirty);
         if (rc) return rc;
-        d_flags = ctx->d_flags_cc;                   // tiles of the cross-correlation window kernel (32 Kbit)
-        d_flags_ac = ctx->d_flags_cc + flag_bytes;   // tiles of the autocorrelation window kernel (64 Kbit), same flag0 per job
-        d_nflagged = (u32 *)(ctx->d_flags_cc + 2 * flag_bytes);
-        d_jobstat = (u32 *)(ctx->d_flags_cc + 2 * flag_bytes + 16);   // per job: tiles seen / read-dense / edge-dense (k_cc_events)
+        d_flags = area;                              // tiles of the cross-correlation window kernel (32 Kbit)
+        d_flags_ac = area + flag_bytes;              // tiles of the autocorrelation window kernel (64 Kbit), same flag0 per job
+        d_nflagged = (u32 *)(area + 2 * flag_bytes);
+        d_jobstat = (u32 *)(area + 2 * flag_bytes + 16);   // per job: tiles seen / read-dense / edge-dense (k_cc_events)
         flag_bytes_all = flag_bytes;
-        d_plan_cc = d_jobstat + 4 * SP_MAXJOBS;      // work split of the two window launches (k_plan_flagged)
+        d_plan_cc = (u32 *)((unsigned char *)d_jobstat + stat_bytes);   // work split of the two window launches (k_events_finish)
         d_plan_ac = d_plan_cc + PLAN_WORDS;
-        PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, 2 * flag_bytes + 16 + stat_bytes, ctx->stream));
-        if (fuse_mlen) fused->done = true;   // row MLEN and scalar [2] are written by this call (k_events_tail)
+        if (fuse_mlen) fused->done = true;   // row MLEN and scalar [2] are written by this call (k_events_finish)
     }
     ReduceSpec rs_ev = rs;
     for (u32 i = 0; i < nr; i++)
@@ -2556,7 +2592,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         if (use_events) {
             memset(&tab, 0, sizeof tab);
             // (the next 32 jobs: their own flagged-tile counters and job statistics)
-            if (lo) PMX_HIP(hipMemsetAsync(d_nflagged, 0, 16 + 4 * SP_MAXJOBS * sizeof(u32), ctx->stream));
+            if (lo) PMX_HIP(hipMemsetAsync(d_nflagged, 0, 16 + EV_STAT_BYTES, ctx->stream));
             const bool deep = has_m && ctx->deep_lists;   // PMX_FLAG_DEEP_LISTS: the larger list pool at four workgroups per CU
             // workgroups per CU: what the instantiation was built for (5 / 4 / 8), or fewer if this device takes fewer (the
             // grid is one round of resident workgroups: a sixth that does not fit would run as a tail behind the others)
@@ -2594,28 +2630,6 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             PMX_CHECK_LAUNCH("k_cc_events");
             rc = pmx_prof_end(ctx, &tl);
             if (rc) return rc;
-            if (fuse_mlen) {
-                // the edge-pair sums EE = P - N go to the P row of the per-job scratch as signed numbers, N is cleared,
-                // popcount(M) and the run count to its scalars: what k_autocorr_pairs + k_reduce_pairs leave there
-                const u32 lagcap = (u32)(((size_t)fused_lag + 1 + 1023) / 1024 * 1024);
-                ReduceSpec r2;
-                memset(&r2, 0, sizeof r2);
-                r2.nrows = 2;
-                r2.src_row[0] = 5; r2.dst_row[0] = 0; r2.is_signed[0] = 1;
-                r2.src_row[1] = 4; r2.dst_row[1] = 2 * lagcap; r2.is_scalar[1] = 1; r2.scalar_off = 4;
-                r2.nzero = 1;
-                r2.zero_row[0] = lagcap;
-                r2.use_out2 = 1;
-                r2.n_override = fused_lag + 1;
-                r2.out_stride = out_stride;
-                // (few chromosomes with many workgroups each -- a shard of a multi-GPU run --: more phases per block)
-                hipLaunchKernelGGL(k_reduce_segments2, dim3(32, nr + nz + 3, n), dim3(nwg > 128u * n ? 1024 : 256), 0, ctx->stream,
-                                   (const u32 *)ctx->d_slab, tab, (u32)EV_SEG_ROWS, rs_ev, r2);
-            } else {
-                hipLaunchKernelGGL(k_reduce_segments, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab,
-                                   tab, (u32)EV_SEG_ROWS, rs_ev, (const u32 *)nullptr);
-            }
-            PMX_CHECK_LAUNCH("k_reduce_segments");
         }
         // Pass 2 (window kernel): every tile, or -- behind the event pass -- only the tiles it flagged (the whole grid returns
         // at once when there are none).  Behind the event pass it writes a slab of its own and k_events_tail adds its sums.
@@ -2631,10 +2645,10 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         if (use_events) {
             // the flagged tiles in equal shares (one small block; returns at once when nothing was flagged)
             if (nwg > 2048) {
-                pmx_set_error("k_plan_flagged: %u workgroups exceed its tables", nwg);
+                pmx_set_error("k_events_finish: %u workgroups exceed the planner's tables", nwg);
                 return PMX_ERR_INVALID;
             }
-            // (both window launches of this batch are planned in ONE launch: the autocorrelation launch's shape is known here)
+            // (both window launches of this batch are planned in the same launch: the autocorrelation launch's shape is known here)
             PlanLaunch pcc, pac;
             memset(&pcc, 0, sizeof pcc);
             memset(&pac, 0, sizeof pac);
@@ -2649,13 +2663,33 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
                 memset(&tabA, 0, sizeof tabA);
                 plan_launch(ctx, va.data(), n, true, AC_WAVES, &tabA, &totalA, &tpwA, &nwgA);
                 if (nwgA > 2048) {
-                    pmx_set_error("k_plan_flagged: %u workgroups exceed its tables", nwgA);
+                    pmx_set_error("k_events_finish: %u workgroups exceed the planner's tables", nwgA);
                     return PMX_ERR_INVALID;
                 }
                 fill_plan_launch(pac, tabA, n, totalA, nwgA, raw_lo, raw_hi, 1u, (const unsigned char *)d_flags_ac, d_nflagged + 1, d_plan_ac);
             }
-            hipLaunchKernelGGL(k_plan_flagged, dim3(fuse_mlen ? 2 : 1), dim3(1024), 0, ctx->stream, pcc, pac);
-            PMX_CHECK_LAUNCH("k_plan_flagged");
+            // sums over the workgroups' segments, prefix sums, the mappable-length recurrence, the plan of the window launches
+            // and the clearing of the other flag area: ONE launch (k_reduce_segments2 + k_plan_flagged + half of k_events_tail + a
+            // memset until round 3)
+            EvFinishArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.slab = ctx->d_slab;
+            fa.jobsum = EV_JOBSUM(d_jobstat);
+            fa.S = max_shift;
+            fa.out_stride = out_stride;
+            fa.has_m = has_m ? 1u : 0u;
+            fa.do_ncc = do_ncc ? 1u : 0u;
+            fa.fused_mlen = fuse_mlen ? 1u : 0u;
+            fa.zero_mlen = zero_mlen ? 1u : 0u;
+            fa.keep_scalar2 = rs.keep_scalar2;
+            fa.max_lag = fuse_mlen ? fused_lag : 0u;
+            fa.lagcap = (u32)(((size_t)(fuse_mlen ? fused_lag : 0) + 1 + 1023) / 1024 * 1024);
+            fa.c = c;
+            fa.zero_area = reinterpret_cast<uint4 *>(d_other_area);
+            fa.zero_quads = (u32)(other_dirty / 16);
+            hipLaunchKernelGGL(k_events_finish, dim3(EVF_TASKS, n + 1), dim3(1024), 0, ctx->stream, tab, n, fa, pcc, pac);
+            PMX_CHECK_LAUNCH("k_events_finish");
+            ctx->flags_cc_dirty[(ctx->flags_cc_area & 1u)] = 0;   // (flags_cc_area already points at the other area: the next pass's)
         }
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, use_events);
         if (rc) return rc;
@@ -2709,7 +2743,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         hipLaunchKernelGGL(k_events_tail, dim3(n, 4), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
                            (const u32 *)ctx->d_slab_fb, (const u32 *)ctx->d_slab_ac, (const u32 *)d_nflagged, max_shift, out_stride,
                            has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c, fuse_mlen ? 1u : 0u, 1024u, 1u,
-                           (const u32 *)d_plan_cc, (const u32 *)(fuse_mlen ? d_plan_ac : nullptr));
+                           (const u32 *)d_plan_cc, (const u32 *)(fuse_mlen ? d_plan_ac : nullptr), 1u);
         PMX_CHECK_LAUNCH("k_events_tail");
     }
     return PMX_OK;

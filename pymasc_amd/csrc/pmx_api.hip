@@ -83,6 +83,8 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->flags_bytes = 0;
     ctx->d_flags_cc = nullptr;
     ctx->flags_cc_bytes = 0;
+    ctx->flags_cc_area = 0;
+    ctx->flags_cc_zeroed[0] = ctx->flags_cc_zeroed[1] = ctx->flags_cc_dirty[0] = ctx->flags_cc_dirty[1] = 0;
     ctx->d_slab_ac = nullptr;
     ctx->slab_ac_words = 0;
     ctx->d_slab_fb = nullptr;
@@ -498,7 +500,10 @@ int pmx_debug_poison(pmx_ctx *ctx, uint32_t pattern, uint32_t mask)
     if ((mask & 4) && ctx->d_slab_ac) PMX_HIP(hipMemsetAsync(ctx->d_slab_ac, byte, ctx->slab_ac_words * sizeof(u32), ctx->stream));
     if ((mask & 4) && ctx->d_slab_fb) PMX_HIP(hipMemsetAsync(ctx->d_slab_fb, byte, ctx->slab_fb_words * sizeof(u32), ctx->stream));
     if ((mask & 8) && ctx->d_flags) PMX_HIP(hipMemsetAsync(ctx->d_flags, byte, ctx->flags_bytes, ctx->stream));
-    if ((mask & 16) && ctx->d_flags_cc) PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, byte, ctx->flags_cc_bytes, ctx->stream));
+    if ((mask & 16) && ctx->d_flags_cc) {
+        PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, byte, ctx->flags_cc_bytes, ctx->stream));
+        ctx->flags_cc_zeroed[0] = ctx->flags_cc_zeroed[1] = ctx->flags_cc_dirty[0] = ctx->flags_cc_dirty[1] = 0;   // (neither area is clean now)
+    }
     if ((mask & 32) && ctx->d_scratch) PMX_HIP(hipMemsetAsync(ctx->d_scratch, byte, ctx->scratch_words * sizeof(u64), ctx->stream));
     for (int i = 0; i < 3; i++)
         if ((mask & 64) && ctx->d_stage[i])

@@ -73,6 +73,9 @@ struct pmx_ctx {
     size_t flags_bytes;
     unsigned char *d_flags_cc;   // dense-tile flags (+ counter) the event kernel hands to the window kernel
     size_t flags_cc_bytes;
+    // the event pass uses two areas of d_flags_cc in turn; a pass's k_events_finish clears the other one (kernels_sparse.hip: ev_flag_area)
+    uint32_t flags_cc_area;
+    size_t flags_cc_zeroed[2], flags_cc_dirty[2];
     u32 *d_slab_ac;              // slab of the window autocorrelation kernel (separate: it may run beside k_cc_sparse)
     size_t slab_ac_words;
     u32 *d_slab_fb;              // slab of k_cc_sparse when it runs as the fallback behind the event kernel
