@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeat", type=int, default=3,
+                    help="repetitions of the timed region of --steps steps; the line reports the median one (min / median / max in `repetitions`)")
     ap.add_argument("--workload", choices=["hg38", "stress"], default="hg38",
                     help="hg38: BASELINE config 4 (default, the metric's configuration); stress: config 5, one "
                          "synthetic 10 Gbp / 200-chromosome genome sharded over the ranks, max_shift 5000")
@@ -151,11 +153,11 @@ def cpu_model():
     return "unknown"
 
 
-PROFILE_ROUND = "r3"
+PROFILE_ROUND = "r4"
 
 
 def committed_profile(name, workload_tag):
-    """A counter summary under profiles/ (tools/tools_r3_profile.sh), or (None, reason).  The summaries name the build
+    """A counter summary under profiles/ (tools/tools_r4_profile.sh), or (None, reason).  The summaries name the build
     (pmx_build_id: hash of pymasc_amd/csrc + the header) and the bench workload they were measured on; they are quoted only
     for that build and that workload, so a kernel edit cannot leave stale HBM bytes or pipe utilisation in the line."""
     from pymasc_amd import ffi
@@ -190,6 +192,26 @@ def pipe_utilisation(kernel, workload_tag):
             "lds_bank_conflict_frac": k.get("lds_bank_conflict_frac"),
             "wave_cycles_issuing": k.get("wave_cycles_issuing"), "wave_cycles_waiting": k.get("wave_cycles_waiting"),
             "source": why + " (" + prof.get("how", "rocprofv3 --pmc") + ")", "build_id": prof.get("build_id")}
+
+
+def issue_rate(kernel, workload_tag):
+    """Issued instructions per SIMD-cycle of the dominant kernel: every instruction of a wave's stream (vector, scalar, LDS,
+    branch, memory) counted by the SQ counters, x waves, / (kernel duration x 2.4 GHz x 1024 SIMDs).  DESIGN.md section 8: the
+    event kernel's time follows this count whatever the instruction type; a SIMD issues ~0.4 wave64 instructions per cycle
+    at best (tools/valu_rate.hip: 2.5 cycles per full-rate vector instruction)."""
+    prof, why = committed_profile("pmc_summary", workload_tag)
+    if prof is None:
+        return {"insts_per_simd_cycle": None, "reason": why}
+    k = prof["kernels"].get(kernel.split("+")[0])
+    if not k or not k.get("waves"):
+        return {"insts_per_simd_cycle": None, "reason": f"{why} holds no entry for {kernel}"}
+    per_wave = k["insts_per_wave"]
+    kinds = ("valu", "salu", "lds", "branch", "vmem_rd", "vmem_wr")
+    total = sum(per_wave.get(x, 0.0) for x in kinds) * k["waves"]
+    cycles = k["avg_duration_us"] * 1e-6 * 2.4e9 * 1024
+    return {"insts_per_simd_cycle": total / cycles, "insts_per_wave": {x: per_wave.get(x) for x in kinds},
+            "peak_insts_per_simd_cycle": 0.4, "frac_of_issue_peak": total / cycles / 0.4,
+            "source": why + " (SQ_INSTS_* per dispatch; duration from the --stats pass of the same command)", "build_id": prof.get("build_id")}
 
 
 def main():
@@ -327,24 +349,32 @@ def main():
     # (two empty launches take 10-20 us together, whatever the shard size; real work on dense tiles takes milliseconds)
     prof_level = 2 if (probe[ffi.PMX_KERNEL_CC_EVENTS] > 0 and fallback_ms > 0.04) else 1
     ctx.set_profiling(prof_level)
-    ctx.reset_kernel_times()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rows, totals = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # The timed region: EXACTLY args.steps steps between two fences (barrier + synchronize on both sides), max over ranks.
+    # It is run `args.repeat` times (default 3) and the line reports the MEDIAN repetition -- elapsed, ms_per_step, value and
+    # the live kernel times all belong to that one repetition of args.steps steps; min / median / max go into `repetitions`
+    # (a 10-ms region on one box spreads by a few per cent, more than some of the A/B differences DESIGN.md books).
+    reps = []
+    for _ in range(max(args.repeat, 1)):
+        ctx.reset_kernel_times()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rows, totals = step()
+        fence()
+        reps.append((time.perf_counter() - t0, {k: ctx.kernel_time(k) for k in range(ffi.PMX_KERNEL_COUNT)}))
     ctx.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        t = torch.tensor([r[0] for r in reps], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        reps = [(float(x), r[1]) for x, r in zip(t.tolist(), reps)]
+    order = sorted(range(len(reps)), key=lambda i: reps[i][0])
+    elapsed, ktimes = reps[order[len(order) // 2]]
+    rep_ms = sorted(1e3 * r[0] / args.steps for r in reps)
 
     # consistency of the exchange: all-reduced totals == sum of gathered rows (integers, exact)
     assert torch.equal(rows.sum(dim=0), totals), "result exchange mismatch"
 
     # dominant kernel + roofline from the live HIP-event timings on this rank's stream
-    ktimes = {k: ctx.kernel_time(k) for k in range(ffi.PMX_KERNEL_COUNT)}
     dom = max(ktimes, key=lambda k: ktimes[k][0])
     dom_ms, dom_n = ktimes[dom]
     vec_bytes = sum((v.nbits + 7) // 8 for v in vecs)
@@ -356,12 +386,13 @@ def main():
         ffi.PMX_KERNEL_CC_EVENTS: (3 if with_m else 2) * vec_bytes + (4 if with_m else 1) * out_bytes * len(vecs),
     }[dom]
     alg_bytes_per_launch = per_pass * args.steps / max(dom_n, 1)
+    dense_lane_ops = (S + 1) * (8 * vec_bytes / 32) * (9 if with_m else 3) * args.steps / max(dom_n, 1)
     avg_ms = dom_ms / max(dom_n, 1)
     achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     kernel_ms_per_step = {ctx.kernel_name(k): round(ktimes[k][0] / args.steps, 4) for k in ktimes if ktimes[k][1]}
 
     # HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
-    # rocprofv3 passes of this same command: tools/tools_r3_profile.sh -> profiles/r3_traffic*.json).  Quoted only when
+    # rocprofv3 passes of this same command: tools/tools_r4_profile.sh -> profiles/r4_traffic*.json).  Quoted only when
     # the summary was measured on THIS build of the library and on this workload.
     workload_tag = (f"{args.workload}/{args.mode}/S{S}/L{L}/rho{args.density}/chroms{len(chroms)}/path{args.path}/"
                     f"track{args.track}" + ("" if (args.run_on, args.run_off) == (2000.0, 500.0) else f"-{args.run_on:g}-{args.run_off:g}")
@@ -459,8 +490,13 @@ def main():
                 # a run of reads of one length passes that length as a scalar (what a reader of single-end ChIP-seq data sees)
                 uniform = bool((ln == L).all())
                 # ... and the strand travels in the top bit of the position word (ffi.pack_strand): 4 bytes per read
-                reads[v.name] = (pinned(ffi.pack_strand(pos[order].astype(np.int32), rv[order]), np.int32),
-                                 L if uniform else pinned(ln[order], np.uint16), None)
+                # BENCH_FEED_FORMAT=pos32 (A/B: round 3's form): ffi.pack_strand, 4 bytes per read
+                if os.environ.get("BENCH_FEED_FORMAT") == "pos32":
+                    reads[v.name] = (pinned(ffi.pack_strand(pos[order].astype(np.int32), rv[order]), np.int32),
+                                     L if uniform else pinned(ln[order], np.uint16), None)
+                else:   # ... or, since the reads are sorted, as distances: TWO bytes per read (ffi.pack_delta16), one page-locked block
+                    d16 = ffi.pack_delta16(pos[order], rv[order], ctx, None if uniform else ln[order])
+                    reads[v.name] = (d16, L if uniform else d16.readlen, None)
                 if with_m:      # BigWig (begin, end): set(begin + 1, end); both arrays in one page-locked block
                     b_, e_ = ctx.host_packed([v.h_first.size, v.h_last.size], np.uint32)
                     b_[:] = v.h_first - 1
@@ -530,13 +566,17 @@ def main():
                     assert np.array_equal(mc.ccbins, hr[j, ffi.PMX_ROW_MSCC_CCBINS]), "calculator mscc.ccbins differ"
                     assert np.array_equal(mc.forward_sum, hr[j, ffi.PMX_ROW_MSCC_FSUM]) and np.array_equal(mc.reverse_sum, hr[j, ffi.PMX_ROW_MSCC_RSUM])
             nreads = sum(r[0].size for r in reads.values())
+            d16_mode = os.environ.get("BENCH_FEED_FORMAT") != "pos32"
+            read_bytes = lambda r: ((r[0].words.nbytes + r[0].seg_start.nbytes + r[0].seg_base.nbytes) if d16_mode else r[0].nbytes)
             calc_leg = {"value": work_per_step / dtc, "unit": "shifts*bp/s", "ms_per_step": dtc * 1e3, "steps": n_e2e,
                         "reads": int(nreads), "reads_per_s": nreads / dtc,
-                        "h2d_bytes": int(sum(r[0].nbytes + getattr(r[1], "nbytes", 0) + getattr(r[2], "nbytes", 0) for r in reads.values())
+                        "read_format": "delta16 (2 bytes per read)" if d16_mode else "pos32 (4 bytes per read)",
+                        "h2d_bytes": int(sum(read_bytes(r) + getattr(r[1], "nbytes", 0) + getattr(r[2], "nbytes", 0) for r in reads.values())
                                          + sum(t[0].nbytes + t[1].nbytes for t in tracks.values())),
-                        "what": "CCHipCalculator (the class handler/factory.py constructs): feed_reads(chrom, int32 pos with the "
-                                "strand in its top bit, read length (one int per chromosome where all reads have it, else uint16); "
-                                "page-locked arrays in file order) per chromosome -> pmx_feed_reads "
+                        "what": "CCHipCalculator (the class handler/factory.py constructs): feed_reads(chrom, reads in file order as 16-bit "
+                                "words (strand + distance to the read before, ffi.pack_delta16; BENCH_FEED_FORMAT=pos32: int32 positions with "
+                                "the strand in the top bit), read length (one int per chromosome where all reads have it, else uint16); "
+                                "one page-locked block per chromosome) -> pmx_feed_reads_delta16 / pmx_feed_reads "
                                 "(duplicate rules + read-length sums + bit set on the device) -> finishup_calculation (one batched "
                                 "pmx_cc_batch_dev, one synchronisation, one copy back) -> get_whole_result (the reference's result "
                                 "objects, cc curves computed); rows equal to the resident-vector run"}
@@ -594,7 +634,16 @@ def main():
             "avg_launch_ms": avg_ms,
             "launches": dom_n,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+            # the reference's algorithm as dense integer work -- (S+1) N / 32 word-steps of >= 3 (NCC) / 9
+            # (NCC+MSCC) lane-ops -- against the vector peak of 7.9e13 lane-ops/s.  The event formulation does not execute
+            # that work (it enumerates ~3000 events per 64 Kbit instead), so this reads ABOVE 1: it says how far the
+            # reformulation is from the dense algorithm's own roofline, not how busy the vector pipes are (see `issue`).
+            "dense_lane_ops_per_launch": dense_lane_ops,
+            "dense_equivalent_frac_of_valu_peak": (dense_lane_ops / (avg_ms * 1e-3) / 7.9e13) if avg_ms > 0 else None,
+            "issue": issue_rate(ctx.kernel_name(dom), workload_tag),
         },
+        "repetitions": {"n": len(reps), "steps_each": args.steps, "ms_per_step_min_median_max":
+                        [round(rep_ms[0], 5), round(rep_ms[len(rep_ms) // 2], 5), round(rep_ms[-1], 5)]},
         "pipe_utilisation": pipe_utilisation(ctx.kernel_name(dom), workload_tag),
         "build_id": ffi.build_id(),
         # HIP-event durations per step.  k_cc_events takes the sparse tiles (and the run-edge pairs of the mappable-length

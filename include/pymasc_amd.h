@@ -62,10 +62,10 @@ extern "C" {
 #define PMX_FLAG_SKIP_MLEN    8u  /* the caller holds mappable_len already (the *_mappability.json cache,
                                    * handler/mappability.py:239-259): no autocorrelation pass; row 4 and
                                    * scalars[2] are written as zeros */
-/* default (neither): the set-bit kernels for read_len <= 1024 -- for max_shift <= 1023 the event kernel on the
- * tiles (64 Kbit) whose read / run-edge lists fit its LDS lists and the window kernel on the others, for larger
- * max_shift the window kernel in chunks of 1024 shifts --, the dense kernels for longer reads.  The integers are
- * the same whichever kernel produced them.
+/* default (neither): the set-bit kernels for read_len <= 1024 -- for max_shift <= 8191 the event kernel on the
+ * tiles (64 Kbit) whose read / run-edge lists fit its LDS lists and the window kernel on the others (beyond 1023
+ * shifts in chunks of 1024 shifts), for max_shift > 8191 the window kernel alone in chunks of 1024 shifts --, the
+ * dense kernels for longer reads.  The integers are the same whichever kernel produced them.
  * Environment switches read once per process (A/B measurements, tests): PMX_CC_EVENTS=0 (window kernel on every
  * tile), PMX_CC_FUSE_MLEN=0 (mappable-length pass not fused into the event kernel), PMX_AUTOCORR_PAIRS=0,
  * PMX_AUTOCORR_FORK=0.
@@ -158,6 +158,17 @@ int pmx_host_free(pmx_ctx *ctx, void *h);
 int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *h_pos, uint32_t pos_bytes,
                    const void *h_readlen, uint32_t len_bytes, const uint8_t *h_is_reverse, uint64_t n,
                    uint64_t reads_before, uint64_t *d_state);
+/* The same run of reads in TWO bytes per read (round 4: the feed of a genome is a PCIe copy, and the reads of a sorted BAM
+ * lie ~100 bp apart): h_words[i] = strand in bit 15 (set: reverse), distance to the position of read i - 1 in bits 0..14.
+ * The run is cut into nseg SEGMENTS of 1..4096 reads: h_seg_start[s] = index of the first read of segment s
+ * (h_seg_start[0] = 0, h_seg_start[nseg] = n), h_seg_base[s] = its absolute 1-based position (its distance field is 0); a
+ * new segment begins at least every 4096 reads and wherever two neighbours lie 32767 bp or more apart.  Read lengths as
+ * for pmx_feed_reads.  nbits < 2^31 (32-bit positions: what a BAM file can hold, SAMv1 4.2).  The device expands the
+ * words to positions (one workgroup per segment) and applies the rules of feed_forward_read / feed_reverse_read
+ * (mscc.pyx:370-418) exactly as pmx_feed_reads does.  Asynchronous. */
+int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const uint16_t *h_words, uint64_t n,
+                           const uint32_t *h_seg_start, const int32_t *h_seg_base, uint32_t nseg, const void *h_readlen,
+                           uint32_t len_bytes, uint64_t reads_before, uint64_t *d_state);
 /* _load_mappability's loop (mscc.pyx:343-344): set(h_first[i] + first_offset, h_last[i]) for n intervals, ends inclusive
  * (BigWig (begin, end) pairs: first_offset = 1).  width_bytes: 4 (uint32) or 8 (int64).  An interval outside [0, nbits) is
  * clipped and recorded in d_state[PMX_FEED_FIRST_OUT_OF_RANGE] (d_state may be NULL).  Asynchronous. */

@@ -322,13 +322,29 @@ class CCHipCalculator:
         self._fed += int(pos.size)
 
     def feed_reads(self, chrom: str, pos: np.ndarray, readlen: np.ndarray, is_reverse: Optional[np.ndarray]) -> None:
-        """Bulk variant of the two methods above for one chromosome: arrays in file order (int32 or int64 positions,
+        """Bulk variant of the two methods above for one chromosome: arrays in file order (int32 or int64 positions -- or an
+        ffi.Delta16Reads, the two-bytes-per-read form of a sorted run, with is_reverse = None --,
         uint16 / int32 / int64 read lengths or ONE int when every read of the chunk has that length, strand as bool / uint8, or
         None with the strand packed into the top bit of every position: ffi.pack_strand).  Not part of the reference protocol; it removes the per-read Python call for
         vectorised readers, and the host does not walk the reads at all: the order of the chunk against the reads fed
         before is checked here (first position), everything else -- order inside the chunk, range, duplicates, read-length
         sums -- by the device, so ReadUnsortedError / IndexError for a read inside the chunk are raised when the results
         of the chromosome are fetched (flush + get_result, finishup_calculation), not by this call."""
+        if isinstance(pos, ffi.Delta16Reads):
+            # two bytes per read (ffi.pack_delta16 / a reader that emits the form): the host sees the first and the last
+            # position of the run, the device everything else
+            if pos.size == 0:
+                return
+            self._check_pos(chrom, pos.first_pos)
+            if self._buf.n:
+                self._to_device(*self._buf.take())
+            self._start_chromosome_on_device()
+            self._inflight.append(self._ctx.feed_reads_delta16(self._d_f, self._d_r, self._cur_nbits, pos,
+                                                               readlen if np.ndim(readlen) == 0 else np.asarray(readlen),
+                                                               self._fed, self._state_ptr(self._cur_slot)))
+            self._fed += pos.size
+            self._last_pos = max(self._last_pos, pos.last_pos)
+            return
         pos = np.asarray(pos)
         if pos.size == 0:
             return

@@ -272,6 +272,57 @@ int pmx_launch_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t n
     return PMX_ERR_INVALID;
 }
 
+// ---- the 2-bytes-per-read form of a run of reads (pmx_feed_reads_delta16, round 4) ----
+// Reads of a sorted BAM lie ~100 bp apart: a word of 16 bits holds the strand (bit 15) and the distance to the read before
+// it (bits 0..14).  The run is cut into SEGMENTS of at most FEED_SEG_READS reads -- every FEED_SEG_READS reads, and wherever
+// two neighbours lie 32767 bp or more apart --, each with the absolute position of its first read in a table (that read's
+// distance field is 0): one workgroup expands a segment with one block scan, nothing is carried between workgroups.
+// Output: the 4-bytes-per-read form k_feed_reads takes (int32 position, strand in the top bit).
+#define FEED_SEG_READS 4096u
+__global__ void __launch_bounds__(256) k_feed_expand16(const unsigned short *__restrict__ words, const u32 *__restrict__ seg_start,
+                                                       const int32_t *__restrict__ seg_base, uint64_t n, int32_t *__restrict__ pos)
+{
+    __shared__ u32 wsum[4];
+    const u32 s = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u32 i0 = seg_start[s], i1 = seg_start[s + 1];      // (the table ends with n)
+    const u32 cnt = i1 > i0 ? i1 - i0 : 0u;
+    if (cnt == 0 || cnt > FEED_SEG_READS || i1 > n) return;   // (a malformed table is caught on the host; never index beyond n)
+    // 16 consecutive reads per thread
+    const u32 k0 = 16 * tid;
+    u32 w[16], run = 0;
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) {
+        w[k] = k0 + k < cnt ? (u32)words[i0 + k0 + k] : 0u;
+        run += w[k] & 0x7fffu;
+    }
+    u32 x = run;   // inclusive scan of the thread sums over the workgroup
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 y = __shfl_up(x, off, 64);
+        if (lane >= (u32)off) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    u32 before = x - run;
+    for (u32 v = 0; v < wave; v++) before += wsum[v];
+    u32 p = (u32)seg_base[s] + before;
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) {
+        p += w[k] & 0x7fffu;
+        if (k0 + k < cnt) pos[i0 + k0 + k] = (int32_t)(p | ((w[k] >> 15) << 31));
+    }
+}
+
+int pmx_launch_feed_expand16(pmx_ctx *ctx, const void *d_words, const void *d_seg_start, const void *d_seg_base, uint32_t nseg,
+                             uint64_t n, void *d_pos32)
+{
+    if (n == 0 || nseg == 0) return PMX_OK;
+    hipLaunchKernelGGL(k_feed_expand16, dim3(nseg), dim3(256), 0, ctx->stream, (const unsigned short *)d_words, (const u32 *)d_seg_start,
+                       (const int32_t *)d_seg_base, n, (int32_t *)d_pos32);
+    PMX_CHECK_LAUNCH("k_feed_expand16");
+    return PMX_OK;
+}
+
 int pmx_launch_set_regions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to, uint32_t width,
                              uint64_t n, int64_t offset, uint64_t *d_err)
 {

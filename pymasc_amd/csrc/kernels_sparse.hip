@@ -2291,20 +2291,28 @@ static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p)
 }
 
 // resident workgroups per CU of a max_shift <= 1023 instantiation on this device, at most `built_for` (asked once per instantiation)
+// (cached per DEVICE: a process may hold one context per GPU, and both the occupancy answer and the function attribute of
+// ev_big_launch belong to the current device)
+#define EV_MAX_DEVICES 64
 template <bool HAS_M, bool DO_NCC, bool DO_MLEN, bool DEEP>
-static u32 ev_resident_per_cu(u32 built_for)
+static u32 ev_resident_per_cu(pmx_ctx *ctx, u32 built_for)
 {
-    static int cached = -1;
-    if (cached < 0) {
-        int n = 0;
+    static int cached[EV_MAX_DEVICES];
+    static bool known[EV_MAX_DEVICES];
+    const int dev = ctx->device >= 0 && ctx->device < EV_MAX_DEVICES ? ctx->device : -1;
+    int n = dev >= 0 && known[dev] ? cached[dev] : -1;
+    if (n < 0) {
         auto kern = k_cc_events<HAS_M, DO_NCC, DO_MLEN, 1, false, SpJobTable, DEEP>;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(kern), 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = (int)built_for;
         }
-        cached = n;
+        if (dev >= 0) {
+            cached[dev] = n;
+            known[dev] = true;
+        }
     }
-    return (u32)cached < built_for ? (u32)cached : built_for;
+    return (u32)n < built_for ? (u32)n : built_for;
 }
 
 template <bool HAS_M, bool DO_NCC, u32 NSG>
@@ -2312,11 +2320,12 @@ static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTableRef 
                          u32 max_shift, u32 nhr, unsigned char *d_flags, u32 *d_nflagged, u32 *d_jobstat)
 {
     auto kern = k_cc_events<HAS_M, DO_NCC, false, NSG, true, SpJobTableRef>;
-    static bool attr_set = false;   // (a context is single-threaded; the attribute is per process and device function)
-    if (!attr_set) {
+    static bool attr_set[EV_MAX_DEVICES];   // (per device function AND device: set once per GPU of the process, see ev_resident_per_cu)
+    const int dev = ctx->device >= 0 && ctx->device < EV_MAX_DEVICES ? ctx->device : -1;
+    if (dev < 0 || !attr_set[dev]) {
         PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 64));
-        attr_set = true;
+        if (dev >= 0) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256 * NSG), pl.lds_bytes, ctx->stream, tab, n, total, tpw, c, max_shift, nhr, 0u,
                        pl.hn, pl.lo, ctx->d_slab, d_flags, d_flags, d_nflagged, d_jobstat);
@@ -2598,7 +2607,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             // grid is one round of resident workgroups: a sixth that does not fit would run as a tail behind the others)
             u32 per_cu = has_m ? (deep ? 4 : EV_WAVES) : EV_WAVES_NCC;
             {
-#define EV_OCC(HM, NC, ML, DP) ev_resident_per_cu<HM, NC, ML, DP>(per_cu)
+#define EV_OCC(HM, NC, ML, DP) ev_resident_per_cu<HM, NC, ML, DP>(ctx, per_cu)
                 if (has_m && do_ncc && fuse_mlen) per_cu = deep ? EV_OCC(true, true, true, true) : EV_OCC(true, true, true, false);
                 else if (has_m && do_ncc) per_cu = deep ? EV_OCC(true, true, false, true) : EV_OCC(true, true, false, false);
                 else if (has_m && fuse_mlen) per_cu = deep ? EV_OCC(true, false, true, true) : EV_OCC(true, false, true, false);
@@ -2817,11 +2826,12 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
             rc = upload_table(ctx, tab, &ref);
             if (rc) return rc;
             if (lds_bytes > 64 * 1024) {   // (max_lag above ~7870: the histograms alone pass 64 KB)
-                static bool attr_set = false;
-                if (!attr_set) {
+                static bool attr_set[EV_MAX_DEVICES];   // (per device, see ev_big_launch)
+                const int dev = ctx->device >= 0 && ctx->device < EV_MAX_DEVICES ? ctx->device : -1;
+                if (dev < 0 || !attr_set[dev]) {
                     PMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_autocorr_pairs<JT>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-                    attr_set = true;
+                    if (dev >= 0) attr_set[dev] = true;
                 }
             }
             pmx_timed_launch tl;

@@ -816,6 +816,45 @@ int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, c
     return feed_release(ctx, slot);
 }
 
+int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const uint16_t *h_words, uint64_t n,
+                           const uint32_t *h_seg_start, const int32_t *h_seg_base, uint32_t nseg, const void *h_readlen,
+                           uint32_t len_bytes, uint64_t reads_before, uint64_t *d_state)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    REQUIRE(ctx && d_F && d_R && d_state, "pmx_feed_reads_delta16: NULL argument");
+    REQUIRE(n == 0 || (h_words && h_seg_start && h_seg_base && h_readlen && nseg >= 1), "pmx_feed_reads_delta16: NULL read arrays");
+    REQUIRE(len_bytes == 0 || len_bytes == 2 || len_bytes == 4 || len_bytes == 8,
+            "pmx_feed_reads_delta16: read lengths must be 2, 4 or 8 bytes wide (0: one int64 for all)");
+    REQUIRE(nbits >= 1 && nbits < (1ull << 31), "pmx_feed_reads_delta16: nbits must be in [1, 2^31) (32-bit positions: what a BAM file holds)");
+    REQUIRE(n < (1ull << 32), "pmx_feed_reads_delta16: at most 2^32 - 1 reads per call");
+    if (n == 0) return PMX_OK;
+    // the segment table as the kernel will index it: starts increasing from 0, at most 4096 reads each, ends with n
+    // (checked here, on a few hundred words: the kernel never reads beyond the run)
+    REQUIRE(h_seg_start[0] == 0 && h_seg_start[nseg] == n, "pmx_feed_reads_delta16: the segment table must start at 0 and end with n");
+    for (uint32_t s = 0; s < nseg; s++)
+        REQUIRE(h_seg_start[s + 1] > h_seg_start[s] && h_seg_start[s + 1] - h_seg_start[s] <= 4096u,
+                "pmx_feed_reads_delta16: segments hold 1..4096 reads");
+    const int64_t uniform_len = len_bytes == 0 ? *(const int64_t *)h_readlen : 0;
+    // slot: [words][segment starts (nseg + 1)][segment bases][read lengths][expanded positions (device only)]
+    const size_t o_start = align16((size_t)n * 2), o_base = o_start + align16(((size_t)nseg + 1) * 4);
+    const size_t o_len = o_base + align16((size_t)nseg * 4), o_pos = o_len + align16((size_t)n * len_bytes);
+    unsigned char *d = nullptr;
+    uint32_t slot = 0;
+    int rc = feed_acquire(ctx, o_pos + (size_t)n * 4, &d, &slot);
+    if (rc) return rc;
+    const FeedPart parts[4] = {{0, h_words, (size_t)n * 2}, {o_start, h_seg_start, ((size_t)nseg + 1) * 4}, {o_base, h_seg_base, (size_t)nseg * 4},
+                               {o_len, len_bytes ? h_readlen : nullptr, (size_t)n * len_bytes}};
+    rc = feed_copy(ctx, d, parts, 4);
+    if (rc) return rc;
+    rc = feed_publish(ctx);
+    if (rc) return rc;
+    rc = pmx_launch_feed_expand16(ctx, d, d + o_start, d + o_base, nseg, n, d + o_pos);
+    if (rc) return rc;
+    rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d + o_pos, 4, d + o_len, len_bytes, uniform_len, nullptr, n, reads_before, d_state);
+    if (rc) return rc;
+    return feed_release(ctx, slot);
+}
+
 int pmx_bits_set_regions_async(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
                                uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state)
 {

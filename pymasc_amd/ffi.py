@@ -50,7 +50,7 @@ EXPORTS = [
     "pmx_bits_alloc", "pmx_bits_free", "pmx_bits_clear", "pmx_bits_upload", "pmx_bits_download",
     "pmx_bits_set_positions", "pmx_bits_set_positions_dev", "pmx_bits_set_regions", "pmx_bits_set_regions_dev",
     "pmx_bits_count",
-    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_bits_set_regions_async", "pmx_bits_build_batch",
+    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_delta16", "pmx_bits_set_regions_async", "pmx_bits_build_batch",
     "pmx_bits_build_status",
     "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
     "pmx_mappable_len_batch_dev",
@@ -100,6 +100,7 @@ def load_library(path: Optional[str] = None):
     L.pmx_host_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
     L.pmx_host_free.argtypes = [vp, vp]
     L.pmx_feed_reads.argtypes = [vp, vp, vp, u64, vp, u32, vp, u32, vp, u64, u64, vp]
+    L.pmx_feed_reads_delta16.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp, u32, vp, u32, u64, vp]
     L.pmx_bits_set_regions_async.argtypes = [vp, vp, u64, vp, vp, u32, u64, ctypes.c_int64, vp]
     L.pmx_bits_build_batch.argtypes = [vp, u32, vp, u32]
     L.pmx_bits_build_status.argtypes = [vp]
@@ -135,6 +136,72 @@ def pack_strand(pos: np.ndarray, is_reverse: np.ndarray) -> np.ndarray:
     top = dt.type(-1) << dt.type(8 * dt.itemsize - 1)
     out[np.asarray(is_reverse, dtype=bool)] |= top
     return out
+
+
+DELTA16_SEGMENT_READS = 4096     # include/pymasc_amd.h: pmx_feed_reads_delta16
+DELTA16_MAX_GAP = 32766
+
+
+class Delta16Reads:
+    """A run of reads of one chromosome in file order, two bytes per read (pmx_feed_reads_delta16): `words` (uint16: strand in
+    bit 15, distance to the previous read in bits 0..14), the segment table `seg_start` (uint32, nseg + 1 entries ending with n)
+    / `seg_base` (int32: absolute position of each segment's first read), and the first / last position of the run -- what
+    the host needs of it (order against the reads fed before; nothing else is looked at on the host)."""
+    __slots__ = ("words", "seg_start", "seg_base", "first_pos", "last_pos", "readlen")
+
+    def __init__(self, words, seg_start, seg_base, first_pos, last_pos, readlen=None):
+        self.words, self.seg_start, self.seg_base, self.first_pos, self.last_pos = words, seg_start, seg_base, int(first_pos), int(last_pos)
+        self.readlen = readlen      # (optional: per-read lengths laid out behind the table in the same page-locked block)
+
+    @property
+    def size(self):
+        return int(self.words.size)
+
+
+def pack_delta16(pos: np.ndarray, is_reverse: np.ndarray, context: "Context" = None, readlen: np.ndarray = None) -> Delta16Reads:
+    """Sorted 1-based positions + strands -> the two-bytes-per-read form (a reader emits this directly; this is the numpy
+    reference of the encoding).  With `context`, the three arrays are laid out in ONE page-locked block in the order the
+    device slot takes them, so that the feed is a single copy."""
+    pos = np.asarray(pos, dtype=np.int64)
+    n = pos.size
+    if n == 0:
+        raise ValueError("pack_delta16: empty run")
+    if (np.diff(pos) < 0).any():
+        raise ValueError("pack_delta16: positions must be sorted (an unsorted run has no distance form; feed it as positions)")
+    if pos[0] < 0 or pos[-1] >= 2**31:
+        raise ValueError("pack_delta16: positions must fit 31 bits")
+    d = np.diff(pos, prepend=pos[:1])
+    starts = np.union1d(np.arange(0, n, DELTA16_SEGMENT_READS), np.flatnonzero(d > DELTA16_MAX_GAP))
+    # (a stretch of far-apart reads can leave a segment longer than the grid allows only if a grid point was skipped: it is not)
+    d[starts] = 0
+    nseg = starts.size
+    lens = None
+    if context is not None and readlen is not None:     # per-read lengths (uint16) ride in the same block: still one copy
+        words, seg_start, seg_base, lens = context.host_packed([n, nseg + 1, nseg, n], [np.uint16, np.uint32, np.int32, np.uint16])
+        lens[:] = readlen
+    elif context is not None:
+        words, seg_start, seg_base = context.host_packed([n, nseg + 1, nseg], [np.uint16, np.uint32, np.int32])
+    else:
+        words, seg_start, seg_base = np.empty(n, np.uint16), np.empty(nseg + 1, np.uint32), np.empty(nseg, np.int32)
+        lens = None if readlen is None else np.asarray(readlen).astype(np.uint16)
+    words[:] = d.astype(np.uint16) | (np.asarray(is_reverse, dtype=bool).astype(np.uint16) << 15)
+    seg_start[:nseg] = starts
+    seg_start[nseg] = n
+    seg_base[:] = pos[starts]
+    return Delta16Reads(words, seg_start, seg_base, pos[0], pos[-1], lens)
+
+
+def unpack_delta16(reads: Delta16Reads):
+    """(positions int64, is_reverse bool): the inverse of pack_delta16 (tests, the CPU stand-in of the device)."""
+    w = reads.words.astype(np.int64)
+    d = w & 0x7fff
+    nseg = reads.seg_base.size
+    cum = np.cumsum(d)
+    starts = reads.seg_start[:nseg].astype(np.int64)
+    seg_of = np.repeat(np.arange(nseg), np.diff(reads.seg_start.astype(np.int64)))
+    # position = the segment's base + the distances of the segment's reads up to and including this one (k_feed_expand16)
+    pos = reads.seg_base.astype(np.int64)[seg_of] + cum - (cum[starts] - d[starts])[seg_of]
+    return pos, (w >> 15).astype(bool)
 
 
 def build_id() -> str:
@@ -284,13 +351,13 @@ class Context:
         """Arrays of `dtype` over ONE page-locked block, back to back with every array padded to 16 bytes: the layout the
         feeders give their staging slot, so feed_reads / bits_set_regions_async / bits_build_batch copy them in one piece
         (sizes e.g. (n_forward, n_reverse, n_intervals, n_intervals)).  Released with the context (or host_free(first array))."""
-        dt = np.dtype(dtype)
+        dts = [np.dtype(d) for d in dtype] if isinstance(dtype, (list, tuple)) else [np.dtype(dtype)] * len(sizes)   # (one type, or one per array)
         offs, total = [], 0
-        for n in sizes:
+        for n, dt in zip(sizes, dts):
             offs.append(total)
             total += (int(n) * dt.itemsize + 15) & ~15
         block = self.host_array(max(total, 16), np.uint8)
-        return [block[o:o + int(n) * dt.itemsize].view(dt) for o, n in zip(offs, sizes)]
+        return [block[o:o + int(n) * dt.itemsize].view(dt) for o, n, dt in zip(offs, sizes, dts)]
 
     def host_free(self, arr: np.ndarray):
         p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
@@ -305,16 +372,43 @@ class Context:
             a = a.astype(np.int64)
         return np.ascontiguousarray(a)
 
+    def feed_reads_delta16(self, d_F: int, d_R: int, nbits: int, reads: "Delta16Reads", readlen, reads_before: int, d_state: int):
+        """pmx_feed_reads_delta16: a run of reads in two bytes per read (pack_delta16).  Returns the arrays handed over: keep
+        them alive until the next synchronising call."""
+        words = np.ascontiguousarray(reads.words, dtype=np.uint16)
+        seg_start = np.ascontiguousarray(reads.seg_start, dtype=np.uint32)
+        seg_base = np.ascontiguousarray(reads.seg_base, dtype=np.int32)
+        if np.ndim(readlen) == 0:
+            readlen = np.array([int(readlen)], dtype=np.int64)
+            len_bytes = 0
+        else:
+            readlen = self._int_array(readlen, "readlen")
+            len_bytes = readlen.dtype.itemsize
+            assert readlen.size == words.size
+        assert seg_start.size == seg_base.size + 1
+        _check(self._L, self._L.pmx_feed_reads_delta16(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R), int(nbits), words.ctypes.data,
+                                                       int(words.size), seg_start.ctypes.data, seg_base.ctypes.data, int(seg_base.size),
+                                                       readlen.ctypes.data, len_bytes, int(reads_before), ctypes.c_void_p(d_state)))
+        return words, seg_start, seg_base, readlen
+
     def feed_reads(self, d_F: int, d_R: int, nbits: int, pos: np.ndarray, readlen: np.ndarray, is_reverse: np.ndarray,
                    reads_before: int, d_state: int):
         """pmx_feed_reads: a run of reads of one chromosome in file order (int32 / int64 positions, uint16 / int32 / int64
         read lengths -- or ONE int for a run of reads of the same length --, strand as bool / uint8 -- or is_reverse = None with the strand packed into the top bit of
         every position (pack_strand) --; other integer types are converted).
         Returns the arrays actually handed over: keep them alive until the next synchronising call."""
-        pos = self._int_array(pos, "pos")
         if is_reverse is None:                       # the strand travels in the top bit of the position word
+            # ... so the word must keep its width: int32 / int64 as they are, the unsigned packings reinterpreted (a
+            # conversion to int64 would turn bit 31 of a uint32 into part of the position), anything else refused
+            pos = np.asarray(pos)
+            if pos.dtype in (np.dtype(np.uint32), np.dtype(np.uint64)):
+                pos = np.ascontiguousarray(pos).view(np.int32 if pos.dtype.itemsize == 4 else np.int64)
+            elif pos.dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+                raise TypeError("feed_reads with the strand packed into the top bit takes 32- or 64-bit positions, not %s" % pos.dtype)
+            pos = np.ascontiguousarray(pos)
             rev = None
         else:
+            pos = self._int_array(pos, "pos")
             rev = np.ascontiguousarray(is_reverse)
             if rev.dtype != np.uint8:
                 rev = rev.view(np.uint8) if rev.dtype == np.bool_ else rev.astype(np.uint8)

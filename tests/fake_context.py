@@ -118,7 +118,11 @@ class FakeContext:
     def feed_reads(self, d_F, d_R, nbits, pos, readlen, is_reverse, reads_before, d_state):
         F, R, st = self._mem[d_F], self._mem[d_R], self._mem[d_state]
         pos = np.asarray(pos)
-        if is_reverse is None:            # strand packed into the top bit
+        if is_reverse is None:            # strand packed into the top bit (the width rules of ffi.Context.feed_reads)
+            if pos.dtype in (np.dtype(np.uint32), np.dtype(np.uint64)):
+                pos = pos.view(np.int32 if pos.dtype.itemsize == 4 else np.int64)
+            elif pos.dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+                raise TypeError("packed strand needs 32- or 64-bit positions")
             is_reverse = pos < 0
             pos = pos & ((1 << (8 * pos.dtype.itemsize - 1)) - 1)
         pos, rev = pos.tolist(), np.asarray(is_reverse).astype(bool).tolist()
@@ -155,6 +159,10 @@ class FakeContext:
         st[ffi.PMX_FEED_LAST_FORWARD_POS] = last_f
         st[ffi.PMX_FEED_READS] += np.uint64(len(pos))
         return pos, readlen, rev
+
+    def feed_reads_delta16(self, d_F, d_R, nbits, reads, readlen, reads_before, d_state):
+        pos, rev = ffi.unpack_delta16(reads)
+        return self.feed_reads(d_F, d_R, nbits, pos, readlen, rev, reads_before, d_state)
 
     def bits_set_regions_async(self, p, nbits, first, last, first_offset=0, d_state=None):
         w = self._mem[p]

@@ -271,3 +271,91 @@ def test_mappable_len_batch_matches_oracle(ctx, max_shift):
         np.testing.assert_array_equal(got.astype(np.int64), oracle.mappable_len_readless(M, n, max_shift).astype(np.int64))
     for d in dM + dO:
         ctx.bits_free(d)
+
+
+# ---- the two-bytes-per-read form (pmx_feed_reads_delta16): the same cases through ffi.pack_delta16 --------------------
+def device_feed_delta16(ctx, pos, rlen, rev, nbits, cuts, ldt, pinned=False):
+    d_F, d_R = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits)
+    d_st = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    keep, fed = [], 0
+    for a, b in zip([0] + cuts, cuts + [pos.size]):
+        if b > a:
+            reads = ffi.pack_delta16(pos[a:b], rev[a:b], ctx if pinned else None)
+            keep.append(ctx.feed_reads_delta16(d_F, d_R, nbits, reads, rlen[a:b].astype(ldt) if ldt else int(rlen[0]), fed, d_st))
+            fed += b - a
+    F, R = ctx.bits_download(d_F, nbits), ctx.bits_download(d_R, nbits)
+    st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+    for d in (d_F, d_R, d_st):
+        ctx.bits_free(d)
+    return F, R, st
+
+
+@pytest.mark.parametrize("ldt", [np.uint16, np.int32, np.int64])
+@pytest.mark.parametrize("nchunks", [1, 2, 7])
+def test_delta16_feed_matches_the_reference_rules(ctx, nchunks, ldt):
+    S, L, glen = 300, 36, 200000
+    rng = np.random.default_rng(900 * nchunks + np.dtype(ldt).itemsize)
+    pos, rlen, rev = make_reads(rng, 30000, glen, lens=(20, 36, 36, 36, 50, 101))
+    pos[:3] = 0
+    pos.sort()
+    wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
+    cuts = sorted(rng.choice(np.arange(1, pos.size), size=nchunks - 1, replace=False).tolist()) if nchunks > 1 else []
+    F, R, st = device_feed_delta16(ctx, pos, rlen, rev, nbits, cuts, ldt, pinned=(nchunks == 2))
+    np.testing.assert_array_equal(F, wF)
+    np.testing.assert_array_equal(R, wR)
+    assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+    assert int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0 and int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 0
+    assert int(st[ffi.PMX_FEED_READS]) == pos.size and int(st[ffi.PMX_FEED_LAST_POS]) == int(pos[-1])
+
+
+def test_delta16_segments_at_wide_gaps_and_inside_runs_of_equal_positions(ctx):
+    """Gaps of 32766 / 32767 / 32768 / 10^6 bp between neighbours (the distance field holds 32766 at most), runs of equal
+    positions across segment boundaries (every 4096 reads), chunk cuts inside them, one read length for the run."""
+    S, L, glen = 100, 36, 30_000_000
+    rng = np.random.default_rng(31)
+    parts, at = [], 1
+    for gap in (32766, 32767, 32768, 1_000_000, 5, 32767, 70000):
+        n = int(rng.integers(3000, 9000))
+        p = at + np.sort(rng.integers(0, 4000, size=n))
+        p[rng.random(n) < 0.4] = at + 1777                      # a pile-up: thousands of reads at one position
+        p = np.sort(p)
+        p[0] = at                                                  # (the gap to the part before is exact)
+        parts.append(p)
+        at = int(parts[-1][-1]) + gap
+    pos = np.concatenate(parts).astype(np.int64)
+    rlen = np.full(pos.size, 36, dtype=np.int64)
+    rev = rng.random(pos.size) < 0.5
+    d = np.diff(pos)
+    assert set((32766, 32767, 32768, 1_000_000)) <= set(d.tolist())
+    wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
+    cuts = [4095, 4096, 4097, 8192, 20000]
+    F, R, st = device_feed_delta16(ctx, pos, rlen, rev, nbits, cuts, None)
+    np.testing.assert_array_equal(F, wF)
+    np.testing.assert_array_equal(R, wR)
+    assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+    assert int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0 and int(st[ffi.PMX_FEED_LAST_POS]) == int(pos[-1])
+
+
+def test_delta16_reports_a_run_that_starts_below_the_reads_fed_before_and_a_read_beyond_the_vector(ctx):
+    S, L, glen = 100, 36, 50000
+    nbits = glen + L + S + 100
+    rng = np.random.default_rng(5)
+    pos, rlen, rev = make_reads(rng, 6000, glen)
+    # second run begins below the end of the first one: its first read is the offender (mscc.pyx:362-363)
+    a, b = pos[:3000].copy(), pos[2000:5000].copy()
+    d_F, d_R, d_st = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits), ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    k1 = ctx.feed_reads_delta16(d_F, d_R, nbits, ffi.pack_delta16(a, rev[:3000]), 36, 0, d_st)
+    k2 = ctx.feed_reads_delta16(d_F, d_R, nbits, ffi.pack_delta16(b, rev[2000:5000]), 36, 3000, d_st)
+    st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+    assert ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 3000
+    for d in (d_F, d_R, d_st):
+        ctx.bits_free(d)
+    pos[-2:] = nbits + 5
+    rev[-2:] = False
+    F, R, st = device_feed_delta16(ctx, pos, rlen, rev, nbits, [2500], np.int64)
+    assert ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == pos.size - 2
+    with pytest.raises(ffi.PmxError):          # a segment table that does not end with n
+        bad = ffi.pack_delta16(pos[:100], rev[:100])
+        bad.seg_start[-1] = 99
+        ctx.feed_reads_delta16(ctx.bits_alloc(nbits), ctx.bits_alloc(nbits), nbits, bad, 36, 0, ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64))
+    del k1, k2
