@@ -510,6 +510,8 @@ def main():
             def calc_step():
                 t0 = time.perf_counter()
                 calc = CCHipCalculator(S, L, names, lens, bwfeeder=TrackFeeder(tracks) if with_m else None, context=ctx)
+                if os.environ.get("BENCH_EARLY_BATCH"):      # (A/B: launch the kernels of every N queued chromosomes during the feed)
+                    calc.early_batch = int(os.environ["BENCH_EARLY_BATCH"])
                 tc = time.perf_counter()
                 for v in vecs:
                     calc.feed_reads(v.name, *reads[v.name])
@@ -531,6 +533,7 @@ def main():
                 stamps.append((tc - t0, t1 - tc, tf - t1, t2 - tf, time.perf_counter() - t2))
                 return whole
             calc_step()
+            calc_step()     # (two untimed genomes: staging slots and vector pool have reached their sizes)
             fence()
             if os.environ.get("BENCH_CALC_PROFILE"):      # where the host time of the calculator leg goes (stderr)
                 import cProfile

@@ -158,17 +158,26 @@ int pmx_host_free(pmx_ctx *ctx, void *h);
 int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *h_pos, uint32_t pos_bytes,
                    const void *h_readlen, uint32_t len_bytes, const uint8_t *h_is_reverse, uint64_t n,
                    uint64_t reads_before, uint64_t *d_state);
+/* The same with flags.  PMX_FEED_WHOLE_VECTORS: this run is the FIRST of its chromosome (reads_before = 0) and d_F / d_R
+ * need not be cleared -- the call writes EVERY word of both vectors: the words are dealt to workgroups, each finds the
+ * reads of its words in the sorted run and stores them whole, instead of one atomic OR per read into cleared vectors
+ * (round 4: the kernels of the feed, not the PCIe copy, paced a genome).  Same rules, same state words.  Later runs of
+ * the chromosome are fed without the flag. */
+#define PMX_FEED_WHOLE_VECTORS 1u
+int pmx_feed_reads_ex(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *h_pos, uint32_t pos_bytes,
+                      const void *h_readlen, uint32_t len_bytes, const uint8_t *h_is_reverse, uint64_t n,
+                      uint64_t reads_before, uint64_t *d_state, uint32_t flags);
 /* The same run of reads in TWO bytes per read (round 4: the feed of a genome is a PCIe copy, and the reads of a sorted BAM
  * lie ~100 bp apart): h_words[i] = strand in bit 15 (set: reverse), distance to the position of read i - 1 in bits 0..14.
- * The run is cut into nseg SEGMENTS of 1..4096 reads: h_seg_start[s] = index of the first read of segment s
+ * The run is cut into nseg SEGMENTS of 1..1024 reads: h_seg_start[s] = index of the first read of segment s
  * (h_seg_start[0] = 0, h_seg_start[nseg] = n), h_seg_base[s] = its absolute 1-based position (its distance field is 0); a
- * new segment begins at least every 4096 reads and wherever two neighbours lie 32767 bp or more apart.  Read lengths as
+ * new segment begins at least every 1024 reads and wherever two neighbours lie 32767 bp or more apart.  Read lengths as
  * for pmx_feed_reads.  nbits < 2^31 (32-bit positions: what a BAM file can hold, SAMv1 4.2).  The device expands the
- * words to positions (one workgroup per segment) and applies the rules of feed_forward_read / feed_reverse_read
- * (mscc.pyx:370-418) exactly as pmx_feed_reads does.  Asynchronous. */
+ * words to positions (one wavefront per segment) and applies the rules of feed_forward_read / feed_reverse_read
+ * (mscc.pyx:370-418) exactly as pmx_feed_reads does.  flags: PMX_FEED_WHOLE_VECTORS (above) or 0.  Asynchronous. */
 int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const uint16_t *h_words, uint64_t n,
                            const uint32_t *h_seg_start, const int32_t *h_seg_base, uint32_t nseg, const void *h_readlen,
-                           uint32_t len_bytes, uint64_t reads_before, uint64_t *d_state);
+                           uint32_t len_bytes, uint64_t reads_before, uint64_t *d_state, uint32_t flags);
 /* _load_mappability's loop (mscc.pyx:343-344): set(h_first[i] + first_offset, h_last[i]) for n intervals, ends inclusive
  * (BigWig (begin, end) pairs: first_offset = 1).  width_bytes: 4 (uint32) or 8 (int64).  An interval outside [0, nbits) is
  * clipped and recorded in d_state[PMX_FEED_FIRST_OUT_OF_RANGE] (d_state may be NULL).  Asynchronous. */

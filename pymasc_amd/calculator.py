@@ -240,10 +240,12 @@ class CCHipCalculator:
         if self.logger_lock:
             self.logger_lock.release()
 
-    def _vector(self, nbits: int):
-        """(pointer, pool capacity) of a zeroed HBM bit-vector of >= nbits (the clear is queued on the stream)."""
+    def _vector(self, nbits: int, clear: bool = True):
+        """(pointer, pool capacity) of a zeroed HBM bit-vector of >= nbits (the clear is queued on the stream; clear=False: the
+        caller's next kernel writes every word of it)."""
         ptr, cap = self._ctx.pool_alloc(nbits)
-        self._ctx.bits_clear(ptr, nbits)
+        if clear:
+            self._ctx.bits_clear(ptr, nbits)
         self._resident_bytes += cap // 8
         return ptr, cap
 
@@ -305,20 +307,25 @@ class CCHipCalculator:
         self._check_pos(chrom, pos, pos + readlen - 1, "reverse")
         self._buf.append(pos, readlen, 1)
 
-    def _start_chromosome_on_device(self):
+    def _start_chromosome_on_device(self, clear: bool = True) -> bool:
+        """Slot + F / R vectors of the current chromosome; True if they were taken just now.  clear=False: the vectors are
+        handed out as the pool left them, for a first run that writes every word (PMX_FEED_WHOLE_VECTORS)."""
         if self._cur_slot < 0:
             self._cur_slot = self._new_slot()
-            self._cur_vecs = [self._vector(self._cur_nbits), self._vector(self._cur_nbits)]
+            self._cur_vecs = [self._vector(self._cur_nbits, clear), self._vector(self._cur_nbits, clear)]
             self._d_f, self._d_r = self._cur_vecs[0][0], self._cur_vecs[1][0]
+            return True
+        return False
 
     def _to_device(self, pos: np.ndarray, readlen: np.ndarray, rev: np.ndarray):
         """Queues a run of reads of the current chromosome: copy + the reference's duplicate rules + bit set on the device
         (pmx_feed_reads).  Nothing is read back here."""
         if pos.size == 0:
             return
-        self._start_chromosome_on_device()
+        # the first run of a chromosome writes every word of its vectors itself (no clear, no atomics: k_feed_build)
+        fresh = self._start_chromosome_on_device(clear=False)
         self._inflight.append(self._ctx.feed_reads(self._d_f, self._d_r, self._cur_nbits, pos, readlen, rev, self._fed,
-                                                   self._state_ptr(self._cur_slot)))
+                                                   self._state_ptr(self._cur_slot), whole_vectors=fresh))
         self._fed += int(pos.size)
 
     def feed_reads(self, chrom: str, pos: np.ndarray, readlen: np.ndarray, is_reverse: Optional[np.ndarray]) -> None:
@@ -338,10 +345,10 @@ class CCHipCalculator:
             self._check_pos(chrom, pos.first_pos)
             if self._buf.n:
                 self._to_device(*self._buf.take())
-            self._start_chromosome_on_device()
+            fresh = self._start_chromosome_on_device(clear=False)
             self._inflight.append(self._ctx.feed_reads_delta16(self._d_f, self._d_r, self._cur_nbits, pos,
                                                                readlen if np.ndim(readlen) == 0 else np.asarray(readlen),
-                                                               self._fed, self._state_ptr(self._cur_slot)))
+                                                               self._fed, self._state_ptr(self._cur_slot), whole_vectors=fresh))
             self._fed += pos.size
             self._last_pos = max(self._last_pos, pos.last_pos)
             return

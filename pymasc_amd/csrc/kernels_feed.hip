@@ -235,14 +235,240 @@ static int feed_grid(pmx_ctx *ctx, uint64_t items, int per_block, int per_cu = 8
     return (int)blocks;
 }
 
+// ---- the FIRST run of a chromosome, owner-computes (round 4) ----
+// k_feed_reads sets one bit per read with a 64-bit atomic OR: reads lie ~200 bp apart per strand, so every atomic is a
+// memory-side operation on a line of its own -- 57 us for chromosome 1's 1.3 M reads, plus 15 us for the reverse bits
+// (k_feed_finish) and 2 x 6 us to clear the two vectors first: the feed of a genome was paced by these kernels, not by the
+// PCIe copy (rocprofv3, round 4).  When a run is the first of its chromosome -- the common case: a reader hands over a
+// chromosome at a time -- the vectors hold nothing yet, and the work can be dealt by WORDS instead of by reads:
+// a workgroup owns FB_WORDS words of F and of R, finds the reads whose bits fall into them (the run is sorted: two
+// searches, 64 probes per round), applies the reference's rules to them exactly as k_feed_reads does, sets the bits in
+// LDS and writes its words with plain 16-byte stores -- EVERY word of both vectors is written, so the caller does not
+// clear them.  Sortedness / range errors are found by index slices (every read is looked at once whatever the order),
+// per-workgroup sums go to `partial` and k_feed_build_finish adds them to the chromosome's state (thousands of
+// workgroups adding to seven words would serialise).  An unsorted run leaves vectors of no use, as in the reference (it
+// raises at the first such read, mscc.pyx:362-363); the error word is exact.
+#define FB_WORDS 1024u
+#define FB_PART 8u
+
+// first index i in [0, n] with pos[i] >= target (sorted run); all 64 lanes of a wave call this together
+template <typename PT>
+__device__ __forceinline__ uint64_t feed_lower_bound(const PT *__restrict__ pos, uint64_t n, int64_t target, bool packed, u32 lane)
+{
+    uint64_t lo = 0, hi = n;   // the answer lies in [lo, hi]
+    while (hi - lo > 64) {
+        const uint64_t step = (hi - lo + 63) / 64;
+        const uint64_t probe = lo + (uint64_t)lane * step;
+        const bool below = probe < hi && feed_ld(pos, probe, packed) < target;
+        const u32 cnt = (u32)__popcll(__ballot(below));   // (sorted: the probes below the target are the first cnt)
+        if (cnt == 0) {
+            hi = lo;
+            break;
+        }
+        const uint64_t nhi = lo + (uint64_t)cnt * step;
+        lo = lo + (uint64_t)(cnt - 1) * step + 1;
+        hi = nhi < hi ? nhi : hi;
+    }
+    const uint64_t i = lo + lane;
+    const bool below = i < hi && feed_ld(pos, i, packed) < target;
+    return lo + (uint64_t)__popcll(__ballot(below));
+}
+
+template <typename PT, typename LT>
+__global__ void __launch_bounds__(256) k_feed_build(const PT *__restrict__ pos, const LT *__restrict__ rlen, int64_t ulen,
+                                                    const unsigned char *__restrict__ rev, uint64_t n, uint64_t base, uint64_t nbits,
+                                                    u64 *__restrict__ F, u64 *__restrict__ R, const u64 *__restrict__ state,
+                                                    u64 *__restrict__ partial)
+{
+    __shared__ __align__(16) u64 sF[FB_WORDS];
+    __shared__ __align__(16) u64 sR[FB_WORDS];
+    __shared__ uint64_t s_idx[2];
+    __shared__ u64 part[4][FB_PART];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const bool packed = rev == nullptr;
+    const uint64_t nwords = (nbits + 63) / 64;
+    const uint64_t w0 = (uint64_t)blockIdx.x * FB_WORDS;
+    const uint64_t w1 = w0 + FB_WORDS < nwords ? w0 + FB_WORDS : nwords;
+    const int64_t lo = (int64_t)(w0 * 64), hi = (int64_t)(w1 * 64);
+    const int64_t prev_last = base ? (int64_t)state[PMX_FEED_LAST_POS] : 0;
+    const int64_t prev_fwd = (int64_t)state[PMX_FEED_LAST_FORWARD_POS];
+    int64_t maxlen = (int64_t)state[PMX_FEED_MAX_REVERSE_LEN];
+    if (!rlen && ulen > maxlen) maxlen = ulen;
+    if (maxlen < 1) maxlen = 1;
+    for (u32 i = tid; i < FB_WORDS; i += 256) {
+        sF[i] = 0;
+        sR[i] = 0;
+    }
+    // the reads whose bit can fall into [lo, hi): forward bit = pos, reverse bit = pos + len - 1, len <= maxlen
+    if (wv < 2) {
+        const uint64_t idx = feed_lower_bound(pos, n, wv == 0 ? lo - maxlen + 1 : hi, packed, lane);
+        if (lane == 0) s_idx[wv] = idx;
+    }
+    __syncthreads();
+    const uint64_t i_lo = s_idx[0], i_hi = s_idx[1];
+    u64 fsum = 0, rsum = 0, nf = 0, nr = 0, maxf = 0, e_sort = 0, e_range = 0;
+    bool any_f = false;
+    for (uint64_t i = i_lo + tid; i < i_hi; i += 256) {
+        const int64_t p = feed_ld(pos, i, packed), l = feed_len(rlen, ulen, i);
+        const bool rv = feed_rev(pos, rev, i);
+        const int64_t bit = rv ? p + l - 1 : p;
+        if (bit < lo || bit >= hi || (uint64_t)bit >= nbits) continue;   // another workgroup's read (or out of range: dropped)
+        const u64 mask = 1ull << (bit & 63);
+        const u32 w = (u32)(((uint64_t)bit >> 6) - w0);
+        if (!rv) {
+            // duplicate: an earlier forward read at this position (mscc.pyx:388-392; k_feed_reads)
+            bool dup = p == prev_fwd;
+            for (uint64_t j = i; !dup && j > 0 && feed_ld(pos, j - 1, packed) == p; j--) dup = !feed_rev(pos, rev, j - 1);
+            if (!dup) {
+                fsum += (u64)l;
+                nf++;
+                atomicOr(&sF[w], mask);
+            }
+        } else {
+            // counts iff its bit is clear: nothing was set before this run (the first of the chromosome), so only an earlier
+            // read of the run can have set it (mscc.pyx:416-418; the look-back of k_feed_reads)
+            bool set = false;
+            const int64_t lowest = bit - maxlen + 1;
+            for (uint64_t j = i; !set && j > 0; j--) {
+                const int64_t pj = feed_ld(pos, j - 1, packed);
+                if (pj < lowest) break;
+                set = feed_rev(pos, rev, j - 1) && pj + feed_len(rlen, ulen, j - 1) - 1 == bit;
+            }
+            if (!set) {
+                rsum += (u64)l;
+                nr++;
+            }
+            atomicOr(&sR[w], mask);
+        }
+    }
+    // every read once, by index: order against its predecessor, range, the last forward position of the run
+    {
+        const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+        const uint64_t a = (uint64_t)blockIdx.x * per, b = a + per < n ? a + per : n;
+        for (uint64_t i = a + tid; i < b; i += 256) {
+            const int64_t p = feed_ld(pos, i, packed), l = feed_len(rlen, ulen, i);
+            const bool rv = feed_rev(pos, rev, i);
+            const int64_t before = i ? feed_ld(pos, i - 1, packed) : prev_last;
+            if (p < before) {
+                const u64 code = FEED_ERR_BASE - (base + i);
+                e_sort = code > e_sort ? code : e_sort;
+            }
+            const int64_t bit = rv ? p + l - 1 : p;
+            if (bit < 0 || (uint64_t)bit >= nbits) {
+                const u64 code = FEED_ERR_BASE - (base + i);
+                e_range = code > e_range ? code : e_range;
+                continue;
+            }
+            if (!rv) {
+                any_f = true;
+                if ((u64)p > maxf) maxf = (u64)p;
+            }
+        }
+    }
+    __syncthreads();
+    // my words, whole: the vectors need not have been cleared
+    {
+        const u32 cnt = (u32)(w1 - w0);
+        uint4 *dF = reinterpret_cast<uint4 *>(F + w0), *dR = reinterpret_cast<uint4 *>(R + w0);
+        const uint4 *qF = reinterpret_cast<const uint4 *>(sF), *qR = reinterpret_cast<const uint4 *>(sR);
+        for (u32 i = tid; i < cnt / 2; i += 256) {
+            dF[i] = qF[i];
+            dR[i] = qR[i];
+        }
+        if ((cnt & 1u) && tid == 0) {
+            F[w0 + cnt - 1] = sF[cnt - 1];
+            R[w0 + cnt - 1] = sR[cnt - 1];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        fsum += __shfl_down(fsum, off, 64);
+        rsum += __shfl_down(rsum, off, 64);
+        nf += __shfl_down(nf, off, 64);
+        nr += __shfl_down(nr, off, 64);
+        const u64 a = __shfl_down(maxf, off, 64), b = __shfl_down(e_sort, off, 64), c = __shfl_down(e_range, off, 64);
+        maxf = a > maxf ? a : maxf;
+        e_sort = b > e_sort ? b : e_sort;
+        e_range = c > e_range ? c : e_range;
+    }
+    const bool wave_any_f = __ballot(any_f) != 0;
+    if (lane == 0) {
+        part[wv][0] = fsum;
+        part[wv][1] = rsum;
+        part[wv][2] = nf;
+        part[wv][3] = nr;
+        part[wv][4] = wave_any_f ? maxf + 1 : 0;
+        part[wv][5] = e_sort;
+        part[wv][6] = e_range;
+    }
+    __syncthreads();
+    if (tid < 7) {
+        u64 v = part[0][tid];
+        for (int w = 1; w < 4; w++) v = tid < 4 ? v + part[w][tid] : (part[w][tid] > v ? part[w][tid] : v);
+        partial[(size_t)blockIdx.x * FB_PART + tid] = v;
+    }
+}
+
+template <typename PT>
+__global__ void __launch_bounds__(1024) k_feed_build_finish(const u64 *__restrict__ partial, u32 nblocks, const PT *__restrict__ pos,
+                                                            bool packed, uint64_t n, int64_t ulen, bool uniform, u64 *__restrict__ state)
+{
+    __shared__ u64 acc[16][FB_PART];
+    const u32 tid = threadIdx.x, k = tid & 7u, g = tid >> 3;   // 128 groups of eight: one word each (seven used)
+    u64 v = 0;
+    if (k < 7)
+        for (u32 b = g; b < nblocks; b += 128) {
+            const u64 x = partial[(size_t)b * FB_PART + k];
+            v = k < 4 ? v + x : (x > v ? x : v);
+        }
+    // groups g, g + 8, ... share a lane residue: fold the 8 groups of a wave, then the 16 waves
+    for (int off = 32; off >= 8; off >>= 1) {
+        const u64 o = __shfl_down(v, off, 64);
+        v = k < 4 ? v + o : (o > v ? o : v);
+    }
+    if ((tid & 63u) < 8) acc[tid >> 6][k] = v;
+    __syncthreads();
+    if (tid < 7) {
+        u64 t = acc[0][tid];
+        for (u32 w = 1; w < 16; w++) t = tid < 4 ? t + acc[w][tid] : (acc[w][tid] > t ? acc[w][tid] : t);
+        if (tid == 0) state[PMX_FEED_FORWARD_LEN_SUM] += t;
+        else if (tid == 1) state[PMX_FEED_REVERSE_LEN_SUM] += t;
+        else if (tid == 2) state[PMX_FEED_FORWARD_KEPT] += t;
+        else if (tid == 3) state[PMX_FEED_REVERSE_KEPT] += t;
+        else if (tid == 4) {
+            if (t) state[PMX_FEED_LAST_FORWARD_POS] = t - 1;
+        } else if (tid == 5) {
+            if (t > state[PMX_FEED_FIRST_UNSORTED]) state[PMX_FEED_FIRST_UNSORTED] = t;
+        } else if (t > state[PMX_FEED_FIRST_OUT_OF_RANGE]) state[PMX_FEED_FIRST_OUT_OF_RANGE] = t;
+    }
+    if (tid == 1023) {
+        const int64_t last = feed_ld(pos, n - 1, packed);
+        state[PMX_FEED_LAST_POS] = last < 0 ? 0 : (u64)last;
+        state[PMX_FEED_READS] += n;
+        if (uniform && ulen > 0 && (u64)ulen > state[PMX_FEED_MAX_REVERSE_LEN]) state[PMX_FEED_MAX_REVERSE_LEN] = (u64)ulen;
+    }
+}
+
+// workgroups of k_feed_build for a vector of nbits (and the words of `partial` it needs: FB_PART per workgroup)
+uint32_t pmx_feed_build_blocks(uint64_t nbits) { return (uint32_t)(((nbits + 63) / 64 + FB_WORDS - 1) / FB_WORDS); }
+
 template <typename PT, typename LT>
 static int launch_feed(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *d_pos, const void *d_len,
-                       int64_t ulen, const unsigned char *d_rev, uint64_t n, uint64_t base, u64 *d_state)
+                       int64_t ulen, const unsigned char *d_rev, uint64_t n, uint64_t base, u64 *d_state, u64 *d_partial)
 {
     const int g = feed_grid(ctx, n, 1024, 4);   // (every block ends in a few atomics on the state words)
     if (d_len) {   // (a run of one read length carries its bound in `ulen`)
         hipLaunchKernelGGL(k_feed_maxlen<LT>, dim3(g), dim3(256), 0, ctx->stream, (const LT *)d_len, ulen, d_rev, n, d_state);
         PMX_CHECK_LAUNCH("k_feed_maxlen");
+    }
+    if (d_partial) {   // the first run of the chromosome: every word of F and R written by its owner (k_feed_build)
+        const u32 nb = pmx_feed_build_blocks(nbits);
+        hipLaunchKernelGGL((k_feed_build<PT, LT>), dim3(nb), dim3(256), 0, ctx->stream, (const PT *)d_pos, (const LT *)d_len, ulen, d_rev,
+                           n, base, nbits, (u64 *)d_F, (u64 *)d_R, (const u64 *)d_state, d_partial);
+        PMX_CHECK_LAUNCH("k_feed_build");
+        hipLaunchKernelGGL(k_feed_build_finish<PT>, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)d_partial, nb, (const PT *)d_pos,
+                           d_rev == nullptr, n, ulen, d_len == nullptr, d_state);
+        PMX_CHECK_LAUNCH("k_feed_build_finish");
+        return PMX_OK;
     }
     hipLaunchKernelGGL((k_feed_reads<PT, LT>), dim3(g), dim3(256), 0, ctx->stream, (const PT *)d_pos, (const LT *)d_len, ulen, d_rev, n,
                        base, nbits, (u64 *)d_F, (const u64 *)d_R, d_state);
@@ -255,12 +481,12 @@ static int launch_feed(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbit
 
 int pmx_launch_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *d_pos, uint32_t pos_bytes,
                           const void *d_len, uint32_t len_bytes, int64_t uniform_len, const unsigned char *d_rev, uint64_t n,
-                          uint64_t base, uint64_t *d_state)
+                          uint64_t base, uint64_t *d_state, uint64_t *d_partial)
 {
     if (n == 0) return PMX_OK;
     u64 *st = (u64 *)d_state;
     if (len_bytes == 0) d_len = nullptr;     // one length for every read
-#define FEED(PT, LT) return launch_feed<PT, LT>(ctx, d_F, d_R, nbits, d_pos, d_len, uniform_len, d_rev, n, base, st)
+#define FEED(PT, LT) return launch_feed<PT, LT>(ctx, d_F, d_R, nbits, d_pos, d_len, uniform_len, d_rev, n, base, st, (u64 *)d_partial)
     if (pos_bytes == 4 && (len_bytes == 4 || len_bytes == 0)) FEED(int32_t, int32_t);
     if (pos_bytes == 8 && (len_bytes == 8 || len_bytes == 0)) FEED(int64_t, int64_t);
     if (pos_bytes == 4 && len_bytes == 2) FEED(int32_t, uint16_t);
@@ -278,34 +504,30 @@ int pmx_launch_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t n
 // two neighbours lie 32767 bp or more apart --, each with the absolute position of its first read in a table (that read's
 // distance field is 0): one workgroup expands a segment with one block scan, nothing is carried between workgroups.
 // Output: the 4-bytes-per-read form k_feed_reads takes (int32 position, strand in the top bit).
-#define FEED_SEG_READS 4096u
-__global__ void __launch_bounds__(256) k_feed_expand16(const unsigned short *__restrict__ words, const u32 *__restrict__ seg_start,
-                                                       const int32_t *__restrict__ seg_base, uint64_t n, int32_t *__restrict__ pos)
+#define FEED_SEG_READS 1024u
+__global__ void __launch_bounds__(64) k_feed_expand16(const unsigned short *__restrict__ words, const u32 *__restrict__ seg_start,
+                                                      const int32_t *__restrict__ seg_base, uint64_t n, int32_t *__restrict__ pos)
 {
-    __shared__ u32 wsum[4];
-    const u32 s = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // ONE wavefront per segment (chromosome 1: 1300 segments in flight instead of 320 workgroups of four; no LDS, no barrier)
+    const u32 s = blockIdx.x, lane = threadIdx.x;
     const u32 i0 = seg_start[s], i1 = seg_start[s + 1];      // (the table ends with n)
     const u32 cnt = i1 > i0 ? i1 - i0 : 0u;
     if (cnt == 0 || cnt > FEED_SEG_READS || i1 > n) return;   // (a malformed table is caught on the host; never index beyond n)
-    // 16 consecutive reads per thread
-    const u32 k0 = 16 * tid;
+    // 16 consecutive reads per lane
+    const u32 k0 = 16 * lane;
     u32 w[16], run = 0;
 #pragma unroll
     for (u32 k = 0; k < 16; k++) {
         w[k] = k0 + k < cnt ? (u32)words[i0 + k0 + k] : 0u;
         run += w[k] & 0x7fffu;
     }
-    u32 x = run;   // inclusive scan of the thread sums over the workgroup
+    u32 x = run;   // inclusive scan of the lane sums
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const u32 y = __shfl_up(x, off, 64);
         if (lane >= (u32)off) x += y;
     }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    u32 before = x - run;
-    for (u32 v = 0; v < wave; v++) before += wsum[v];
-    u32 p = (u32)seg_base[s] + before;
+    u32 p = (u32)seg_base[s] + x - run;
 #pragma unroll
     for (u32 k = 0; k < 16; k++) {
         p += w[k] & 0x7fffu;
@@ -317,7 +539,7 @@ int pmx_launch_feed_expand16(pmx_ctx *ctx, const void *d_words, const void *d_se
                              uint64_t n, void *d_pos32)
 {
     if (n == 0 || nseg == 0) return PMX_OK;
-    hipLaunchKernelGGL(k_feed_expand16, dim3(nseg), dim3(256), 0, ctx->stream, (const unsigned short *)d_words, (const u32 *)d_seg_start,
+    hipLaunchKernelGGL(k_feed_expand16, dim3(nseg), dim3(64), 0, ctx->stream, (const unsigned short *)d_words, (const u32 *)d_seg_start,
                        (const int32_t *)d_seg_base, n, (int32_t *)d_pos32);
     PMX_CHECK_LAUNCH("k_feed_expand16");
     return PMX_OK;

@@ -791,7 +791,22 @@ int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, c
                    const void *h_readlen, uint32_t len_bytes, const uint8_t *h_is_reverse, uint64_t n,
                    uint64_t reads_before, uint64_t *d_state)
 {
+    return pmx_feed_reads_ex(ctx, d_F, d_R, nbits, h_pos, pos_bytes, h_readlen, len_bytes, h_is_reverse, n, reads_before, d_state, 0);
+}
+
+int pmx_feed_reads_ex(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *h_pos, uint32_t pos_bytes,
+                      const void *h_readlen, uint32_t len_bytes, const uint8_t *h_is_reverse, uint64_t n,
+                      uint64_t reads_before, uint64_t *d_state, uint32_t flags)
+{
     if (ctx) (void)hipSetDevice(ctx->device);
+    const bool whole = (flags & PMX_FEED_WHOLE_VECTORS) != 0;
+    REQUIRE(!whole || reads_before == 0, "pmx_feed_reads_ex: PMX_FEED_WHOLE_VECTORS is for the first run of a chromosome (reads_before = 0)");
+    if (whole && n == 0) {   // nothing to set: the promise is still that every word is written
+        REQUIRE(ctx && d_F && d_R, "pmx_feed_reads_ex: NULL argument");
+        PMX_HIP(hipMemsetAsync(d_F, 0, words_for(nbits) * sizeof(uint64_t), ctx->stream));
+        PMX_HIP(hipMemsetAsync(d_R, 0, words_for(nbits) * sizeof(uint64_t), ctx->stream));
+        return PMX_OK;
+    }
     REQUIRE(ctx && d_F && d_R && d_state, "pmx_feed_reads: NULL argument");
     REQUIRE(n == 0 || (h_pos && h_readlen), "pmx_feed_reads: NULL read arrays");
     REQUIRE((pos_bytes == 4 || pos_bytes == 8) && (len_bytes == 0 || len_bytes == 2 || len_bytes == 4 || len_bytes == 8),
@@ -800,9 +815,10 @@ int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, c
     if (n == 0) return PMX_OK;
     const int64_t uniform_len = len_bytes == 0 ? *(const int64_t *)h_readlen : 0;   // (read now: the caller's word may be gone later)
     const size_t o_len = align16((size_t)n * pos_bytes), o_rev = o_len + align16((size_t)n * len_bytes);
+    const size_t o_part = o_rev + align16((size_t)n);      // (PMX_FEED_WHOLE_VECTORS: per-workgroup sums of k_feed_build)
     unsigned char *d = nullptr;
     uint32_t slot = 0;
-    int rc = feed_acquire(ctx, o_rev + n, &d, &slot);
+    int rc = feed_acquire(ctx, o_part + (whole ? (size_t)pmx_feed_build_blocks(nbits) * 64 : 0), &d, &slot);
     if (rc) return rc;
     const FeedPart parts[3] = {{0, h_pos, (size_t)n * pos_bytes}, {o_len, len_bytes ? h_readlen : nullptr, (size_t)n * len_bytes},
                                {o_rev, h_is_reverse, (size_t)n}};
@@ -811,16 +827,24 @@ int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, c
     rc = feed_publish(ctx);
     if (rc) return rc;
     rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d, pos_bytes, d + o_len, len_bytes, uniform_len, h_is_reverse ? d + o_rev : nullptr,
-                               n, reads_before, d_state);
+                               n, reads_before, d_state, whole ? (uint64_t *)(d + o_part) : nullptr);
     if (rc) return rc;
     return feed_release(ctx, slot);
 }
 
 int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const uint16_t *h_words, uint64_t n,
                            const uint32_t *h_seg_start, const int32_t *h_seg_base, uint32_t nseg, const void *h_readlen,
-                           uint32_t len_bytes, uint64_t reads_before, uint64_t *d_state)
+                           uint32_t len_bytes, uint64_t reads_before, uint64_t *d_state, uint32_t flags)
 {
     if (ctx) (void)hipSetDevice(ctx->device);
+    const bool whole = (flags & PMX_FEED_WHOLE_VECTORS) != 0;
+    REQUIRE(!whole || reads_before == 0, "pmx_feed_reads_delta16: PMX_FEED_WHOLE_VECTORS is for the first run of a chromosome (reads_before = 0)");
+    if (whole && n == 0) {
+        REQUIRE(ctx && d_F && d_R, "pmx_feed_reads_delta16: NULL argument");
+        PMX_HIP(hipMemsetAsync(d_F, 0, words_for(nbits) * sizeof(uint64_t), ctx->stream));
+        PMX_HIP(hipMemsetAsync(d_R, 0, words_for(nbits) * sizeof(uint64_t), ctx->stream));
+        return PMX_OK;
+    }
     REQUIRE(ctx && d_F && d_R && d_state, "pmx_feed_reads_delta16: NULL argument");
     REQUIRE(n == 0 || (h_words && h_seg_start && h_seg_base && h_readlen && nseg >= 1), "pmx_feed_reads_delta16: NULL read arrays");
     REQUIRE(len_bytes == 0 || len_bytes == 2 || len_bytes == 4 || len_bytes == 8,
@@ -828,19 +852,20 @@ int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t 
     REQUIRE(nbits >= 1 && nbits < (1ull << 31), "pmx_feed_reads_delta16: nbits must be in [1, 2^31) (32-bit positions: what a BAM file holds)");
     REQUIRE(n < (1ull << 32), "pmx_feed_reads_delta16: at most 2^32 - 1 reads per call");
     if (n == 0) return PMX_OK;
-    // the segment table as the kernel will index it: starts increasing from 0, at most 4096 reads each, ends with n
+    // the segment table as the kernel will index it: starts increasing from 0, at most 1024 reads each, ends with n
     // (checked here, on a few hundred words: the kernel never reads beyond the run)
     REQUIRE(h_seg_start[0] == 0 && h_seg_start[nseg] == n, "pmx_feed_reads_delta16: the segment table must start at 0 and end with n");
     for (uint32_t s = 0; s < nseg; s++)
-        REQUIRE(h_seg_start[s + 1] > h_seg_start[s] && h_seg_start[s + 1] - h_seg_start[s] <= 4096u,
-                "pmx_feed_reads_delta16: segments hold 1..4096 reads");
+        REQUIRE(h_seg_start[s + 1] > h_seg_start[s] && h_seg_start[s + 1] - h_seg_start[s] <= 1024u,
+                "pmx_feed_reads_delta16: segments hold 1..1024 reads");
     const int64_t uniform_len = len_bytes == 0 ? *(const int64_t *)h_readlen : 0;
     // slot: [words][segment starts (nseg + 1)][segment bases][read lengths][expanded positions (device only)]
     const size_t o_start = align16((size_t)n * 2), o_base = o_start + align16(((size_t)nseg + 1) * 4);
     const size_t o_len = o_base + align16((size_t)nseg * 4), o_pos = o_len + align16((size_t)n * len_bytes);
+    const size_t o_part = o_pos + align16((size_t)n * 4);
     unsigned char *d = nullptr;
     uint32_t slot = 0;
-    int rc = feed_acquire(ctx, o_pos + (size_t)n * 4, &d, &slot);
+    int rc = feed_acquire(ctx, o_part + (whole ? (size_t)pmx_feed_build_blocks(nbits) * 64 : 0), &d, &slot);
     if (rc) return rc;
     const FeedPart parts[4] = {{0, h_words, (size_t)n * 2}, {o_start, h_seg_start, ((size_t)nseg + 1) * 4}, {o_base, h_seg_base, (size_t)nseg * 4},
                                {o_len, len_bytes ? h_readlen : nullptr, (size_t)n * len_bytes}};
@@ -850,7 +875,8 @@ int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t 
     if (rc) return rc;
     rc = pmx_launch_feed_expand16(ctx, d, d + o_start, d + o_base, nseg, n, d + o_pos);
     if (rc) return rc;
-    rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d + o_pos, 4, d + o_len, len_bytes, uniform_len, nullptr, n, reads_before, d_state);
+    rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d + o_pos, 4, d + o_len, len_bytes, uniform_len, nullptr, n, reads_before, d_state,
+                               whole ? (uint64_t *)(d + o_part) : nullptr);
     if (rc) return rc;
     return feed_release(ctx, slot);
 }

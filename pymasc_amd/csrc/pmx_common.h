@@ -39,7 +39,7 @@ struct pmx_timed_launch {
 };
 
 #ifndef PMX_FEED_SLOTS
-#define PMX_FEED_SLOTS 3
+#define PMX_FEED_SLOTS 6
 #endif
 #define PMX_JOBTAB_SLOTS 8
 
@@ -130,7 +130,8 @@ int pmx_launch_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, u64 
 // stream-ordered feeding (kernels_feed.hip): device arrays in, nothing read back
 int pmx_launch_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *d_pos, uint32_t pos_bytes,
                           const void *d_len, uint32_t len_bytes, int64_t uniform_len, const unsigned char *d_rev, uint64_t n,
-                          uint64_t base, uint64_t *d_state);
+                          uint64_t base, uint64_t *d_state, uint64_t *d_partial = nullptr);   // d_partial: PMX_FEED_WHOLE_VECTORS (k_feed_build)
+uint32_t pmx_feed_build_blocks(uint64_t nbits);
 int pmx_launch_feed_expand16(pmx_ctx *ctx, const void *d_words, const void *d_seg_start, const void *d_seg_base, uint32_t nseg,
                              uint64_t n, void *d_pos32);
 int pmx_launch_set_regions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to, uint32_t width,

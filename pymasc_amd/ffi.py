@@ -34,6 +34,7 @@ PMX_FEED_FORWARD_LEN_SUM, PMX_FEED_REVERSE_LEN_SUM, PMX_FEED_FORWARD_KEPT, PMX_F
 PMX_FEED_FIRST_UNSORTED, PMX_FEED_FIRST_OUT_OF_RANGE, PMX_FEED_LAST_POS, PMX_FEED_LAST_FORWARD_POS = 4, 5, 6, 7
 PMX_FEED_READS, PMX_FEED_MAX_REVERSE_LEN, PMX_FEED_CHUNK_FORWARD_POS, PMX_FEED_WORDS = 8, 9, 10, 16
 PMX_FEED_ERR_BASE = 1 << 62
+PMX_FEED_WHOLE_VECTORS = 1   # pmx_feed_reads_ex / pmx_feed_reads_delta16: the first run of a chromosome writes every word
 PMX_PATH_DENSE = 1
 PMX_PATH_SPARSE = 2
 
@@ -50,7 +51,7 @@ EXPORTS = [
     "pmx_bits_alloc", "pmx_bits_free", "pmx_bits_clear", "pmx_bits_upload", "pmx_bits_download",
     "pmx_bits_set_positions", "pmx_bits_set_positions_dev", "pmx_bits_set_regions", "pmx_bits_set_regions_dev",
     "pmx_bits_count",
-    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_delta16", "pmx_bits_set_regions_async", "pmx_bits_build_batch",
+    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_ex", "pmx_feed_reads_delta16", "pmx_bits_set_regions_async", "pmx_bits_build_batch",
     "pmx_bits_build_status",
     "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
     "pmx_mappable_len_batch_dev",
@@ -100,7 +101,8 @@ def load_library(path: Optional[str] = None):
     L.pmx_host_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
     L.pmx_host_free.argtypes = [vp, vp]
     L.pmx_feed_reads.argtypes = [vp, vp, vp, u64, vp, u32, vp, u32, vp, u64, u64, vp]
-    L.pmx_feed_reads_delta16.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp, u32, vp, u32, u64, vp]
+    L.pmx_feed_reads_delta16.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp, u32, vp, u32, u64, vp, u32]
+    L.pmx_feed_reads_ex.argtypes = [vp, vp, vp, u64, vp, u32, vp, u32, vp, u64, u64, vp, u32]
     L.pmx_bits_set_regions_async.argtypes = [vp, vp, u64, vp, vp, u32, u64, ctypes.c_int64, vp]
     L.pmx_bits_build_batch.argtypes = [vp, u32, vp, u32]
     L.pmx_bits_build_status.argtypes = [vp]
@@ -138,7 +140,7 @@ def pack_strand(pos: np.ndarray, is_reverse: np.ndarray) -> np.ndarray:
     return out
 
 
-DELTA16_SEGMENT_READS = 4096     # include/pymasc_amd.h: pmx_feed_reads_delta16
+DELTA16_SEGMENT_READS = 1024     # include/pymasc_amd.h: pmx_feed_reads_delta16
 DELTA16_MAX_GAP = 32766
 
 
@@ -372,9 +374,11 @@ class Context:
             a = a.astype(np.int64)
         return np.ascontiguousarray(a)
 
-    def feed_reads_delta16(self, d_F: int, d_R: int, nbits: int, reads: "Delta16Reads", readlen, reads_before: int, d_state: int):
-        """pmx_feed_reads_delta16: a run of reads in two bytes per read (pack_delta16).  Returns the arrays handed over: keep
-        them alive until the next synchronising call."""
+    def feed_reads_delta16(self, d_F: int, d_R: int, nbits: int, reads: "Delta16Reads", readlen, reads_before: int, d_state: int,
+                           whole_vectors: bool = False):
+        """pmx_feed_reads_delta16: a run of reads in two bytes per read (pack_delta16).  whole_vectors: PMX_FEED_WHOLE_VECTORS
+        (the first run of the chromosome; the vectors need not be cleared).  Returns the arrays handed over: keep them alive
+        until the next synchronising call."""
         words = np.ascontiguousarray(reads.words, dtype=np.uint16)
         seg_start = np.ascontiguousarray(reads.seg_start, dtype=np.uint32)
         seg_base = np.ascontiguousarray(reads.seg_base, dtype=np.int32)
@@ -388,11 +392,12 @@ class Context:
         assert seg_start.size == seg_base.size + 1
         _check(self._L, self._L.pmx_feed_reads_delta16(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R), int(nbits), words.ctypes.data,
                                                        int(words.size), seg_start.ctypes.data, seg_base.ctypes.data, int(seg_base.size),
-                                                       readlen.ctypes.data, len_bytes, int(reads_before), ctypes.c_void_p(d_state)))
+                                                       readlen.ctypes.data, len_bytes, int(reads_before), ctypes.c_void_p(d_state),
+                                                       PMX_FEED_WHOLE_VECTORS if whole_vectors else 0))
         return words, seg_start, seg_base, readlen
 
     def feed_reads(self, d_F: int, d_R: int, nbits: int, pos: np.ndarray, readlen: np.ndarray, is_reverse: np.ndarray,
-                   reads_before: int, d_state: int):
+                   reads_before: int, d_state: int, whole_vectors: bool = False):
         """pmx_feed_reads: a run of reads of one chromosome in file order (int32 / int64 positions, uint16 / int32 / int64
         read lengths -- or ONE int for a run of reads of the same length --, strand as bool / uint8 -- or is_reverse = None with the strand packed into the top bit of
         every position (pack_strand) --; other integer types are converted).
@@ -420,10 +425,11 @@ class Context:
             len_bytes = readlen.dtype.itemsize
             assert pos.size == readlen.size
         assert rev is None or rev.size == pos.size
-        _check(self._L, self._L.pmx_feed_reads(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R), int(nbits), pos.ctypes.data,
-                                               pos.dtype.itemsize, readlen.ctypes.data, len_bytes,
-                                               rev.ctypes.data if rev is not None else None,
-                                               pos.size, int(reads_before), ctypes.c_void_p(d_state)))
+        _check(self._L, self._L.pmx_feed_reads_ex(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R), int(nbits), pos.ctypes.data,
+                                                  pos.dtype.itemsize, readlen.ctypes.data, len_bytes,
+                                                  rev.ctypes.data if rev is not None else None,
+                                                  pos.size, int(reads_before), ctypes.c_void_p(d_state),
+                                                  PMX_FEED_WHOLE_VECTORS if whole_vectors else 0))
         return pos, readlen, rev
 
     def bits_set_regions_async(self, d_words: int, nbits: int, first: np.ndarray, last: np.ndarray, first_offset: int = 0,

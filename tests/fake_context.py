@@ -54,7 +54,9 @@ class FakeContext:
         self._mem.pop(p, None)
 
     def pool_alloc(self, nbits):
-        return self.bits_alloc(nbits), nbits
+        p = self.bits_alloc(nbits)
+        self._mem[p][:] = np.uint64(0xdeadbeefdeadbeef)     # (the real pool hands vectors out as they were left: never rely on zeros)
+        return p, nbits
 
     def pool_free(self, p, cap):
         self.bits_free(p)
@@ -115,8 +117,12 @@ class FakeContext:
 
     # ---- the stream-ordered feeders (pmx_feed_reads, pmx_bits_set_regions_async, pmx_mappable_len_batch_dev): the reference's
     # per-read rules restated read by read (mscc.pyx:351-418), state words as in include/pymasc_amd.h
-    def feed_reads(self, d_F, d_R, nbits, pos, readlen, is_reverse, reads_before, d_state):
+    def feed_reads(self, d_F, d_R, nbits, pos, readlen, is_reverse, reads_before, d_state, whole_vectors=False):
         F, R, st = self._mem[d_F], self._mem[d_R], self._mem[d_state]
+        if whole_vectors:                 # PMX_FEED_WHOLE_VECTORS: the first run writes every word of both vectors
+            assert reads_before == 0
+            F[:ffi.nwords(nbits)] = 0
+            R[:ffi.nwords(nbits)] = 0
         pos = np.asarray(pos)
         if is_reverse is None:            # strand packed into the top bit (the width rules of ffi.Context.feed_reads)
             if pos.dtype in (np.dtype(np.uint32), np.dtype(np.uint64)):
@@ -160,9 +166,9 @@ class FakeContext:
         st[ffi.PMX_FEED_READS] += np.uint64(len(pos))
         return pos, readlen, rev
 
-    def feed_reads_delta16(self, d_F, d_R, nbits, reads, readlen, reads_before, d_state):
+    def feed_reads_delta16(self, d_F, d_R, nbits, reads, readlen, reads_before, d_state, whole_vectors=False):
         pos, rev = ffi.unpack_delta16(reads)
-        return self.feed_reads(d_F, d_R, nbits, pos, readlen, rev, reads_before, d_state)
+        return self.feed_reads(d_F, d_R, nbits, pos, readlen, rev, reads_before, d_state, whole_vectors)
 
     def bits_set_regions_async(self, p, nbits, first, last, first_offset=0, d_state=None):
         w = self._mem[p]

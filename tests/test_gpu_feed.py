@@ -37,14 +37,24 @@ def reference_feed(pos, rlen, rev, S, L, glen):
     return oc._F, oc._R, oc._f_rls, oc._r_rls, oc._nbits
 
 
-def device_feed(ctx, pos, rlen, rev, nbits, cuts, pdt, ldt):
+def garbage_vectors(ctx, nbits):
+    """F and R as the context's pool may hand them out: full of somebody else's bits (PMX_FEED_WHOLE_VECTORS writes every word)."""
     d_F, d_R = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits)
+    junk = np.full(ffi.nwords(nbits), 0xdeadbeefcafef00d, dtype=np.uint64)
+    ctx.bits_upload(d_F, junk, nbits)
+    ctx.bits_upload(d_R, ~junk, nbits)
+    return d_F, d_R
+
+
+def device_feed(ctx, pos, rlen, rev, nbits, cuts, pdt, ldt, whole=False):
+    d_F, d_R = garbage_vectors(ctx, nbits) if whole else (ctx.bits_alloc(nbits), ctx.bits_alloc(nbits))
     d_st = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
     keep = []
     fed = 0
     for a, b in zip([0] + cuts, cuts + [pos.size]):
         if b > a:
-            keep.append(ctx.feed_reads(d_F, d_R, nbits, pos[a:b].astype(pdt), rlen[a:b].astype(ldt), rev[a:b], fed, d_st))
+            keep.append(ctx.feed_reads(d_F, d_R, nbits, pos[a:b].astype(pdt), rlen[a:b].astype(ldt), rev[a:b], fed, d_st,
+                                       whole_vectors=whole and fed == 0))
             fed += b - a
     F, R = ctx.bits_download(d_F, nbits), ctx.bits_download(d_R, nbits)
     st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
@@ -274,14 +284,15 @@ def test_mappable_len_batch_matches_oracle(ctx, max_shift):
 
 
 # ---- the two-bytes-per-read form (pmx_feed_reads_delta16): the same cases through ffi.pack_delta16 --------------------
-def device_feed_delta16(ctx, pos, rlen, rev, nbits, cuts, ldt, pinned=False):
-    d_F, d_R = ctx.bits_alloc(nbits), ctx.bits_alloc(nbits)
+def device_feed_delta16(ctx, pos, rlen, rev, nbits, cuts, ldt, pinned=False, whole=False):
+    d_F, d_R = garbage_vectors(ctx, nbits) if whole else (ctx.bits_alloc(nbits), ctx.bits_alloc(nbits))
     d_st = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
     keep, fed = [], 0
     for a, b in zip([0] + cuts, cuts + [pos.size]):
         if b > a:
             reads = ffi.pack_delta16(pos[a:b], rev[a:b], ctx if pinned else None)
-            keep.append(ctx.feed_reads_delta16(d_F, d_R, nbits, reads, rlen[a:b].astype(ldt) if ldt else int(rlen[0]), fed, d_st))
+            keep.append(ctx.feed_reads_delta16(d_F, d_R, nbits, reads, rlen[a:b].astype(ldt) if ldt else int(rlen[0]), fed, d_st,
+                                               whole_vectors=whole and fed == 0))
             fed += b - a
     F, R = ctx.bits_download(d_F, nbits), ctx.bits_download(d_R, nbits)
     st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
@@ -310,7 +321,7 @@ def test_delta16_feed_matches_the_reference_rules(ctx, nchunks, ldt):
 
 def test_delta16_segments_at_wide_gaps_and_inside_runs_of_equal_positions(ctx):
     """Gaps of 32766 / 32767 / 32768 / 10^6 bp between neighbours (the distance field holds 32766 at most), runs of equal
-    positions across segment boundaries (every 4096 reads), chunk cuts inside them, one read length for the run."""
+    positions across segment boundaries (every 1024 reads), chunk cuts inside them, one read length for the run."""
     S, L, glen = 100, 36, 30_000_000
     rng = np.random.default_rng(31)
     parts, at = [], 1
@@ -328,7 +339,7 @@ def test_delta16_segments_at_wide_gaps_and_inside_runs_of_equal_positions(ctx):
     d = np.diff(pos)
     assert set((32766, 32767, 32768, 1_000_000)) <= set(d.tolist())
     wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
-    cuts = [4095, 4096, 4097, 8192, 20000]
+    cuts = [1023, 1024, 1025, 4096, 20000]
     F, R, st = device_feed_delta16(ctx, pos, rlen, rev, nbits, cuts, None)
     np.testing.assert_array_equal(F, wF)
     np.testing.assert_array_equal(R, wR)
@@ -359,3 +370,57 @@ def test_delta16_reports_a_run_that_starts_below_the_reads_fed_before_and_a_read
         bad.seg_start[-1] = 99
         ctx.feed_reads_delta16(ctx.bits_alloc(nbits), ctx.bits_alloc(nbits), nbits, bad, 36, 0, ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64))
     del k1, k2
+
+
+# ---- PMX_FEED_WHOLE_VECTORS: the first run of a chromosome writes every word of uncleared vectors (k_feed_build) ----------
+@pytest.mark.parametrize("glen,nreads", [(200000, 30000), (70, 40), (65536 * 3 - 436, 9000), (1_500_000, 200)])
+@pytest.mark.parametrize("nchunks", [1, 3])
+def test_whole_vector_feed_matches_the_reference_rules(ctx, nchunks, glen, nreads):
+    """Vectors full of junk, first run with PMX_FEED_WHOLE_VECTORS (every word written by the workgroup that owns it: words
+    without reads too, the tail of the last word, vectors of one workgroup and of many), later runs the ordinary way."""
+    S, L = 300, 36
+    rng = np.random.default_rng(7000 + nchunks + glen)
+    pos, rlen, rev = make_reads(rng, nreads, glen, lens=(20, 36, 36, 36, 50, 101))
+    pos[:3] = 0
+    pos.sort()
+    wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
+    cuts = sorted(rng.choice(np.arange(1, pos.size), size=nchunks - 1, replace=False).tolist()) if nchunks > 1 else []
+    for fmt in ("pos", "delta16"):
+        if fmt == "pos":
+            F, R, st = device_feed(ctx, pos, rlen, rev, nbits, cuts, np.int32, np.uint16, whole=True)
+        else:
+            F, R, st = device_feed_delta16(ctx, pos, rlen, rev, nbits, cuts, np.int32, whole=True)
+        np.testing.assert_array_equal(F, wF)
+        np.testing.assert_array_equal(R, wR)
+        assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+        popc = lambda w: int(oracle.lib().pmo_count(oracle._p(np.ascontiguousarray(w)), w.size))
+        assert int(st[ffi.PMX_FEED_FORWARD_KEPT]) == popc(wF) and int(st[ffi.PMX_FEED_REVERSE_KEPT]) == popc(wR)
+        assert int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0 and int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 0
+        assert int(st[ffi.PMX_FEED_READS]) == pos.size and int(st[ffi.PMX_FEED_LAST_POS]) == int(pos[-1])
+
+
+def test_whole_vector_feed_pile_ups_and_errors(ctx):
+    """Runs of equal positions with mixed strands and lengths (the look-backs cross workgroup boundaries of the word-wise
+    deal), a chunk cut inside one, then the first unsorted / first out-of-range read of a whole-vector run."""
+    S, L, glen = 100, 36, 500000
+    rng = np.random.default_rng(77)
+    pos = np.sort(rng.integers(1, 80, size=20000)).astype(np.int64) * 5000 + 65500      # pile-ups next to 64-Kbit boundaries
+    rlen = rng.choice(np.asarray([30, 36, 36, 40, 75]), size=pos.size).astype(np.int64)
+    rev = rng.random(pos.size) < 0.5
+    wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
+    F, R, st = device_feed(ctx, pos, rlen, rev, nbits, [9999], np.int64, np.int64, whole=True)
+    np.testing.assert_array_equal(F, wF)
+    np.testing.assert_array_equal(R, wR)
+    assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+    pos, rlen, rev = make_reads(rng, 5000, glen)
+    bad = 3210
+    pos[bad] = pos[bad - 1] - 1
+    pos[bad + 1:] = np.maximum(pos[bad + 1:], pos[bad - 1])
+    F, R, st = device_feed(ctx, pos, rlen, rev, nbits, [], np.int32, np.int32, whole=True)
+    assert ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == bad
+    pos, rlen, rev = make_reads(rng, 5000, glen)
+    pos[-2:] = nbits + 5
+    rev[-2:] = False
+    F, R, st = device_feed(ctx, pos, rlen, rev, nbits, [], np.int64, np.uint16, whole=True)
+    assert ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == pos.size - 2
+    assert int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0
