@@ -308,7 +308,10 @@ def main():
     dense = any(window_only_hint(v.n_forward, v.n_reverse, v.n_runs if with_m else 0, v.length, S) for v in vecs)
     deep = not dense and any(deep_lists_hint(v.n_forward, v.n_reverse, v.n_runs if with_m else 0, v.length, S) for v in vecs)
     hinted = (dense or deep) and args.path == "auto" and not args.no_hint
-    step_flags = flags | ((ffi.PMX_FLAG_WINDOW_ONLY if dense else ffi.PMX_FLAG_DEEP_LISTS) if hinted else 0)
+    # (--no-hint: flags = 0, and pmx_cc_batch_dev takes the hint itself from a sample of the vectors: one small launch + one
+    # synchronisation per call; otherwise one of the three hints, as the calculator always gives one)
+    step_flags = flags | ((ffi.PMX_FLAG_WINDOW_ONLY if dense else ffi.PMX_FLAG_DEEP_LISTS) if hinted else
+                          (ffi.PMX_FLAG_EVENTS_HINT if args.path == "auto" and not args.no_hint else 0))
 
     def step():
         # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev) on tstream, then the exchange

@@ -49,7 +49,8 @@ extern "C" {
 /* flags for pmx_cc_dev / pmx_calc_correlation */
 #define PMX_FLAG_SKIP_NCC     1u  /* skip_ncc=True (mscc.pyx:235,313): row 0 left zero (popcounts still reported) */
 #define PMX_FLAG_FORCE_DENSE  2u  /* use the dense word-parallel kernels (one lane per shift)          */
-#define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven kernels (error if unsupported)        */
+#define PMX_FLAG_FORCE_SPARSE 4u  /* insist on the set-bit driven kernels (error if unsupported); no density probe:
+                                   * the event kernel finds the tiles beyond its lists itself (see PMX_FLAG_EVENTS_HINT) */
 #define PMX_FLAG_WINDOW_ONLY 16u  /* hint: the caller knows the vectors are dense -- per 65536 positions, forward reads +
                                    * reverse reads + 2 x mappable runs above 2416 (3304 without a track), or 2 x runs above 1536
                                    * (max_shift <= 1023: ~1.8 % read starts per strand, ~110 M reads on hg38; above 1023: 768 forward /
@@ -59,6 +60,11 @@ extern "C" {
                                    * between ~1.5 % and ~3.2 % read starts per strand): the instantiation with the larger
                                    * list pool (4328 entries per 65536 positions, four workgroups per CU instead of
                                    * five).  Same integers either way */
+#define PMX_FLAG_EVENTS_HINT 64u  /* hint: the caller knows the data is within the event kernel's lists (the ordinary case:
+                                   * up to ~1.5 % read starts per strand on an ordinary track).  Without ANY of the three
+                                   * hints pmx_cc_batch_dev / pmx_calc_correlation take one from a sample of the vectors
+                                   * themselves (16 tiles of each of the largest chromosomes: one small launch and ONE
+                                   * SYNCHRONISATION of the stream per call, ~20 us): pass a hint to stay asynchronous */
 #define PMX_FLAG_SKIP_MLEN    8u  /* the caller holds mappable_len already (the *_mappability.json cache,
                                    * handler/mappability.py:239-259): no autocorrelation pass; row 4 and
                                    * scalars[2] are written as zeros */

@@ -95,12 +95,12 @@ class _ReadBuffer:
 class _Pending:
     """One chromosome whose kernels are queued: where its rows / feed state will be, and what to build from them."""
 
-    __slots__ = ("chrom", "slot", "kind", "has_m", "known", "glen", "nreads", "vecs", "nbits", "flags", "launched")
+    __slots__ = ("chrom", "slot", "kind", "has_m", "known", "glen", "nreads", "vecs", "nbits", "flags", "hint", "launched")
 
-    def __init__(self, chrom, slot, kind, has_m=False, known=None, glen=0, nreads=0, vecs=(), nbits=0, flags=0):
+    def __init__(self, chrom, slot, kind, has_m=False, known=None, glen=0, nreads=0, vecs=(), nbits=0, flags=0, hint=0):
         self.chrom, self.slot, self.kind, self.has_m, self.known, self.glen, self.nreads = (
             chrom, slot, kind, has_m, known, glen, nreads)
-        self.vecs, self.nbits, self.flags = vecs, nbits, flags     # [(device pointer, pool capacity)]: F, R[, M]
+        self.vecs, self.nbits, self.flags, self.hint = vecs, nbits, flags, hint     # [(device pointer, pool capacity)]: F, R[, M]
         self.launched = False                                       # its kernels are in the stream already (_run_cc)
 
 
@@ -409,10 +409,15 @@ class CCHipCalculator:
         # of letting it find out (same integers either way).  The strand split is not known on the host (the device walks
         # the reads): half the reads fed stands for a strand.
         counts = (0.5 * self._fed, 0.5 * self._fed, getattr(self, "_n_runs", 0) if d_m is not None else 0, glen, self.max_shift)
+        # (kept apart from the flags: one batched pass serves chromosomes whose hints differ -- chrM beside the autosomes --,
+        # with the hint most of its positions ask for, see _run_cc; a hint is always given, so that the library does not
+        # take one itself from a sample of the vectors: that costs a synchronisation of the stream, pymasc_amd.h)
         if window_only_hint(*counts):
-            flags |= ffi.PMX_FLAG_WINDOW_ONLY
+            hint = ffi.PMX_FLAG_WINDOW_ONLY
         elif deep_lists_hint(*counts):
-            flags |= ffi.PMX_FLAG_DEEP_LISTS     # deep, but within the event kernel's larger list pool
+            hint = ffi.PMX_FLAG_DEEP_LISTS       # deep, but within the event kernel's larger list pool
+        else:
+            hint = ffi.PMX_FLAG_EVENTS_HINT
         c = L - 1
         known = self._known_mlen.get(chrom) if d_m is not None else None
         if known is not None and len(known) <= max(c, S - c):      # cache too short for this run: recompute
@@ -423,7 +428,7 @@ class CCHipCalculator:
         vecs = self._cur_vecs + ([m_vec] if m_vec is not None else [])
         self._cur_vecs = []
         self._pending.append(_Pending(chrom, slot, "cc", has_m=d_m is not None, known=known, glen=glen, nreads=self._fed,
-                                      vecs=vecs, nbits=nbits, flags=flags))
+                                      vecs=vecs, nbits=nbits, flags=flags, hint=hint))
         self._cur_slot = -1
         # every `early_batch` chromosomes the kernels of those queued so far are launched (nothing is waited for or read
         # back), so that the fetch at the end finds only the last few to do
@@ -461,13 +466,20 @@ class CCHipCalculator:
 
     def _run_cc(self):
         """_calc_correlation's loop (mscc.pyx:288-317) for every chromosome queued since the last fetch: one batched pass per
-        group of chromosomes that share the kernel flags (normally one group)."""
+        group of chromosomes that share the kernel flags -- with / without a track, with / without a cached lag table:
+        normally one group; the density hints of the chromosomes do NOT split a pass --."""
         groups: Dict[Tuple[int, bool], List[_Pending]] = {}
         for p in self._pending:
             if p.kind == "cc" and not p.launched:
                 groups.setdefault((p.flags, p.has_m), []).append(p)
                 p.launched = True
         for (flags, has_m), ps in groups.items():
+            # the density hint of the pass: what most of its positions ask for (same integers whatever it says)
+            total = float(sum(p.nbits for p in ps)) or 1.0
+            w_window = sum(p.nbits for p in ps if p.hint == ffi.PMX_FLAG_WINDOW_ONLY) / total
+            w_deep = sum(p.nbits for p in ps if p.hint == ffi.PMX_FLAG_DEEP_LISTS) / total
+            flags |= (ffi.PMX_FLAG_WINDOW_ONLY if w_window > 0.5 else
+                      ffi.PMX_FLAG_DEEP_LISTS if w_window + w_deep > 0.5 else ffi.PMX_FLAG_EVENTS_HINT)
             self._ctx.cc_batch_dev([p.vecs[0][0] for p in ps], [p.vecs[1][0] for p in ps],
                                    [p.vecs[2][0] for p in ps] if has_m else None, [p.nbits for p in ps], self._kshift,
                                    self.read_len, flags, [self._slot_ptr(p.slot) for p in ps])

@@ -62,6 +62,70 @@ __global__ void __launch_bounds__(256) k_count(const u64 *__restrict__ words, ui
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
+// ---- density probe (round 4): what pmx_cc_batch_dev does for a caller that gives no hint ----
+// The event kernel's lists hold a bounded number of reads and run edges per 64-Kbit tile; beyond that the window kernels
+// are the right choice from the start (PMX_FLAG_WINDOW_ONLY), and in between the DEEP instantiation (PMX_FLAG_DEEP_LISTS).
+// A caller that knows its counts says so; for one that does not, PMX_PROBE_SAMPLES evenly spread tiles of each of the
+// largest chromosomes are counted here -- forward reads, reverse reads, run edges -- and the host applies the rule the
+// calculator applies to the counts it holds (pymasc_amd/calculator.py: window_only_hint / deep_lists_hint).  One small
+// launch + one 2-KB copy + one synchronisation per call, instead of an event pass that finds out tile by tile and a
+// window pass behind it (round 3: 5-15 % above 1.8 % reads per strand).
+__global__ void __launch_bounds__(256) k_density_probe(const pmx_probe_jobs jobs, u32 *__restrict__ out)
+{
+    const u32 job = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const uint64_t nbits = jobs.nbits[job];
+    const uint64_t ntiles = (nbits + 65535) / 65536;
+    if (ntiles == 0) return;
+    const uint64_t nsamp = ntiles < PMX_PROBE_SAMPLES ? ntiles : PMX_PROBE_SAMPLES;
+    if (s >= nsamp) return;
+    const uint64_t tile = (2 * (uint64_t)s + 1) * ntiles / (2 * nsamp);   // the middle of the s-th of nsamp stretches
+    const uint64_t nw = (nbits + 31) / 32;                                  // dwords of a vector
+    const u32 *F = jobs.F[job], *R = jobs.R[job], *M = jobs.M[job];
+    u32 cf = 0, cr = 0, ce = 0;
+    const uint64_t j0 = tile * 2048 + 8 * (uint64_t)tid;
+    u32 prev = (M && j0 > 0 && j0 - 1 < nw) ? M[j0 - 1] : 0u;
+    for (u32 k = 0; k < 8; k++) {
+        const uint64_t j = j0 + k;
+        if (j >= nw) break;
+        u32 f = F[j], r = R[j];
+        if (j == nw - 1 && (nbits & 31)) {          // bits beyond the vector's length do not count
+            const u32 keep = (1u << (nbits & 31)) - 1u;
+            f &= keep;
+            r &= keep;
+        }
+        cf += __popc(f);
+        cr += __popc(r);
+        if (M) {
+            const u32 m = M[j];
+            ce += __popc(m ^ ((m << 1) | (prev >> 31)));
+            prev = m;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cf += __shfl_down(cf, off, 64);
+        cr += __shfl_down(cr, off, 64);
+        ce += __shfl_down(ce, off, 64);
+    }
+    if ((tid & 63) == 0) {
+        if (cf) atomicAdd(&out[4 * job + 0], cf);
+        if (cr) atomicAdd(&out[4 * job + 1], cr);
+        if (ce) atomicAdd(&out[4 * job + 2], ce);
+    }
+    if (tid == 0) {
+        const uint64_t b0 = tile * 65536, left = nbits - b0;
+        atomicAdd(&out[4 * job + 3], (u32)(left < 65536 ? left : 65536));   // positions sampled
+    }
+}
+
+int pmx_launch_density_probe(pmx_ctx *ctx, const pmx_probe_jobs *jobs, uint32_t njobs, uint32_t *d_out)
+{
+    if (njobs == 0) return PMX_OK;
+    PMX_HIP(hipMemsetAsync(d_out, 0, (size_t)njobs * 4 * sizeof(u32), ctx->stream));
+    hipLaunchKernelGGL(k_density_probe, dim3(njobs, PMX_PROBE_SAMPLES), dim3(256), 0, ctx->stream, *jobs, d_out);
+    PMX_CHECK_LAUNCH("k_density_probe");
+    return PMX_OK;
+}
+
 static int grid_for(pmx_ctx *ctx, uint64_t items, int per_block)
 {
     uint64_t blocks = (items + per_block - 1) / per_block;

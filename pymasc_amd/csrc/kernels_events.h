@@ -202,9 +202,52 @@ __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, 
     }
 }
 
+// The interior tile of the max_shift <= 1023 instantiations (round 4): every address is a UNIFORM base -- vector + tile, in
+// scalar registers -- plus a per-thread 32-bit byte offset, so the loads take the scalar-base form and the address
+// arithmetic is a handful of scalar instructions instead of ~80 vector ones (64-bit per-thread pointer arithmetic for
+// every load; the prefetch was 4.7 % of a tile).  The halo quad is loaded under a wave-uniform role (`wave` is a scalar):
+// wave 1 M below the tile, wave 2 M above it, wave 3 R above it (lanes beyond the role re-read the role's last quad).
+template <bool HAS_M>
+__device__ __forceinline__ void ev_fetch_fast(EvRegs &er, const SpJobRegs &jb, u32 local_tile, u32 tid, u32 wave, u32 nhr)
+{
+    const size_t tb = (size_t)local_tile * (EV_TBW * 4u);   // (uniform) byte offset of the tile in its vectors
+    const char *fb = reinterpret_cast<const char *>(jb.F) + tb;
+    const char *rb = reinterpret_cast<const char *>(jb.R) + tb;
+    const char *mb = reinterpret_cast<const char *>(jb.M) + tb;
+    const u32 voff = 16u * tid, lane = tid & 63u;
+    // (every offset is formed as ONE 32-bit per-thread value added to a scalar base: an immediate beyond +-4 KB would
+    // push the compiler back to 64-bit per-thread pointers)
+#pragma unroll
+    for (u32 q = 0; q < EV_NQ; q++) {
+        const u32 vq = voff + q * (SP_TBW * 4u);
+        er.f[q] = *reinterpret_cast<const uint4 *>(fb + vq);
+        er.r[q] = *reinterpret_cast<const uint4 *>(rb + vq);
+        if (HAS_M) {
+            er.m[q] = *reinterpret_cast<const uint4 *>(mb + vq);
+            // (uniform) the dword below lane 0's quad.  SIGNED: wave 0 of quad 0 reads the dword BELOW the tile -- as an
+            // unsigned 32-bit offset "0 - 4" is +4 GB (a memory fault on the first interior tile, caught in review of the
+            // round-4 work in progress)
+            const int32_t sq = (int32_t)(q * (SP_TBW * 4u) + wave * 1024u) - 4;
+            er.wb[q] = *reinterpret_cast<const u32 *>(mb + sq);
+        } else {
+            er.m[q] = make_uint4(0, 0, 0, 0);
+            er.wb[q] = 0;
+        }
+    }
+    // ONE halo load for every lane, from a base the wave's role picks (scalar selects, no branch: loads of the roles in
+    // separate branches target the same registers, and the compiler waits for everything in flight between them):
+    // wave 1 M below the tile, wave 2 M above it, wave 3 R above it; lanes beyond the role repeat its last quad; wave 0
+    // re-reads a quad of R and ignores it.  hbw: the dword below the first halo quad (waves 1 and 2).
+    const char *hb = (HAS_M && wave == 1) ? mb - EV_LO * 4u : (HAS_M && wave == 2) ? mb + EV_TBW * 4u : wave == 3 ? rb + EV_TBW * 4u : rb;
+    const u32 lim = (HAS_M && wave == 1) ? 63u : (HAS_M && wave == 2) ? 8u : wave == 3 ? nhr - 1u : 63u;
+    const u32 vh = 16u * (lane < lim ? lane : lim);
+    er.h = *reinterpret_cast<const uint4 *>(hb + vh);
+    er.hbw = HAS_M ? *reinterpret_cast<const u32 *>(hb - 4) : 0u;
+}
+
 template <bool HAS_M, bool BIG>
 __device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u32 local_tile, u32 tid, u32 nhr, u32 lo,
-                                             bool skip_reads = false)
+                                             bool skip_reads = false, u32 wave = 0)
 {
     const int64_t d0 = (int64_t)local_tile * EV_TBW;
     const int64_t low = d0 - (int64_t)lo - 1;
@@ -213,6 +256,11 @@ __device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u3
     const bool interior = jb.aligned16 && low >= 0 && hi + 2 <= jb.nbits / 32;
     // (tried: raw buffer loads from a scalar resource + one 32-bit lane offset for the interior tile -- 67 fewer vector
     // but 160 more scalar instructions in the kernel, 1.4 % slower with M, 9 % slower NCC-only: same-box A/B, round 3)
+#ifndef EV_NO_FAST_FETCH
+    if (!BIG && interior && !skip_reads)
+        ev_fetch_fast<HAS_M>(er, jb, local_tile, tid, wave, nhr);
+    else
+#endif
     if (interior)
         ev_fetch<HAS_M, false, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads);
     else
@@ -335,7 +383,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
         act_var = g0 + sg < lim;
     }
-    if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, g0 + sg - pj.tile0, tid_, nhr, LO);
+    if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, g0 + sg - pj.tile0, tid_, nhr, LO, false, wave);
     // Read-dense stretches (deep data: every tile far above the list capacities): after two such tiles in a row the
     // workgroup hands the REST of its tile range in this chromosome to the window kernels in one go (flags only, nothing
     // staged): the event kernel then costs two tiles per workgroup instead of a wasted pass over everything.  (NSG == 1)
@@ -498,8 +546,13 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                     }
                 }
                 if (tid == 0) {
-                    atomicAdd(&xch[8 + 0], nF);
-                    atomicAdd(&xch[8 + 1], nRt);
+                    if (NSG == 1) {   // one thread between two barriers: plain adds (the atomic optimiser wraps an LDS atomic in a
+                        xch[8 + 0] += nF;   // wave reduction of ~14 instructions, even under tid == 0)
+                        xch[8 + 1] += nRt;
+                    } else {          // (thread 0 of EVERY sub-group comes here)
+                        atomicAdd(&xch[8 + 0], nF);
+                        atomicAdd(&xch[8 + 1], nRt);
+                    }
                 }
             } else {
                 // dense tile: left to k_cc_sparse (both of its 32-Kbit tiles; the flag array is padded per job)
@@ -596,7 +649,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                 const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
                 act_var = gnext + sg < lim;
             }
-            if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, gnext + sg - pj.tile0, tid, nhr, LO, NSG == 1 && next_skip);
+            if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, gnext + sg - pj.tile0, tid, nhr, LO, NSG == 1 && next_skip, wave);
         } else if (NSG > 1) {
             act_var = false;
         }

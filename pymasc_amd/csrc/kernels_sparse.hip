@@ -2470,6 +2470,9 @@ int pmx_events_take_big(uint32_t max_shift)
     return max_shift > 1023 && max_shift <= EV_MAX_SHIFT && events_enabled() && events_big_enabled();
 }
 
+// does the event kernel take this shift range at all (the density probe of pmx_cc_batch_dev only matters then)
+int pmx_events_used(uint32_t max_shift) { return (max_shift <= 1023 && events_enabled()) || pmx_events_take_big(max_shift); }
+
 // The sub-group count the BIG launch of this shift range will use (0: none).  With ONE sub-group per workgroup (max_shift <=
 // 2047: 35 KB of LDS, four workgroups per CU) a CU has LDS to spare and the mappable-length pair pass runs beside the event
 // kernel on the auxiliary stream (hg38, -d 1024: 0.74 -> 0.68 ms; -d 2047: 0.85 -> 0.80); with 2 or 4 sub-groups it loses.

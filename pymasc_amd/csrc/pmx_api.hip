@@ -1,6 +1,7 @@
 // extern "C" surface of libpymasc_hip.so -- see include/pymasc_amd.h for the contract and the
 // reference interfaces each entry point replaces.
 #include "pmx_common.h"
+#include <algorithm>
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -84,6 +85,8 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->d_flags_cc = nullptr;
     ctx->flags_cc_bytes = 0;
     ctx->flags_cc_area = 0;
+    ctx->d_probe = nullptr;
+    ctx->h_probe = nullptr;
     ctx->flags_cc_zeroed[0] = ctx->flags_cc_zeroed[1] = ctx->flags_cc_dirty[0] = ctx->flags_cc_dirty[1] = 0;
     ctx->d_slab_ac = nullptr;
     ctx->slab_ac_words = 0;
@@ -195,6 +198,8 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (ctx->d_slab2) (void)hipFree(ctx->d_slab2);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_flags_cc) (void)hipFree(ctx->d_flags_cc);
+    if (ctx->d_probe) (void)hipFree(ctx->d_probe);
+    if (ctx->h_probe) (void)hipHostFree(ctx->h_probe);
     if (ctx->d_slab_ac) (void)hipFree(ctx->d_slab_ac);
     if (ctx->d_slab_fb) (void)hipFree(ctx->d_slab_fb);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -1060,6 +1065,63 @@ int pmx_mappable_len_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *con
 }
 
 // one chromosome through the dense kernels (atomics into a zeroed block)
+// The hint a caller without counts would give (include/pymasc_amd.h: PMX_FLAG_WINDOW_ONLY / PMX_FLAG_DEEP_LISTS), from a
+// sample of the vectors themselves: k_density_probe on the (at most 64) largest chromosomes of the batch, one copy, one
+// synchronisation.  Same rule as pymasc_amd/calculator.py (window_only_hint / deep_lists_hint: the AVERAGE tile against the
+// event kernel's list capacities), weighted by chromosome length: the batch takes the choice that most of its positions ask for.
+static int auto_density_hint(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, const uint64_t *const *d_R,
+                             const uint64_t *const *d_M, const uint64_t *nbits, uint32_t max_shift, bool has_m, uint32_t *hint)
+{
+    *hint = 0;
+    if (!ctx->d_probe) {
+        PMX_HIP(hipMalloc((void **)&ctx->d_probe, PMX_PROBE_JOBS * 4 * sizeof(uint32_t)));
+        PMX_HIP(hipHostMalloc((void **)&ctx->h_probe, PMX_PROBE_JOBS * 4 * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    std::vector<uint32_t> order(njobs);
+    for (uint32_t i = 0; i < njobs; i++) order[i] = i;
+    if (njobs > PMX_PROBE_JOBS) {
+        std::partial_sort(order.begin(), order.begin() + PMX_PROBE_JOBS, order.end(),
+                          [&](uint32_t a, uint32_t b) { return nbits[a] > nbits[b]; });
+        order.resize(PMX_PROBE_JOBS);
+    }
+    pmx_probe_jobs pj;
+    memset(&pj, 0, sizeof pj);
+    const uint32_t n = (uint32_t)order.size();
+    for (uint32_t k = 0; k < n; k++) {
+        pj.F[k] = (const u32 *)d_F[order[k]];
+        pj.R[k] = (const u32 *)d_R[order[k]];
+        pj.M[k] = has_m ? (const u32 *)d_M[order[k]] : nullptr;
+        pj.nbits[k] = nbits[order[k]];
+    }
+    int rc = pmx_launch_density_probe(ctx, &pj, n, ctx->d_probe);
+    if (rc) return rc;
+    PMX_HIP(hipMemcpyAsync(ctx->h_probe, ctx->d_probe, (size_t)n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    // list capacities per 64-Kbit tile: kernels_events.h (EV_POOL_SMALL / EV_POOL_DEEP / EV_CAPF + EV_CAPR + EV_CAPE_SMALL / EV_CAPE)
+    const double POOL = 2416, POOL_NCC = 768 + 1000 + 1536, POOL_DEEP = 4328, EDGES = 1536, CAPF = 768, CAPR = 1000, EDGES_BIG = 384;
+    double w_window = 0, w_deep = 0, w_all = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t *c = ctx->h_probe + 4 * k;
+        if (!c[3]) continue;
+        const double per_tile = 65536.0 / (double)c[3];
+        const double f = c[0] * per_tile, r = c[1] * per_tile, e = has_m ? c[2] * per_tile : 0.0;
+        bool window, deep = false;
+        if (max_shift <= 1023) {
+            window = e > EDGES || f + r + e > (has_m ? POOL_DEEP : POOL_NCC);
+            deep = !window && has_m && f + r + e > 0.85 * POOL;
+        } else {
+            window = f > CAPF || r > CAPR || e > EDGES_BIG;
+        }
+        const double w = (double)pj.nbits[k];
+        w_all += w;
+        if (window) w_window += w;
+        else if (deep) w_deep += w;
+    }
+    if (w_all > 0 && w_window > 0.5 * w_all) *hint = PMX_FLAG_WINDOW_ONLY;
+    else if (w_all > 0 && w_window + w_deep > 0.5 * w_all) *hint = PMX_FLAG_DEEP_LISTS;
+    return PMX_OK;
+}
+
 static int cc_dense_one(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uint64_t *d_M, uint64_t nbits,
                         uint32_t max_shift, uint32_t read_len, bool do_ncc, bool do_mlen, uint64_t *d_out)
 {
@@ -1157,6 +1219,19 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             if (rc) return rc;
         }
         return PMX_OK;
+    }
+    // no hint from the caller: take one from a sample of the vectors (one small launch, one synchronisation)
+    static const bool probe_enabled = [] {   // PMX_DENSITY_PROBE=0: never (A/B, tests of the unhinted event path)
+        const char *e = getenv("PMX_DENSITY_PROBE");
+        return !(e && e[0] == '0');
+    }();
+    // (PMX_FLAG_FORCE_SPARSE: the set-bit path exactly as it is without a hint -- the event kernel finds dense tiles itself)
+    if (probe_enabled && !(flags & (PMX_FLAG_WINDOW_ONLY | PMX_FLAG_DEEP_LISTS | PMX_FLAG_EVENTS_HINT | PMX_FLAG_FORCE_SPARSE)) &&
+        pmx_events_used(max_shift)) {
+        uint32_t hint = 0;
+        int rc = auto_density_hint(ctx, njobs, d_F, d_R, d_M, nbits, max_shift, has_m, &hint);
+        if (rc) return rc;
+        flags |= hint;
     }
     const uint32_t chunk = pmx_cc_batch_jobs(max_shift);
     const size_t ac_words = pmx_autocorr_scratch_words(max_lag);

@@ -75,6 +75,7 @@ struct pmx_ctx {
     size_t flags_cc_bytes;
     // the event pass uses two areas of d_flags_cc in turn; a pass's k_events_finish clears the other one (kernels_sparse.hip: ev_flag_area)
     uint32_t flags_cc_area;
+    uint32_t *d_probe, *h_probe;   // density probe: device counters + their page-locked copy (pmx_cc_batch_dev without a hint)
     size_t flags_cc_zeroed[2], flags_cc_dirty[2];
     u32 *d_slab_ac;              // slab of the window autocorrelation kernel (separate: it may run beside k_cc_sparse)
     size_t slab_ac_words;
@@ -110,6 +111,15 @@ struct pmx_ctx {
     u64 *d_pad_stage;
     size_t pad_stage_words;
 };
+
+// density probe (kernels_bits.hip): up to PMX_PROBE_JOBS chromosomes per launch, PMX_PROBE_SAMPLES tiles of 64 Kbit each
+#define PMX_PROBE_JOBS 64u
+#define PMX_PROBE_SAMPLES 16u
+struct pmx_probe_jobs {
+    const u32 *F[PMX_PROBE_JOBS], *R[PMX_PROBE_JOBS], *M[PMX_PROBE_JOBS];
+    uint64_t nbits[PMX_PROBE_JOBS];
+};
+int pmx_launch_density_probe(pmx_ctx *ctx, const pmx_probe_jobs *jobs, uint32_t njobs, uint32_t *d_out);   // d_out: [4 per job] forward, reverse, edges, positions sampled
 
 // profiling helpers (pmx_api.hip)
 int pmx_prof_begin(pmx_ctx *ctx, int kernel_id, pmx_timed_launch *tl, bool fallback = false);
@@ -162,6 +172,7 @@ int pmx_sparse_supported(uint32_t max_shift, uint32_t read_len);
 int pmx_events_can_fuse_mlen(uint32_t max_shift, uint32_t max_lag);
 // the event kernel (not the window kernel in shift chunks) takes this max_shift > 1023
 int pmx_events_take_big(uint32_t max_shift);
+int pmx_events_used(uint32_t max_shift);      // the event kernel takes this shift range (any of its instantiations)
 int pmx_events_big_subgroups(uint32_t max_shift, int has_m);
 uint32_t pmx_sparse_max_jobs(void);
 uint32_t pmx_cc_batch_jobs(uint32_t max_shift);   // jobs per call of pmx_launch_cc_sparse_batch (device-side job tables beyond 1023 shifts)

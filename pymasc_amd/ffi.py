@@ -25,6 +25,7 @@ PMX_NROWS = 6
 PMX_FLAG_SKIP_NCC = 1
 PMX_FLAG_WINDOW_ONLY = 16
 PMX_FLAG_DEEP_LISTS = 32
+PMX_FLAG_EVENTS_HINT = 64     # the caller knows the data fits the event kernel's lists (no density probe, no synchronisation)
 PMX_FLAG_FORCE_DENSE = 2
 PMX_FLAG_FORCE_SPARSE = 4
 PMX_FLAG_SKIP_MLEN = 8

@@ -165,3 +165,23 @@ def test_back_to_back_batches_whose_job_table_grows(ctx, S):
     for cases, outs in ((small, o1), (large, o2)):
         for (nbits, F, R, M), o in zip(cases, outs):
             check_block(o.cpu().numpy().view(np.uint64), oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
+
+
+@pytest.mark.parametrize("density,expect_events", [(0.004, True), (0.06, False)])
+def test_a_call_without_a_hint_takes_one_from_a_sample_of_the_vectors(ctx, density, expect_events):
+    """flags = 0: pmx_cc_batch_dev counts 16 sampled tiles per chromosome (k_density_probe) and gives itself the hint a caller
+    with counts would give -- sparse data stays on the event kernel, data far beyond its lists goes straight to the window
+    kernels (no event pass in front of them: the 5-15 % of round 3).  Same integers as with PMX_FLAG_FORCE_SPARSE (no probe)."""
+    S, L = 300, 36
+    lens = [300000, 120000, 70000]
+    cases = [synth.make_case(900 + i, n, S, L, density, density, True, mean_on=2000, mean_off=500) for i, n in enumerate(lens)]
+    ctx.set_profiling(2)
+    ctx.reset_kernel_times()
+    outs = run_batch(ctx, cases, S, L, True, 0)
+    ev_launches = ctx.kernel_time(ffi.PMX_KERNEL_CC_EVENTS)[1]
+    ctx.set_profiling(False)
+    assert (ev_launches > 0) == expect_events
+    forced = run_batch(ctx, cases, S, L, True, ffi.PMX_FLAG_FORCE_SPARSE)
+    for (nbits, F, R, M), out, f in zip(cases, outs, forced):
+        check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
+        assert np.array_equal(out[:ffi.PMX_ROW_SCALARS], f[:ffi.PMX_ROW_SCALARS])

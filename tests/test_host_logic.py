@@ -337,8 +337,19 @@ def test_dense_data_hint_from_the_counts_the_calculator_holds():
     calc.finishup_calculation()
     ocalc.finishup_calculation()
     assert_matches_oracle(calc, ocalc, names)
-    assert [bool(f & ffi.PMX_FLAG_WINDOW_ONLY) for f in ctx.flags] == [False, False, True, True]
-    assert [bool(f & ffi.PMX_FLAG_DEEP_LISTS) for f in ctx.flags] == [False, True, False, False]
+    # ONE batched pass for the four chromosomes (their hints do not split it: round-3 advisor finding), with the hint most of
+    # its positions ask for: sparse / deep / window / window at equal lengths -> half window, three quarters deep or beyond
+    hints = ffi.PMX_FLAG_WINDOW_ONLY | ffi.PMX_FLAG_DEEP_LISTS | ffi.PMX_FLAG_EVENTS_HINT
+    assert [f & hints for f in ctx.flags] == [ffi.PMX_FLAG_DEEP_LISTS] * 4
+    # a long sparse chromosome beside a short dense one: the pass is the sparse one's (and a hint is ALWAYS given: without
+    # one the library samples the vectors and synchronises the stream)
+    ctx2 = Recording()
+    calc2 = CCHipCalculator(100, 36, ["long", "mito"], [60000, 3000], context=ctx2)
+    p1 = np.sort(rng.choice(np.arange(1, 59000), size=200, replace=False))
+    p2 = np.sort(rng.choice(np.arange(1, 2900), size=900, replace=False))
+    feed_all(calc2, [(False, "long", int(p), 36) for p in p1] + [(True, "mito", int(p), 36) for p in p2])
+    calc2.finishup_calculation()
+    assert [f & hints for f in ctx2.flags] == [ffi.PMX_FLAG_EVENTS_HINT] * 2
 
 
 def test_fetching_results_between_two_bulk_chunks_keeps_the_feed_state_of_the_chromosome_being_fed():
