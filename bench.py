@@ -313,6 +313,8 @@ def main():
     step_flags = flags | ((ffi.PMX_FLAG_WINDOW_ONLY if dense else ffi.PMX_FLAG_DEEP_LISTS) if hinted else
                           (ffi.PMX_FLAG_EVENTS_HINT if args.path == "auto" and not args.no_hint else 0))
 
+    xtimes = []          # (start, end) events of every step's result exchange on xstream
+
     def step():
         # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev) on tstream, then the exchange
         # on xstream (double-buffered result blocks)
@@ -325,10 +327,14 @@ def main():
         ev_done[b].record(tstream)
         with torch.cuda.stream(xstream):
             xstream.wait_event(ev_done[b])
+            x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            x0.record(xstream)
             if world > 1 and backend != "nccl":
                 out = sharding.exchange_results(d_rows[b].cpu(), assignment, len(jobs))
             else:
                 out = sharding.exchange_results(d_rows[b], assignment, len(jobs), force_collectives=args.force_collectives)
+            x1.record(xstream)
+            xtimes.append((x0, x1))
             ev_free[b].record(xstream)
         return out
 
@@ -359,19 +365,21 @@ def main():
     reps = []
     for _ in range(max(args.repeat, 1)):
         ctx.reset_kernel_times()
+        del xtimes[:]
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             rows, totals = step()
         fence()
-        reps.append((time.perf_counter() - t0, {k: ctx.kernel_time(k) for k in range(ffi.PMX_KERNEL_COUNT)}))
+        reps.append((time.perf_counter() - t0, {k: ctx.kernel_time(k) for k in range(ffi.PMX_KERNEL_COUNT)},
+                     sum(a.elapsed_time(b) for a, b in xtimes) / max(len(xtimes), 1)))
     ctx.set_profiling(False)
     if world > 1:
         t = torch.tensor([r[0] for r in reps], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        reps = [(float(x), r[1]) for x, r in zip(t.tolist(), reps)]
+        reps = [(float(x), r[1], r[2]) for x, r in zip(t.tolist(), reps)]
     order = sorted(range(len(reps)), key=lambda i: reps[i][0])
-    elapsed, ktimes = reps[order[len(order) // 2]]
+    elapsed, ktimes, exchange_ms = reps[order[len(order) // 2]]
     rep_ms = sorted(1e3 * r[0] / args.steps for r in reps)
 
     # consistency of the exchange: all-reduced totals == sum of gathered rows (integers, exact)
@@ -415,6 +423,21 @@ def main():
 
     work_per_step = (S + 1) * total_bp
     value = work_per_step * args.steps / elapsed
+
+    # what every rank did, in the line of rank 0 (N > 1): one driver run explains itself -- the share of the genome each rank
+    # holds (LPT over whole chromosomes), its kernels' time per step, the result exchange's time on its second stream
+    loads = [sum(costs[j] for j in a) for a in assignment]
+    mine_info = {"rank": rank, "jobs": len(mine), "bp": int(loads[rank]),
+                 "kernel_ms_per_step": {ctx.kernel_name(k): round(ktimes[k][0] / args.steps, 4) for k in ktimes if ktimes[k][1]},
+                 "exchange_ms_per_step": round(exchange_ms, 4)}
+    per_rank = [mine_info]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_info)
+    multi_gpu = {"ranks": world, "lpt_imbalance": (max(loads) / (sum(loads) / world) - 1.0) if sum(loads) else 0.0,
+                 "exchange": "all_gather_into_tensor(rows) + all_reduce(totals) on a second stream, overlapping the next step's kernels",
+                 "per_rank": per_rank,
+                 "measured_on_hardware": bool(world > 1 and backend == "nccl")}
 
     # ---- end to end: reads + intervals in HOST memory -> vectors -> the same kernels -> rows back in host
     # memory.  Never `value`; reported beside it.  Two legs:
@@ -648,6 +671,7 @@ def main():
             "dense_equivalent_frac_of_valu_peak": (dense_lane_ops / (avg_ms * 1e-3) / 7.9e13) if avg_ms > 0 else None,
             "issue": issue_rate(ctx.kernel_name(dom), workload_tag),
         },
+        "multi_gpu": multi_gpu,
         "repetitions": {"n": len(reps), "steps_each": args.steps, "ms_per_step_min_median_max":
                         [round(rep_ms[0], 5), round(rep_ms[len(rep_ms) // 2], 5), round(rep_ms[-1], 5)]},
         "pipe_utilisation": pipe_utilisation(ctx.kernel_name(dom), workload_tag),

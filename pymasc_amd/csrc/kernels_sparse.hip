@@ -1912,14 +1912,15 @@ __device__ __forceinline__ void autocorr_finish_job(const SpJobDev &jb, long lon
     }
 }
 
+#define AC_FINISH_THREADS 1024u   // (256 until round 4: 42 us for config 5's 200 chromosomes x 4901 lags -- two dependent passes of 20 entries per thread)
 template <typename JT = SpJobTable>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(AC_FINISH_THREADS)
 k_autocorr_finish(const JT jobs, u32 max_lag, u32 lagcap, u32 mode, int32_t c, u32 max_shift, u32 out_stride)
 {
     __shared__ long long part[256];
     const SpJobDev &jb = jobs.j[blockIdx.x];
     if (!(jb.flags & 1u)) return;   // one finish per chromosome (its chunk-0 job)
-    autocorr_finish_job(jb, part, max_lag, lagcap, mode, c, max_shift, out_stride);
+    autocorr_finish_job(jb, part, max_lag, lagcap, mode, c, max_shift, out_stride, AC_FINISH_THREADS);
 }
 
 // Work split of a window kernel that runs BEHIND the event / pair kernel and only sees the tiles it flagged.  Equal shares
@@ -2906,7 +2907,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         JT ref;
         rc = upload_table(ctx, tab, &ref);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_autocorr_finish<JT>, dim3(n), dim3(256), 0, ctx->stream, ref, max_lag, lagcap, mode,
+        hipLaunchKernelGGL(k_autocorr_finish<JT>, dim3(n), dim3(AC_FINISH_THREADS), 0, ctx->stream, ref, max_lag, lagcap, mode,
                            (int32_t)read_len - 1, max_shift, out_stride);
         PMX_CHECK_LAUNCH("k_autocorr_finish");
     }

@@ -110,15 +110,14 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
         ctx->feed_used[i] = false;
     }
     ctx->feed_next = 0;
-    for (int i = 0; i < 2; i++) {
-        ctx->d_jobtab[i] = nullptr;
-        ctx->jobtab_bytes[i] = 0;
-    }
     for (int i = 0; i < PMX_JOBTAB_SLOTS; i++) {
+        ctx->d_jobtab[i] = nullptr;
         ctx->h_jobtab[i] = nullptr;
         ctx->h_jobtab_bytes[i] = 0;
         ctx->jobtab_done[i] = nullptr;
+        ctx->jobtab_mark[i][0] = ctx->jobtab_mark[i][1] = nullptr;
         ctx->jobtab_used[i] = false;
+        ctx->jobtab_marked[i] = false;
     }
     ctx->jobtab_next = 0;
     ctx->copy_stream = nullptr;
@@ -143,6 +142,7 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
         }
         ctx->own_stream = true;
     }
+    ctx->user_stream = ctx->stream;
     bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->feed_copied, hipEventDisableTiming) == hipSuccess;
@@ -182,11 +182,12 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->copy_stream2) (void)hipStreamDestroy(ctx->copy_stream2);
     if (ctx->d_build_err) (void)hipFree(ctx->d_build_err);
-    for (int i = 0; i < 2; i++)
-        if (ctx->d_jobtab[i]) (void)hipFree(ctx->d_jobtab[i]);
     for (int i = 0; i < PMX_JOBTAB_SLOTS; i++) {
+        if (ctx->d_jobtab[i]) (void)hipFree(ctx->d_jobtab[i]);
         if (ctx->h_jobtab[i]) (void)hipHostFree(ctx->h_jobtab[i]);
         if (ctx->jobtab_done[i]) (void)hipEventDestroy(ctx->jobtab_done[i]);
+        if (ctx->jobtab_mark[i][0]) (void)hipEventDestroy(ctx->jobtab_mark[i][0]);
+        if (ctx->jobtab_mark[i][1]) (void)hipEventDestroy(ctx->jobtab_mark[i][1]);
     }
     for (auto &tl : ctx->timed) {
         (void)hipEventDestroy(tl.start);
@@ -236,38 +237,55 @@ int pmx_ensure_scratch(pmx_ctx *ctx, size_t words)
 
 int pmx_upload_jobtab(pmx_ctx *ctx, const void *src, size_t bytes, const void **d)
 {
-    const int si = ctx->stream == ctx->aux_stream ? 1 : 0;
-    if (ctx->jobtab_bytes[si] < bytes) {
-        if (ctx->d_jobtab[si]) {
-            PMX_HIP(hipStreamSynchronize(ctx->stream));
-            PMX_HIP(hipFree(ctx->d_jobtab[si]));
-            ctx->d_jobtab[si] = nullptr;
-            ctx->jobtab_bytes[si] = 0;
-        }
-        const size_t want = bytes * 2 + 4096;
-        PMX_HIP(hipMalloc(&ctx->d_jobtab[si], want));
-        ctx->jobtab_bytes[si] = want;
-    }
-    // page-locked staging slot: taken again only after the copy out of it has run
+    // A ring of PMX_JOBTAB_SLOTS (page-locked staging buffer, device buffer) pairs.  The copy runs on the COPY stream and
+    // the caller's stream only waits for its event: a table does not depend on the kernels queued before it, so it
+    // travels while they run (round 4; a copy queued on the compute stream itself stalled it for ~30 us per table, five
+    // tables per config-5 step).  A slot is taken again after PMX_JOBTAB_SLOTS further uploads, once the stream has
+    // passed the point it had reached when the NEXT table was uploaded -- every launcher queues a table's consumers
+    // before it uploads another table (jobtab_mark[]).
     const uint32_t slot = ctx->jobtab_next;
+    const uint32_t prev = (slot + PMX_JOBTAB_SLOTS - 1) % PMX_JOBTAB_SLOTS;
     ctx->jobtab_next = (slot + 1) % PMX_JOBTAB_SLOTS;
-    if (!ctx->jobtab_done[slot]) PMX_HIP(hipEventCreateWithFlags(&ctx->jobtab_done[slot], hipEventDisableTiming));
-    if (ctx->jobtab_used[slot]) PMX_HIP(hipEventSynchronize(ctx->jobtab_done[slot]));
+    if (!ctx->jobtab_done[slot]) {
+        PMX_HIP(hipEventCreateWithFlags(&ctx->jobtab_done[slot], hipEventDisableTiming));
+        PMX_HIP(hipEventCreateWithFlags(&ctx->jobtab_mark[slot][0], hipEventDisableTiming));
+        PMX_HIP(hipEventCreateWithFlags(&ctx->jobtab_mark[slot][1], hipEventDisableTiming));
+    }
+    // the consumers of the previous table are queued by now: mark BOTH streams of the context (a launcher may have been
+    // pointed at the auxiliary stream: pmx_cc_batch_dev forks the mappable-length pass there)
+    if (ctx->jobtab_used[prev]) {
+        PMX_HIP(hipEventRecord(ctx->jobtab_mark[prev][0], ctx->user_stream));
+        PMX_HIP(hipEventRecord(ctx->jobtab_mark[prev][1], ctx->aux_stream));
+        ctx->jobtab_marked[prev] = true;
+    }
+    if (ctx->jobtab_used[slot]) {
+        PMX_HIP(hipEventSynchronize(ctx->jobtab_done[slot]));           // the copy out of the staging buffer
+        if (ctx->jobtab_marked[slot]) {                                 // the kernels that read the device buffer
+            PMX_HIP(hipEventSynchronize(ctx->jobtab_mark[slot][0]));
+            PMX_HIP(hipEventSynchronize(ctx->jobtab_mark[slot][1]));
+        } else {                                                        // (not expected: a ring of one)
+            PMX_HIP(hipStreamSynchronize(ctx->user_stream));
+            PMX_HIP(hipStreamSynchronize(ctx->aux_stream));
+        }
+    }
     if (ctx->h_jobtab_bytes[slot] < bytes) {
         if (ctx->h_jobtab[slot]) PMX_HIP(hipHostFree(ctx->h_jobtab[slot]));
+        if (ctx->d_jobtab[slot]) PMX_HIP(hipFree(ctx->d_jobtab[slot]));
         ctx->h_jobtab[slot] = nullptr;
+        ctx->d_jobtab[slot] = nullptr;
         ctx->h_jobtab_bytes[slot] = 0;
         const size_t want = bytes * 2 + 4096;
         PMX_HIP(hipHostMalloc(&ctx->h_jobtab[slot], want, hipHostMallocDefault));
+        PMX_HIP(hipMalloc(&ctx->d_jobtab[slot], want));
         ctx->h_jobtab_bytes[slot] = want;
     }
     memcpy(ctx->h_jobtab[slot], src, bytes);
-    // (the device buffer of a stream is reused by every upload on it: the copy is ordered behind the kernels that still read
-    // the previous table, which were queued on the same stream)
-    PMX_HIP(hipMemcpyAsync(ctx->d_jobtab[si], ctx->h_jobtab[slot], bytes, hipMemcpyHostToDevice, ctx->stream));
-    PMX_HIP(hipEventRecord(ctx->jobtab_done[slot], ctx->stream));
+    PMX_HIP(hipMemcpyAsync(ctx->d_jobtab[slot], ctx->h_jobtab[slot], bytes, hipMemcpyHostToDevice, ctx->copy_stream2));
+    PMX_HIP(hipEventRecord(ctx->jobtab_done[slot], ctx->copy_stream2));
+    PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->jobtab_done[slot], 0));
     ctx->jobtab_used[slot] = true;
-    *d = ctx->d_jobtab[si];
+    ctx->jobtab_marked[slot] = false;
+    *d = ctx->d_jobtab[slot];
     return PMX_OK;
 }
 

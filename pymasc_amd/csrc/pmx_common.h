@@ -94,15 +94,16 @@ struct pmx_ctx {
     hipStream_t copy_stream;     // H2D copies of the feeders run here, one slot ahead of the kernels on `stream`
     hipStream_t copy_stream2;    // ... the small interval copies of pmx_bits_set_regions_async here, beside the read copies
     hipEvent_t feed_copied;
-    // job tables in device memory (kernels_sparse.hip: SpJobTableRef): one buffer per stream of the context (main / auxiliary),
-    // filled from a ring of page-locked staging slots so that an upload never waits for the GPU
-    void *d_jobtab[2];
-    size_t jobtab_bytes[2];
+    // job tables in device memory (kernels_sparse.hip: SpJobTableRef): a ring of (page-locked staging buffer, device buffer)
+    // pairs filled on the second copy stream, so that neither the host nor the compute stream waits for an upload
+    void *d_jobtab[PMX_JOBTAB_SLOTS];
     void *h_jobtab[PMX_JOBTAB_SLOTS];
-    size_t h_jobtab_bytes[PMX_JOBTAB_SLOTS];
-    hipEvent_t jobtab_done[PMX_JOBTAB_SLOTS];
-    bool jobtab_used[PMX_JOBTAB_SLOTS];
+    size_t h_jobtab_bytes[PMX_JOBTAB_SLOTS];              // (capacity of both buffers of the slot)
+    hipEvent_t jobtab_done[PMX_JOBTAB_SLOTS];             // the copy into the device buffer has run (copy stream)
+    hipEvent_t jobtab_mark[PMX_JOBTAB_SLOTS][2];          // where the context's two streams stood when the NEXT table was uploaded
+    bool jobtab_used[PMX_JOBTAB_SLOTS], jobtab_marked[PMX_JOBTAB_SLOTS];
     uint32_t jobtab_next;
+    hipStream_t user_stream;     // `stream` as given at creation (launchers may point `stream` at aux_stream for a while)
     u64 *d_build_err;            // pmx_bits_build_batch: one range-error word per job since the last pmx_bits_build_status
     size_t build_err_cap, build_err_jobs;
     u64 *d_out_stage;

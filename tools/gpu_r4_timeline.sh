@@ -16,7 +16,7 @@ idx = [i for i, r in enumerate(rows) if 'k_cc_events' in r['Kernel_Name'] or ('k
 names = [rows[i]['Kernel_Name'] for i in idx]
 start = max(i for i in idx if 'k_cc_events' in rows[i]['Kernel_Name']) if any('k_cc_events' in n for n in names) else idx[-1]
 t0 = int(rows[start]['Start_Timestamp']); prev_end = None
-for r in rows[max(0, start - 2):start + 24]:
+for r in rows[max(0, start - 12):start + 12]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     gap = (s - prev_end) / 1e3 if prev_end else 0.0
     print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f} us  gap {gap:7.1f} us  {r['Kernel_Name'][:60]}")
