@@ -131,7 +131,7 @@ struct EvLds {
     static constexpr u32 IDXR = IDXF + (HAS_M ? 66u : 0u);          // its first forward / reverse read
     static constexpr u32 MT0 = IDXR + (HAS_M ? 66u : 0u);           // [3] = the dword below the staged range, [4..] = M
     static_assert(MT0 % 4 == 0, "alignment of the 16-byte stores");
-    __host__ __device__ static constexpr u32 sg_words(u32 lo) { return MT0 + (HAS_M ? 4u + lo + EV_TBW + EV_HI : 0u); }
+    __host__ __device__ static constexpr u32 sg_words(u32 lo, u32 hi = EV_HI) { return MT0 + (HAS_M ? 4u + lo + EV_TBW + hi : 0u); }
     // shared block (hn: entries per row, a multiple of 128)
     __host__ __device__ static constexpr u32 row_words(u32 hn) { return BIG ? hn / 2 : hn; }
     __host__ __device__ static constexpr u32 o_gf(u32 hn) { return hn; }
@@ -140,7 +140,7 @@ struct EvLds {
     __host__ __device__ static constexpr u32 o_dump(u32 hn) { return o_gr(hn) + (HAS_M ? row_words(hn) : 0u); }
     __host__ __device__ static constexpr u32 o_xch(u32 hn) { return o_dump(hn) + 64; }    // [0..7] sub-group counts, [8..13] scalars
     __host__ __device__ static constexpr u32 o_sg(u32 hn) { return o_xch(hn) + 16; }
-    __host__ __device__ static constexpr u32 total(u32 hn, u32 lo, u32 nsg) { return o_sg(hn) + nsg * sg_words(lo); }
+    __host__ __device__ static constexpr u32 total(u32 hn, u32 lo, u32 nsg, u32 hi = EV_HI) { return o_sg(hn) + nsg * sg_words(lo, hi); }
 };
 
 struct EvRegs {
@@ -162,7 +162,7 @@ __device__ __forceinline__ u32 ev_role_mlo_index(u32 tid) { return BIG ? tid : (
 template <bool HAS_M, bool GUARD, bool BIG>
 __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, const u32 *__restrict__ R,
                                          const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid, u32 nhr, u32 lo,
-                                         bool skip_reads)
+                                         bool skip_reads, u32 nhm = EV_HI / 4u)
 {
     if (skip_reads) nhr = 0;   // (uniform) the reads of this stretch belong to the window kernel: only M is staged
 #pragma unroll
@@ -187,7 +187,7 @@ __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, 
     // ONE halo load for every lane (lanes without a role re-read their own quad and ignore it): loads of the roles in
     // separate branches target the same registers, and the compiler then waits for everything in flight between them
     const u32 ht = tid & 63u, hw = tid >> 6;
-    const bool m_lo = HAS_M && ev_role_mlo<BIG>(tid, lo), m_hi = HAS_M && hw == 2 && ht < 9, r_hi = hw == 3 && ht < nhr;
+    const bool m_lo = HAS_M && ev_role_mlo<BIG>(tid, lo), m_hi = HAS_M && hw == 2 && ht < nhm, r_hi = hw == 3 && ht < nhr;
     const u32 *hp = (m_lo || m_hi || skip_reads) ? M : R;   // (skip_reads without M does not occur)
     int64_t jh = d0 + 4 * (int64_t)tid;
     if (m_lo) jh = d0 - (int64_t)lo + 4 * (int64_t)ev_role_mlo_index<BIG>(tid);
@@ -247,11 +247,11 @@ __device__ __forceinline__ void ev_fetch_fast(EvRegs &er, const SpJobRegs &jb, u
 
 template <bool HAS_M, bool BIG>
 __device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u32 local_tile, u32 tid, u32 nhr, u32 lo,
-                                             bool skip_reads = false, u32 wave = 0)
+                                             bool skip_reads = false, u32 wave = 0, u32 hi_dwords = EV_HI)
 {
     const int64_t d0 = (int64_t)local_tile * EV_TBW;
     const int64_t low = d0 - (int64_t)lo - 1;
-    const u32 above = (BIG && 4 * nhr > EV_HI) ? 4 * nhr : EV_HI;   // dwords read above the tile (M: EV_HI, R: 4 nhr)
+    const u32 above = (BIG && 4 * nhr > hi_dwords) ? 4 * nhr : hi_dwords;   // dwords read above the tile (M: hi_dwords, R: 4 nhr)
     const uint64_t hi = (uint64_t)d0 + EV_TBW + above;
     const bool interior = jb.aligned16 && low >= 0 && hi + 2 <= jb.nbits / 32;
     // (tried: raw buffer loads from a scalar resource + one 32-bit lane offset for the interior tile -- 67 fewer vector
@@ -262,9 +262,9 @@ __device__ __forceinline__ void ev_fetch_job(EvRegs &er, const SpJobRegs &jb, u3
     else
 #endif
     if (interior)
-        ev_fetch<HAS_M, false, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads);
+        ev_fetch<HAS_M, false, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads, hi_dwords / 4u);
     else
-        ev_fetch<HAS_M, true, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads);
+        ev_fetch<HAS_M, true, BIG>(er, jb.F, jb.R, jb.M, d0, jb.nbits, tid, nhr, lo, skip_reads, hi_dwords / 4u);
 }
 
 // forward list entry: bits 0..16 biased position, 17..29 index of the first reverse read at or above it, 31 = M[x]
@@ -321,6 +321,16 @@ __device__ __forceinline__ void ev_add_cell(u32 *row, u32 cell, u32 val)
         atomicAdd(&row[cell], val);
 }
 
+// BIG with the mappable-length pairs: row 5 of a (workgroup, job) segment takes WORKGROUP-scope atomic adds (done in the
+// XCD's L2: the row is this workgroup's alone until the kernel ends); it is cleared with plain stores when the workgroup
+// enters the job, and they have been performed before the workgroup's next barrier
+__device__ __forceinline__ void ev_zero_row5(u32 *__restrict__ slab, u32 segment, u32 hn, u32 gt, u32 nt)
+{
+    u32 *row = slab + ((size_t)segment * EV_SEG_ROWS + 5u) * hn;
+    for (u32 i = gt; i < hn; i += nt) row[i] = 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // slab segment of a (workgroup, job) pair: EV_SEG_ROWS rows of `hn` u32: ncc, GF, cc, GR, scalars (|F|, |R|, Bf, R0,
 // popcount(M), runs), EE
 // DO_MLEN: also the pairs of run edges (the mappable-length autocorrelation, see k_autocorr_pairs): EE[k] = sum of
@@ -333,19 +343,19 @@ __device__ __forceinline__ void ev_add_cell(u32 *row, u32 cell, u32 val)
 template <bool HAS_M, bool DO_NCC, bool DO_MLEN, u32 NSG, bool BIG, typename JT = SpJobTable, bool DEEP = false>
 __global__ void __launch_bounds__(256 * NSG, BIG ? 4 : (HAS_M ? (DEEP ? 4 : EV_WAVES) : EV_WAVES_NCC))
 k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, u32 S, u32 nhr, u32 max_lag,
-            u32 hn_arg, u32 lo_arg, u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags,
+            u32 hn_arg, u32 lo_arg, u32 hi_arg, u32 *__restrict__ slab, unsigned char *__restrict__ tile_flags,
             unsigned char *__restrict__ tile_flags_ac, u32 *__restrict__ n_flagged, u32 *__restrict__ jobstat)
 {
     typedef EvLds<HAS_M, BIG, DEEP> L;
     static_assert(!DEEP || (HAS_M && !BIG), "DEEP: the max_shift <= 1023 instantiations with a track");
     static_assert(BIG || NSG == 1, "the max_shift <= 1023 instantiations are one sub-group per workgroup");
-    static_assert(!(BIG && DO_MLEN), "the edge pairs of the mappable-length pass are not fused beyond 1023 lags");
     constexpr u32 NT = 256 * NSG;
     extern __shared__ __align__(16) u32 ev_dyn_lds[];
     __shared__ __align__(16) u32 ev_static_lds[BIG ? 4 : L::total(1024, EV_LO, 1)];
     u32 *const lds = BIG ? ev_dyn_lds : ev_static_lds;
     const u32 HN = BIG ? hn_arg : 1024u;      // entries per histogram row
     const u32 LO = BIG ? lo_arg : EV_LO;      // dwords of M staged below the tile
+    const u32 HI = BIG ? hi_arg : EV_HI;      // ... and above it (BIG with the mappable-length pairs: max_lag bits, a multiple of 4 dwords)
     const u32 BIAS = LO * 32u;                // list positions are relative to the first staged bit of M
     const u32 sg = NSG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0u;
     u32 *const hN = lds;
@@ -353,7 +363,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
     u32 *const hGR = lds + L::o_gr(HN);
     u32 *const hEE = lds + L::o_ee(HN);
     u32 *const xch = lds + L::o_xch(HN);
-    u32 *const sgb = lds + L::o_sg(HN) + sg * L::sg_words(LO);
+    u32 *const sgb = lds + L::o_sg(HN) + sg * L::sg_words(LO, HI);
     u32 *const MT = sgb + L::MT0 + 4;
     unsigned short *const idxF = reinterpret_cast<unsigned short *>(sgb + L::IDXF);
     unsigned short *const idxR = reinterpret_cast<unsigned short *>(sgb + L::IDXR);
@@ -373,6 +383,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
 
     FIRST_JOB(ji, JT, jobs, njobs, g0)
     u32 jn = ji;
+    if (BIG && DO_MLEN) ev_zero_row5(slab, blockIdx.x + ji, HN, gt, NT);
     EvRegs er;
     SpJobRegs pj;   // job of the tiles being prefetched (index jn), held in scalar registers
     load_job(pj, jobs.j[ji]);
@@ -383,7 +394,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
         act_var = g0 + sg < lim;
     }
-    if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, g0 + sg - pj.tile0, tid_, nhr, LO, false, wave);
+    if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, g0 + sg - pj.tile0, tid_, nhr, LO, false, wave, HI);
     // Read-dense stretches (deep data: every tile far above the list capacities): after two such tiles in a row the
     // workgroup hands the REST of its tile range in this chromosome to the window kernels in one go (flags only, nothing
     // staged): the event kernel then costs two tiles per workgroup instead of a wasted pass over everything.  (NSG == 1)
@@ -424,7 +435,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         asm volatile("" : "+v"(tid));
         const u32 lane = tid & 63;
         u32 cF[EV_NQ] = {0, 0}, cR[EV_NQ] = {0, 0}, cE[EV_NQ] = {0, 0}, cEh = 0, cRh = 0, pendM = 0, pendU = 0;
-        const bool h_below = HAS_M && ev_role_mlo<BIG>(tid, LO), h_above = HAS_M && wave == 2 && lane < 9;
+        const bool h_below = HAS_M && ev_role_mlo<BIG>(tid, LO), h_above = HAS_M && wave == 2 && lane < HI / 4u;
         const u32 hb = ev_role_mlo_index<BIG>(tid);
         const bool h_r = wave == 3 && lane < nhr;
         u32 pF = 0, pR = 0, pE = 0, pH = 0, sF = 0, sR = 0, sH = 0, sE = 0, sX = 0;
@@ -586,6 +597,9 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                 } else if (h_above) {
                     const u32 oa = TXb + TE0 + TE1 + (eX >> 16);
                     ap_emit(Eh, er.h, oa, BIAS + EV_TB + 128u * lane, LE);
+                    // (BIG with the mappable-length pairs: the run edges further above the tile than the read length are in
+                    // the list as PARTNERS of the pairs only; the edge events of fsum / rsum end in front of them)
+                    if (BIG && DO_MLEN && lane == EV_HI / 4u) sgb[L::MISC + 1] = oa;
                 }
                 if (tid >= 2 * EV_PAD && tid < 2 * EV_PAD + 4) LE[nE + tid - 2 * EV_PAD] = EV_POS;   // sentinels
                 cntM += pendM;
@@ -639,26 +653,67 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         }
         EV_STAMP(3)
         // ---- prefetch the next tile into the (now free) registers ----
-        if (gnext < g1) {
-            if (gnext >= pj.tile_end) {   // rare: the next tile belongs to the next job
-                jn = ji + 1;
-                load_job(pj, jobs.j[jn]);
-                next_skip = false;
+        // (BIG with the mappable-length pairs: issued BEHIND their global atomics, after B1 -- the memory operations of a wave
+        // complete in issue order, so loads queued behind the atomics wait for them by the time they are needed, a tile
+        // later, at no cost; atomics queued behind the loads were waited for at every barrier of the next tile: +22 %)
+        constexpr bool LATE_FETCH = BIG && DO_MLEN;
+        auto prefetch_next = [&]() {
+            if (gnext < g1) {
+                if (gnext >= pj.tile_end) {   // rare: the next tile belongs to the next job
+                    jn = ji + 1;
+                    load_job(pj, jobs.j[jn]);
+                    next_skip = false;
+                }
+                if (NSG > 1) {
+                    const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
+                    act_var = gnext + sg < lim;
+                }
+                if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, gnext + sg - pj.tile0, tid, nhr, LO, NSG == 1 && next_skip, wave, HI);
+            } else if (NSG > 1) {
+                act_var = false;
             }
-            if (NSG > 1) {
-                const u32 lim = pj.tile_end < g1 ? pj.tile_end : g1;
-                act_var = gnext + sg < lim;
-            }
-            if (NSG == 1 || act_var) ev_fetch_job<HAS_M, BIG>(er, pj, gnext + sg - pj.tile0, tid, nhr, LO, NSG == 1 && next_skip, wave);
-        } else if (NSG > 1) {
-            act_var = false;
-        }
-        const bool fetched_skip = NSG == 1 && next_skip;
+        };
+        if (!LATE_FETCH) prefetch_next();
         EV_STAMP(4)
         if (EV_PRIO_STAGE) __builtin_amdgcn_s_setprio(0);
         __syncthreads();   // B1: lists, M words and edge ranks visible
         if (EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(EV_PRIO_EVENTS);
         EV_STAMP(5)
+        if (LATE_FETCH) {
+            if (do_edges) {
+                // beyond 1023 lags (round 4): no LDS is left for a row of lags (the histograms of 5000 shifts fill a CU at two
+                // workgroups), and the pairs are few -- ~60 edges per tile, ~4 partners each --: they are added straight to row 5
+                // of the (workgroup, job) segment in the slab with device-scope atomics (zeroed when the workgroup entered
+                // the job).  This replaces the pair pass over M (k_autocorr_pairs: 0.44 ms of config 5's 3.7, M read twice).
+                u32 *const gEE = slab + ((size_t)(blockIdx.x + ji) * EV_SEG_ROWS + 5u) * HN;
+                const u32 nEt = TE0 + TE1;
+                // (one wave per block of 64 edges.  Tried: every wave walking all edges and taking every fourth partner, as in the
+                // edge events -- four times the atomic instructions with a quarter of the lanes each: 3.45 -> 3.5-3.8 ms, unstable)
+                for (u32 b = (wave + 1) & 3; 64 * b < nEt; b += 4) {
+                    const u32 i = 64 * b + lane;
+                    const bool in = i < nEt;
+                    const u32 ent = in ? LE[TXb + i] : 0u;
+                    const u32 pos = ent & EV_POS, hi = pos + max_lag;
+                    u32 e = in ? TXb + i + 1 : nE;
+                    u32 e0 = LE[e];
+                    bool h0 = (e0 & EV_POS) <= hi;
+                    while (__ballot(h0)) {
+                        // WORKGROUP scope: the row belongs to this workgroup alone while the kernel runs, and its waves share one
+                        // CU, hence one L2 -- the add is done there.  At device scope every add is a memory-side operation on a
+                        // line of its own: 37 M of them per config-5 step cost the kernel +0.65 ms (measured).
+#ifndef EV_ABL_NOEE
+                        if (h0) __hip_atomic_fetch_add(&gEE[(e0 & EV_POS) - pos], (u32)(((int32_t)(e0 ^ ent) >> 31) | 1), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+                        e = h0 ? e + 1 : nE;
+                        e0 = LE[e];
+                        h0 = (e0 & EV_POS) <= hi;
+                    }
+                }
+            }
+            prefetch_next();
+        }
+        const bool fetched_skip = NSG == 1 && next_skip;
         if (NSG == 1 && had_dense) {
             const u32 v = __builtin_amdgcn_readfirstlane(sgb[L::MISC]);   // thread 0's verdict on the job (see job_mode)
             job_mode = v > job_mode ? v : job_mode;
@@ -734,10 +789,12 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
             // Every wave walks the same edges and takes every fourth read of a range (two per trip).  A range starts at the
             // first read of its 512-bit block (idxF / idxR, written by the emit): the reads below the range are misses like
             // any other, so there is no search.
+            // (the edges an event can come from: all of the list, or -- see the emit -- all below the extra halo above the tile)
+            const u32 nEv = (HAS_M && BIG && DO_MLEN && HI > EV_HI) ? __builtin_amdgcn_readfirstlane(sgb[L::MISC + 1]) : nE;
             if (HAS_M)
-                for (u32 eb = 0; eb < nE; eb += 64) {
+                for (u32 eb = 0; eb < nEv; eb += 64) {
                     const u32 i = eb + lane;
-                    const bool in = i < nE;
+                    const bool in = i < nEv;
                     const u32 ee = in ? LE[i] : 0u;
                     const int32_t j = (int32_t)(ee & EV_POS);
                     const u32 sgn = (u32)(((int32_t)ee >> 31) | 1);   // E[j]: -1 falling, +1 rising
@@ -801,7 +858,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         {
             // ---- run edges of the tile x the edges within max_lag above them: the mappable-length autocorrelation (also
             // for a tile whose READS went to the window kernel) ----
-            if (DO_MLEN && do_edges) {
+            if (!BIG && DO_MLEN && do_edges) {
                 const u32 dumpEE = L::o_dump(HN) - L::o_ee(HN) + lane;
                 const u32 nEt = TE0 + TE1;   // the tile's own edges sit at list indices [TXb, TXb + nEt)
                 for (u32 b = (wave + 1) & 3; 64 * b < nEt; b += 4) {
@@ -951,6 +1008,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
             }
         }
         if (jn != ji) {
+            if (BIG && DO_MLEN) ev_zero_row5(slab, blockIdx.x + jn, HN, gt, NT);   // (the barrier at the top of the loop follows)
             job_mode = 0;
             next_skip = false;
             unreported = 0;

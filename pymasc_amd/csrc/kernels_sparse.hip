@@ -2111,6 +2111,10 @@ __global__ void __launch_bounds__(1024) k_plan_flagged(const PlanLaunch a, const
 
 // ---- host side ----------------------------------------------------------------------------------------------
 
+static int launch_autocorr_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag, uint32_t mode, uint32_t read_len,
+                                 uint32_t max_shift, uint32_t out_stride, const uint32_t *pre_flag0, const unsigned char *pre_flags,
+                                 const u32 *pre_nflagged);
+
 static uint32_t lg_slot_lanes(uint32_t nshifts)   // nshifts = shifts handled per slot
 {
     const u32 need = (nshifts + 31) / 32;
@@ -2232,18 +2236,9 @@ static bool events_enabled()
     return on;
 }
 
-int pmx_events_can_fuse_mlen(uint32_t max_shift, uint32_t max_lag)
-{
-    static const bool fuse = [] {   // PMX_CC_FUSE_MLEN=0: the mappable-length pass stays a pass of its own
-        const char *e = getenv("PMX_CC_FUSE_MLEN");
-        return !(e && e[0] == '0');
-    }();
-    return events_enabled() && fuse && max_shift <= 1023 && max_lag <= 1023;   // one histogram row of 1024 lags
-}
-
 // ---- the event kernel beyond 1023 shifts (BIG instantiations) ----
 struct EvBigPlan {
-    u32 hn, lo, nsg, lds_bytes, wg_per_cu;
+    u32 hn, lo, nsg, lds_bytes, wg_per_cu, hi;
 };
 
 static bool events_big_enabled()
@@ -2259,12 +2254,20 @@ static bool events_big_enabled()
 // Geometry of a BIG launch: histogram length, staged M below a tile, and the number of sub-groups per workgroup that puts
 // the most wavefronts on a CU (16 at 128 VGPRs; ties go to the smaller workgroup: more independent phase groups).
 // PMX_EV_NSG=1|2|4 in the environment forces the sub-group count (A/B).
+// fused_lag != 0: the mappable-length pairs are taken by this launch too, so the run edges up to fused_lag bits ABOVE a tile
+// must be in its list: that many more dwords of M are staged above it (EV_HI otherwise); one wavefront loads them (<= 64 quads)
 template <bool HAS_M>
-static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p)
+static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p, uint32_t fused_lag = 0)
 {
     typedef EvLds<HAS_M, true> L;
     const u32 hn = (max_shift + 1 + 127) / 128 * 128;
     const u32 lo = ((2 * max_shift + 31) / 32 + 3) / 4 * 4;
+    u32 hi = EV_HI;
+    if (fused_lag) {
+        const u32 need = ((fused_lag + 31) / 32 + 2 + 3) / 4 * 4;
+        hi = need > EV_HI ? need : EV_HI;
+        if (hi > 256u) return false;
+    }
     static const int forced = [] {
         const char *e = getenv("PMX_EV_NSG");
         return e ? atoi(e) : 0;
@@ -2273,7 +2276,7 @@ static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p)
     u32 best_waves = 0;
     for (u32 nsg = 1; nsg <= 4; nsg *= 2) {
         if (forced && (u32)forced != nsg) continue;
-        const u32 bytes = L::total(hn, lo, nsg) * 4 + 16;   // + the static stub
+        const u32 bytes = L::total(hn, lo, nsg, hi) * 4 + 16;   // + the static stub
         if (bytes > lds_cu) continue;
         u32 per_cu = lds_cu / (bytes + 256);                // (allocation granularity)
         if (per_cu * nsg > 4) per_cu = 4 / nsg;
@@ -2283,6 +2286,7 @@ static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p)
             best_waves = waves;
             p->hn = hn;
             p->lo = lo;
+            p->hi = hi;
             p->nsg = nsg;
             p->lds_bytes = bytes - 16;
             p->wg_per_cu = per_cu;
@@ -2316,11 +2320,12 @@ static u32 ev_resident_per_cu(pmx_ctx *ctx, u32 built_for)
     return (u32)n < built_for ? (u32)n : built_for;
 }
 
-template <bool HAS_M, bool DO_NCC, u32 NSG>
+template <bool HAS_M, bool DO_NCC, u32 NSG, bool DO_MLEN = false>
 static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTableRef &tab, u32 n, u32 total, u32 tpw, u32 nwg, u32 c,
-                         u32 max_shift, u32 nhr, unsigned char *d_flags, u32 *d_nflagged, u32 *d_jobstat)
+                         u32 max_shift, u32 nhr, unsigned char *d_flags, u32 *d_nflagged, u32 *d_jobstat, u32 fused_lag = 0,
+                         unsigned char *d_flags_ac = nullptr)
 {
-    auto kern = k_cc_events<HAS_M, DO_NCC, false, NSG, true, SpJobTableRef>;
+    auto kern = k_cc_events<HAS_M, DO_NCC, DO_MLEN, NSG, true, SpJobTableRef>;
     static bool attr_set[EV_MAX_DEVICES];   // (per device function AND device: set once per GPU of the process, see ev_resident_per_cu)
     const int dev = ctx->device >= 0 && ctx->device < EV_MAX_DEVICES ? ctx->device : -1;
     if (dev < 0 || !attr_set[dev]) {
@@ -2328,8 +2333,8 @@ static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTableRef 
                                     160 * 1024 - 64));
         if (dev >= 0) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256 * NSG), pl.lds_bytes, ctx->stream, tab, n, total, tpw, c, max_shift, nhr, 0u,
-                       pl.hn, pl.lo, ctx->d_slab, d_flags, d_flags, d_nflagged, d_jobstat);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256 * NSG), pl.lds_bytes, ctx->stream, tab, n, total, tpw, c, max_shift, nhr, fused_lag,
+                       pl.hn, pl.lo, pl.hi, ctx->d_slab, d_flags, d_flags_ac ? d_flags_ac : d_flags, d_nflagged, d_jobstat);
     PMX_CHECK_LAUNCH("k_cc_events (max_shift > 1023)");
     return PMX_OK;
 }
@@ -2380,15 +2385,19 @@ static int launch_cc_window_chunks(pmx_ctx *ctx, const std::vector<VJob> &vjobs,
 // shift range), then -- for the tiles it flagged as dense only -- the window kernel in chunks of 1024 shifts, whose sums a
 // gated reduce adds to the rows.  The mappable-length pass is not fused here (the caller runs k_autocorr_pairs).
 static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_shift, uint32_t read_len,
-                                bool do_ncc, uint32_t out_stride, const ReduceSpec &rs, u32 nr, u32 nz)
+                                bool do_ncc, uint32_t out_stride, const ReduceSpec &rs, u32 nr, u32 nz, uint32_t fused_lag,
+                                pmx_fused_mlen *fused)
 {
     const bool has_m = jobs[0].d_M != nullptr;
     const u32 c = read_len - 1;
     EvBigPlan pl;
-    if (!(has_m ? ev_big_plan<true>(max_shift, &pl) : ev_big_plan<false>(max_shift, &pl))) {
+    // the mappable-length pairs in the same launch (round 4), when the caller asks for it and the geometry allows it
+    bool fuse_mlen = has_m && fused && fused_lag && pmx_events_can_fuse_mlen(max_shift, fused_lag) && ev_big_plan<true>(max_shift, &pl, fused_lag);
+    if (!fuse_mlen && !(has_m ? ev_big_plan<true>(max_shift, &pl) : ev_big_plan<false>(max_shift, &pl))) {
         pmx_set_error("k_cc_events: no launch geometry for max_shift %u", max_shift);
         return PMX_ERR_INVALID;
     }
+    if (fuse_mlen) fused->done = true;   // row MLEN and scalar [2] are written by this call
     std::vector<uint32_t> flag0(njobs);
     uint64_t total_flags = 0;
     for (uint32_t i = 0; i < njobs; i++) {
@@ -2398,12 +2407,15 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
     const size_t flag_bytes = (size_t)((total_flags + 15) / 16 * 16);
     const uint32_t per_launch = njobs < SP_MAXJOBS_REF ? njobs : SP_MAXJOBS_REF;
     const size_t stat_bytes = 4 * (size_t)per_launch * sizeof(u32);
-    int rc = pmx_ensure_flags_cc(ctx, flag_bytes + 16 + stat_bytes);
+    // [flags of the cc window kernel][flags of the autocorrelation window kernel (fused pairs only)][counters][job statistics]
+    const size_t nflag_arrays = fuse_mlen ? 2 : 1;
+    int rc = pmx_ensure_flags_cc(ctx, nflag_arrays * flag_bytes + 16 + stat_bytes);
     if (rc) return rc;
     unsigned char *d_flags = ctx->d_flags_cc;
-    u32 *d_nflagged = (u32 *)(ctx->d_flags_cc + flag_bytes);
+    unsigned char *d_flags_ac = fuse_mlen ? ctx->d_flags_cc + flag_bytes : nullptr;
+    u32 *d_nflagged = (u32 *)(ctx->d_flags_cc + nflag_arrays * flag_bytes);
     u32 *d_jobstat = d_nflagged + 4;     // per job: tiles seen / read-dense / edge-dense (k_cc_events, one sub-group)
-    PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, flag_bytes + 16 + stat_bytes, ctx->stream));
+    PMX_HIP(hipMemsetAsync(ctx->d_flags_cc, 0, nflag_arrays * flag_bytes + 16 + stat_bytes, ctx->stream));
     ctx->flags_cc_zeroed[0] = ctx->flags_cc_zeroed[1] = ctx->flags_cc_dirty[0] = ctx->flags_cc_dirty[1] = 0;   // (see ev_flag_area)
 
     ReduceSpec rs_ev = rs;
@@ -2433,11 +2445,15 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
         pmx_timed_launch tl;
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_EVENTS, &tl);
         if (rc) return rc;
-#define EVB(HM, NC)                                                                                                         \
-    (pl.nsg == 1   ? ev_big_launch<HM, NC, 1>(ctx, pl, ref, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat)  \
-     : pl.nsg == 2 ? ev_big_launch<HM, NC, 2>(ctx, pl, ref, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat)  \
-                   : ev_big_launch<HM, NC, 4>(ctx, pl, ref, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat))
-        rc = has_m ? (do_ncc ? EVB(true, true) : EVB(true, false)) : EVB(false, true);
+#define EVB(HM, NC, ML)                                                                                                                 \
+    (pl.nsg == 1   ? ev_big_launch<HM, NC, 1, ML>(ctx, pl, ref, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat,  \
+                                                  ML ? fused_lag : 0u, d_flags_ac)                                                      \
+     : pl.nsg == 2 ? ev_big_launch<HM, NC, 2, ML>(ctx, pl, ref, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat,  \
+                                                  ML ? fused_lag : 0u, d_flags_ac)                                                      \
+                   : ev_big_launch<HM, NC, 4, ML>(ctx, pl, ref, n, total, tpw, nwg, c, max_shift, nhr, d_flags, d_nflagged, d_jobstat,  \
+                                                  ML ? fused_lag : 0u, d_flags_ac))
+        if (fuse_mlen) rc = do_ncc ? EVB(true, true, true) : EVB(true, false, true);
+        else rc = has_m ? (do_ncc ? EVB(true, true, false) : EVB(true, false, false)) : EVB(false, true, false);
 #undef EVB
         if (rc) return rc;
         rc = pmx_prof_end(ctx, &tl);
@@ -2445,6 +2461,25 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
         hipLaunchKernelGGL(k_reduce_segments<SpJobTableRef>, dim3(32, nr + nz, n), dim3(256), 0, ctx->stream,
                            (const u32 *)ctx->d_slab, ref, (u32)EV_SEG_ROWS, rs_ev, (const u32 *)nullptr);
         PMX_CHECK_LAUNCH("k_reduce_segments");
+        if (fuse_mlen) {
+            // the pair sums EE = P - N (row 5, signed) -> the P row of the jobs' scratch, N cleared, popcount(M) and the run
+            // count (scalars 4, 5) -> its scalars: what k_autocorr_pairs + k_reduce_pairs leave there
+            const u32 lagcap = (u32)(((size_t)fused_lag + 1 + 1023) / 1024 * 1024);
+            ReduceSpec r2;
+            memset(&r2, 0, sizeof r2);
+            r2.nrows = 2;
+            r2.src_row[0] = 5; r2.dst_row[0] = 0; r2.is_signed[0] = 1;
+            r2.src_row[1] = 4; r2.dst_row[1] = 2 * lagcap; r2.is_scalar[1] = 1; r2.scalar_off = 4;
+            r2.nzero = 1;
+            r2.zero_row[0] = lagcap;
+            r2.use_out2 = 1;
+            r2.n_override = fused_lag + 1;
+            r2.out_stride = out_stride;
+            r2.rowlen = pl.hn;
+            hipLaunchKernelGGL(k_reduce_segments<SpJobTableRef>, dim3(32, 3, n), dim3(256), 0, ctx->stream, (const u32 *)ctx->d_slab, ref,
+                               (u32)EV_SEG_ROWS, r2, (const u32 *)nullptr);
+            PMX_CHECK_LAUNCH("k_reduce_segments (mappable-length pairs)");
+        }
         if (has_m) {
             EvTailPlan tp;
             memset(&tp, 0, sizeof tp);
@@ -2459,7 +2494,11 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
     expand_chunks(jobs, njobs, max_shift + 1, vjobs, flag0.data());
     ReduceSpec rs_w = rs;
     rs_w.accumulate = 1;
-    return launch_cc_window_chunks(ctx, vjobs, has_m, do_ncc, (int32_t)c, rs_w, nr, nz, d_flags, d_nflagged);
+    rc = launch_cc_window_chunks(ctx, vjobs, has_m, do_ncc, (int32_t)c, rs_w, nr, nz, d_flags, d_nflagged);
+    if (rc || !fuse_mlen) return rc;
+    // the window kernel of the mappable-length pass for the tiles whose run edges were not listed (normally none) and the
+    // recurrence A(k+1) = 2 A(k) - A(k-1) - EE(k) -> row MLEN and scalar [2]
+    return launch_autocorr_batch(ctx, jobs, njobs, fused_lag, 1, read_len, max_shift, out_stride, flag0.data(), d_flags_ac, d_nflagged + 1);
 }
 
 // jobs one call of pmx_launch_cc_sparse_batch takes: launches with a device-side job table take the whole batch
@@ -2469,6 +2508,24 @@ uint32_t pmx_autocorr_batch_jobs(void) { return SP_MAXJOBS_REF; }
 int pmx_events_take_big(uint32_t max_shift)
 {
     return max_shift > 1023 && max_shift <= EV_MAX_SHIFT && events_enabled() && events_big_enabled();
+}
+
+int pmx_events_can_fuse_mlen(uint32_t max_shift, uint32_t max_lag)
+{
+    static const bool fuse = [] {   // PMX_CC_FUSE_MLEN=0: the mappable-length pass stays a pass of its own
+        const char *e = getenv("PMX_CC_FUSE_MLEN");
+        return !(e && e[0] == '0');
+    }();
+    if (!(events_enabled() && fuse)) return 0;
+    if (max_shift <= 1023) return max_lag <= 1023;   // one histogram row of 1024 lags
+    // beyond: the pairs go to the slab with global atomics (k_cc_events, BIG + DO_MLEN); the run edges up to max_lag bits above a
+    // tile are staged by one wavefront (PMX_CC_FUSE_MLEN_BIG=0: the pair pass over M stays a pass of its own, A/B)
+    static const bool fuse_big = [] {
+        const char *e = getenv("PMX_CC_FUSE_MLEN_BIG");
+        return !(e && e[0] == '0');
+    }();
+    EvBigPlan pl;
+    return fuse_big && pmx_events_take_big(max_shift) && ev_big_plan<true>(max_shift, &pl, max_lag);
 }
 
 // does the event kernel take this shift range at all (the density probe of pmx_cc_batch_dev only matters then)
@@ -2553,7 +2610,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     rs.keep_scalar2 = (has_m && !zero_mlen) ? 1 : 0;
 
     if (!ctx->window_only && pmx_events_take_big(max_shift))
-        return launch_cc_events_big(ctx, jobs, njobs, max_shift, read_len, do_ncc, out_stride, rs, nr, nz);
+        return launch_cc_events_big(ctx, jobs, njobs, max_shift, read_len, do_ncc, out_stride, rs, nr, nz, fused_lag, fused);
 
     std::vector<VJob> vjobs;
     expand_chunks(jobs, njobs, max_shift + 1, vjobs);
@@ -2627,7 +2684,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             const u32 nhr = (max_shift + 1 + 127) / 128;   // quads of R above a tile that hold partners of its forward reads
 #define EV_LAUNCH_(HM, NC, ML, DP)                                                                                     \
     hipLaunchKernelGGL((k_cc_events<HM, NC, ML, 1, false, SpJobTable, DP>), dim3(nwg), dim3(256), 0, ctx->stream, tab, n, total, tpw, \
-                       (u32)c, max_shift, nhr, fused_lag, 1024u, (u32)EV_LO, ctx->d_slab, d_flags, d_flags_ac, d_nflagged, d_jobstat)
+                       (u32)c, max_shift, nhr, fused_lag, 1024u, (u32)EV_LO, (u32)EV_HI, ctx->d_slab, d_flags, d_flags_ac, d_nflagged, d_jobstat)
 #define EV_LAUNCH(HM, NC, ML)                \
     do {                                     \
         if (deep) EV_LAUNCH_(HM, NC, ML, HM); \
@@ -2774,6 +2831,16 @@ size_t pmx_autocorr_scratch_words(uint32_t max_lag)
 int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag, uint32_t mode,
                                     uint32_t read_len, uint32_t max_shift, uint32_t out_stride)
 {
+    return launch_autocorr_batch(ctx, jobs, njobs, max_lag, mode, read_len, max_shift, out_stride, nullptr, nullptr, nullptr);
+}
+
+// pre_flags != nullptr: the event kernel (max_shift > 1023, fused mappable-length pairs) has left the pair sums, popcount(M)
+// and the run count in the jobs' scratch and flagged the tiles whose run edges it could not list (pre_flag0[job]: index of
+// the job's first tile in pre_flags): only the window kernel for those tiles + the recurrence remain.
+static int launch_autocorr_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs, uint32_t max_lag, uint32_t mode,
+                                 uint32_t read_len, uint32_t max_shift, uint32_t out_stride, const uint32_t *pre_flag0,
+                                 const unsigned char *pre_flags, const u32 *pre_nflagged)
+{
     if (njobs == 0) return PMX_OK;
     const bool chunked = max_lag > 1023;
     const u32 lagcap = (u32)(((size_t)max_lag + 1 + 1023) / 1024 * 1024);
@@ -2786,10 +2853,12 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
         const char *e = getenv("PMX_AUTOCORR_PAIRS");
         return !(e && e[0] == '0');
     }();
-    const bool use_pairs = pairs_enabled && max_lag + 1 <= AP_MAX_LAGS;
+    const bool use_pairs = !pre_flags && pairs_enabled && max_lag + 1 <= AP_MAX_LAGS;
     std::vector<uint32_t> flag0(njobs, 0);
-    unsigned char *d_flags = nullptr;
-    u32 *d_nflagged = nullptr;
+    unsigned char *d_flags = const_cast<unsigned char *>(pre_flags);
+    u32 *d_nflagged = const_cast<u32 *>(pre_nflagged);
+    if (pre_flags)
+        for (uint32_t i = 0; i < njobs; i++) flag0[i] = pre_flag0[i];
     const u32 nl = (max_lag + 1 + 63) / 64 * 64;
     int rc;
     if (use_pairs) {
@@ -2864,7 +2933,7 @@ int pmx_launch_autocorr_edges_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t 
     rs.src_row[1] = 1; rs.dst_row[1] = lagcap;       // N
     rs.src_row[2] = 2; rs.dst_row[2] = 2 * lagcap; rs.is_scalar[2] = 1;
     rs.use_out2 = 1;
-    rs.accumulate = use_pairs ? 1 : 0;
+    rs.accumulate = (use_pairs || pre_flags) ? 1 : 0;
     rs.out_stride = out_stride;
 
     for (size_t lo = 0; lo < vjobs.size(); lo += SP_MAXJOBS_REF) {
