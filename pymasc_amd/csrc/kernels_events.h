@@ -80,6 +80,19 @@
 #ifndef EV_PRIO_EDGES
 #define EV_PRIO_EDGES EV_PRIO_EVENTS
 #endif
+#ifndef EV_EDGE_ROLES
+#define EV_EDGE_ROLES 1
+#endif
+#ifndef EV_PAIR_SLOT
+#define EV_PAIR_SLOT(w) (w)     // the first block of 64 forward reads a wave takes in the pair loop (then every fourth)
+#endif
+// (the pair loop deals its blocks of 64 forward reads to waves 0, 1, 2, 3, 0, 1: waves 0 and 1 carry two)
+#ifndef EV_ROLE_F
+#define EV_ROLE_F 1
+#define EV_ROLE_A 2
+#define EV_ROLE_B0 3
+#define EV_ROLE_B1 0
+#endif
 #ifndef EV_WAVES
 #define EV_WAVES 5
 #endif
@@ -732,7 +745,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
             // ---- forward reads x reverse reads in [x, x + S]: ncc, mscc.cc ----
             // No predication: an event that misses is added to the lane's dump slot of the row; idle lanes carry x = 0
             // (every distance from it exceeds S: list positions start at BIAS), finished lanes park on the sentinel.
-            for (u32 b = wave; b < nbF; b += 4) {
+            for (u32 b = EV_PAIR_SLOT(wave); b < nbF; b += 4) {
                 const u32 i = 64 * b + lane;
                 const u32 ent = i < nF ? LF[i] : 0u;
                 const u32 x = ent & EV_POS, xc = x + c;
@@ -799,23 +812,35 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                     const int32_t j = (int32_t)(ee & EV_POS);
                     const u32 sgn = (u32)(((int32_t)ee >> 31) | 1);   // E[j]: -1 falling, +1 rising
                     const int32_t tile_end = (int32_t)(BIAS + EV_TB);
+                    // Which wave walks which range (round 4).  Until round 3 EVERY wave walked all three ranges of every edge and took
+                    // every fourth read: three loop set-ups per wave and edge block, and runs of ~1.6 reads per lane whose longest
+                    // decides the trips.  Now a range belongs to a wave -- wave 1 the forward reads, wave 2 type A, waves 3 and 0
+                    // the halves of type B (twice the reads: 2 S) --: one set-up per wave, longer runs per lane (EV_EDGE_ROLES=0: the old deal).
+#if EV_EDGE_ROLES
+                    const bool roleF = wave == EV_ROLE_F, roleA = wave == EV_ROLE_A, roleB = wave == EV_ROLE_B0 || wave == EV_ROLE_B1;
+                    const u32 woffF = 0, wstrF = 1, woffA = 0, wstrA = 1;
+                    const u32 wstrB = EV_ROLE_B0 == EV_ROLE_B1 ? 1u : 2u, woffB = (EV_ROLE_B0 != EV_ROLE_B1 && wave == EV_ROLE_B1) ? 1u : 0u;
+#else
+                    const bool roleF = true, roleA = true, roleB = true;
+                    const u32 woffF = wave, wstrF = 4, woffA = wave, wstrA = 4, woffB = wave, wstrB = 4;
+#endif
                     // -- forward reads --
-                    {
+                    if (roleF) {
                         const int32_t lo = j - (int32_t)c;
                         const u32 span = in ? S : 0u;
                         int32_t bb = (lo - (int32_t)BIAS) >> 9;
                         bb = bb < 0 ? 0 : (bb > 128 ? 128 : bb);
-                        u32 idx = (u32)idxF[bb] + wave;
-                        u32 e0 = LF[idx], e1 = LF[idx + 4];
+                        u32 idx = (u32)idxF[bb] + woffF;
+                        u32 e0 = LF[idx], e1 = LF[idx + wstrF];
                         u32 u0 = (e0 & EV_POS) - (u32)lo, u1 = (e1 & EV_POS) - (u32)lo;
                         bool more = (int32_t)u0 < (int32_t)span;   // this lane's entry is still below the end of its range
                         if (__ballot(more)) do {                   // (bottom-tested: see the pair loop)
                             const bool h0 = u0 < span && (e0 >> 31) != 0, h1 = u1 < span && (e1 >> 31) != 0;
                             ev_add_cell<BIG>(hGF, h0 ? u0 + 1 : dumpGF, sgn);
                             ev_add_cell<BIG>(hGF, h1 ? u1 + 1 : dumpGF, sgn);
-                            idx = more ? idx + 8 : idx;
+                            idx = more ? idx + 2 * wstrF : idx;
                             e0 = LF[idx];
-                            e1 = LF[idx + 4];
+                            e1 = LF[idx + wstrF];
                             u0 = (e0 & EV_POS) - (u32)lo;
                             u1 = (e1 & EV_POS) - (u32)lo;
                             more = (int32_t)u0 < (int32_t)span;
@@ -824,6 +849,8 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                     // -- reverse reads, type A and type B (the halo entries above the tile are not drivers: the span ends at the tile end) --
 #pragma unroll
                     for (u32 kind = 0; kind < 2; kind++) {
+                        if (!(kind == 0 ? roleA : roleB)) continue;   // (uniform)
+                        const u32 woff = kind == 0 ? woffA : woffB, wstr = kind == 0 ? wstrA : wstrB;
                         const int32_t lo = kind == 0 ? j : j - (int32_t)c;
                         int32_t sp = tile_end - lo;
                         const int32_t full = kind == 0 ? (int32_t)S : 2 * (int32_t)S;
@@ -831,8 +858,8 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                         const u32 span = (in && sp > 0) ? (u32)sp : 0u;
                         int32_t bb = (lo - (int32_t)BIAS) >> 9;
                         bb = bb < 0 ? 0 : (bb > 128 ? 128 : bb);
-                        u32 idx = (u32)idxR[bb] + wave;
-                        u32 p0 = LR[idx], p1 = LR[idx + 4];
+                        u32 idx = (u32)idxR[bb] + woff;
+                        u32 p0 = LR[idx], p1 = LR[idx + wstr];
                         u32 u0 = p0 - (u32)lo, u1 = p1 - (u32)lo;
                         bool more = (int32_t)u0 < (int32_t)span;
                         if (__ballot(more)) do {
@@ -841,9 +868,9 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                             const u32 q0 = h0 ? (kind == 0 ? p0 + c - 2 * d0 : p0 - d0 + 1) : BIAS;
                             const u32 q1 = h1 ? (kind == 0 ? p1 + c - 2 * d1 : p1 - d1 + 1) : BIAS;
                             const u32 m0 = MT[q0 >> 5], m1 = MT[q1 >> 5];
-                            idx = more ? idx + 8 : idx;
+                            idx = more ? idx + 2 * wstr : idx;
                             p0 = LR[idx];
-                            p1 = LR[idx + 4];
+                            p1 = LR[idx + wstr];
                             // -E[j] M[q]
                             ev_add_cell<BIG>(hGR, h0 ? d0 : dumpGR, (0u - sgn) * ((m0 >> (q0 & 31u)) & 1u));
                             ev_add_cell<BIG>(hGR, h1 ? d1 : dumpGR, (0u - sgn) * ((m1 >> (q1 & 31u)) & 1u));
@@ -954,32 +981,117 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                         *dst = v;
                     }
                 } else {
-#pragma nounroll
-                    for (u32 i = gt; i < 2u * 1024u; i += NT) {
-                        // LDS rows GF|EE, GR -> segment rows 1 (GF), 5 (EE), 3 (GR)
-                        const u32 r = i >> 10, k = i & 1023u;
-                        const u32 w = hGF[i];
-                        hGF[i] = 0;
-                        u32 v = w;
-                        if (r == 0) {
-                            const int32_t lo16 = (int32_t)(short)(w & 0xffffu);
-                            v = (u32)lo16;
-                            if (DO_MLEN) {
-                                const u32 e = (u32)(int32_t)(short)((w - (u32)lo16) >> 16);
-                                u32 *de = seg + (size_t)5 * 1024 + k;
-                                *de = add ? *de + e : e;
+                    // max_shift <= 1023 (round 4): the rows leave the workgroup TRANSFORMED -- the inclusive prefix sums of GF and GR,
+                    // and for the edge pairs the recurrence's A(|c - d|) of THIS flush's (popcount(M), runs, EE) --, because all of
+                    // them are linear: the sum over the workgroups of the transformed rows is the transform of the sums.  What
+                    // remains for k_events_finish is a column sum, which any number of workgroups can share (one workgroup per row
+                    // read chromosome 1's 103 segments at ~30 GB/s: 17 us).  Arithmetic modulo 2^32: every total is below 2^32
+                    // (the launcher keeps vectors of 2^32 bits and more off this path).
+                    // (a) the scalars of this flush: the recurrence starts from them
+                    {
+                        u32 v[4] = {cntB, cnt0, cntM, cntU};
+#pragma unroll
+                        for (u32 k = 0; k < 4; k++)
+                            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+                        if ((gt & 63u) == 0) {
+#pragma unroll
+                            for (u32 k = 0; k < 4; k++)
+                                if (k < 2 || DO_MLEN) atomicAdd(&xch[8 + 2 + k], v[k]);
+                        }
+                        cntB = cnt0 = cntM = cntU = 0;
+                    }
+                    __syncthreads();
+                    const u32 a0 = xch[8 + 4], runs = xch[8 + 5];
+                    // (b) cells 4 t .. 4 t + 3 of the three rows
+                    const u32 k0 = 4 * gt;
+                    const uint4 wgf = *reinterpret_cast<const uint4 *>(hGF + k0), wgr = *reinterpret_cast<const uint4 *>(hGF + 1024 + k0);
+                    const u32 cgf[4] = {wgf.x, wgf.y, wgf.z, wgf.w}, cgr[4] = {wgr.x, wgr.y, wgr.z, wgr.w};
+                    u32 pgf[4], pgr[4], dl[4], tGF = 0, tGR = 0, tX = 0;
+#pragma unroll
+                    for (u32 j = 0; j < 4; j++) {
+                        const int32_t lo16 = (int32_t)(short)(cgf[j] & 0xffffu);
+                        const int32_t ee = (int32_t)(short)((cgf[j] - (u32)lo16) >> 16);
+                        tGF += (u32)lo16;
+                        tGR += cgr[j];
+                        tX += (k0 + j == 0) ? 0u - runs : 0u - (u32)ee;    // x(0) = -runs, x(k) = -EE(k)
+                        pgf[j] = tGF;
+                        pgr[j] = tGR;
+                        dl[j] = tX;
+                    }
+                    u32 sGF = tGF, sGR = tGR, sX = tX;
+                    wave_inclusive_scan3(sGF, sGR, sX);
+                    if ((gt & 63u) == 63u) {
+                        wt[0 + (gt >> 6)] = sGF;
+                        wt[4 + (gt >> 6)] = sGR;
+                        wt[8 + (gt >> 6)] = sX;
+                    }
+                    __syncthreads();
+                    u32 bGF = sGF - tGF, bGR = sGR - tGR, bX = sX - tX;
+                    for (u32 w = 0; w < (gt >> 6); w++) {
+                        bGF += wt[w];
+                        bGR += wt[4 + w];
+                        bX += wt[8 + w];
+                    }
+                    u32 tD = 0, ex[4];
+#pragma unroll
+                    for (u32 j = 0; j < 4; j++) {
+                        pgf[j] += bGF;
+                        pgr[j] += bGR;
+                        dl[j] += bX;          // Delta(k), inclusive
+                        ex[j] = tD;           // ... and the sum of the Deltas below k inside the thread
+                        tD += dl[j];
+                    }
+                    {
+                        uint4 *d1 = reinterpret_cast<uint4 *>(seg + 1 * 1024 + k0), *d3 = reinterpret_cast<uint4 *>(seg + 3 * 1024 + k0);
+                        uint4 v1 = make_uint4(pgf[0], pgf[1], pgf[2], pgf[3]), v3 = make_uint4(pgr[0], pgr[1], pgr[2], pgr[3]);
+                        if (add) {
+                            const uint4 o1 = *d1, o3 = *d3;
+                            v1.x += o1.x; v1.y += o1.y; v1.z += o1.z; v1.w += o1.w;
+                            v3.x += o3.x; v3.y += o3.y; v3.z += o3.z; v3.w += o3.w;
+                        }
+                        *d1 = v1;
+                        *d3 = v3;
+                    }
+                    if (DO_MLEN) {
+                        // A(k) = a0 + the sum of Delta(t) over t < k, then row 5 holds A(|c - d|) for the shifts d = 0 .. S
+                        u32 sD = wave_inclusive_scan(tD);
+                        __syncthreads();                    // (wt was read above)
+                        if ((gt & 63u) == 63u) wt[12 + (gt >> 6)] = sD;
+                        __syncthreads();
+                        u32 bD = sD - tD;
+                        for (u32 w = 0; w < (gt >> 6); w++) bD += wt[12 + w];
+                        *reinterpret_cast<uint4 *>(hGF + k0) = make_uint4(a0 + bD + ex[0], a0 + bD + ex[1], a0 + bD + ex[2], a0 + bD + ex[3]);
+                        __syncthreads();
+#pragma unroll
+                        for (u32 j = 0; j < 4; j++) {
+                            const u32 d = k0 + j;
+                            if (d <= S) {
+                                const int32_t k = (int32_t)c - (int32_t)d;
+                                const u32 av = hGF[k < 0 ? -k : k];
+                                u32 *de = seg + (size_t)5 * 1024 + d;
+                                *de = add ? *de + av : av;
                             }
                         }
-                        u32 *dst = seg + (size_t)(2 * r + 1) * 1024 + k;
-                        *dst = add ? *dst + v : v;
+                        __syncthreads();
                     }
+                    *reinterpret_cast<uint4 *>(hGF + k0) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4 *>(hGF + 1024 + k0) = make_uint4(0, 0, 0, 0);
+                    // (c) the scalar row of the segment and the chromosome's totals (k_events_finish reads six words per job)
+                    if (gt < 6) {
+                        const u32 v = xch[8 + gt];
+                        u32 *ds = seg + 4 * HN + gt;
+                        *ds = add ? *ds + v : v;
+                        if (v) atomicAdd(EV_JOBSUM(jobstat) + 6 * ji + gt, (unsigned long long)v);
+                    }
+                    __syncthreads();
+                    if (gt < 6) xch[8 + gt] = 0;
                 }
             }
             accF = 0;
             accR = 0;
             accE = 0;
             seg_written = true;
-            if (leaving) {
+            if (leaving && !(!BIG && HAS_M)) {   // (max_shift <= 1023 with a track: written with every flush, above)
                 // scalars: |F|, |R|, Bf, R0, popcount(M), runs -> row 4 of the segment
                 u32 v[6] = {0, 0, cntB, cnt0, cntM, cntU};
 #pragma unroll
@@ -1004,8 +1116,8 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                 cnt0 = 0;
                 cntM = 0;
                 cntU = 0;
-                seg_written = false;
             }
+            if (leaving) seg_written = false;
         }
         if (jn != ji) {
             if (BIG && DO_MLEN) ev_zero_row5(slab, blockIdx.x + jn, HN, gt, NT);   // (the barrier at the top of the loop follows)
@@ -1033,163 +1145,96 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
 // Round 4.  Until round 3 the step behind k_cc_events was k_reduce_segments2 (16 us), k_plan_flagged (6 us), two window
 // launches that return at once (2 x 6 us), k_events_tail (8 us) and a memset in front (5 us): 0.057 ms of a 0.49-ms step,
 // and as much as a rank's whole share of the kernel at 8 GPUs.  (Folding the sums into the event kernel's epilogue -- the
-// last workgroup of a chromosome -- was priced and not built: ONE workgroup reads another CU's fresh data at 40-70 GB/s,
+// last workgroup of a chromosome -- was priced and not built: ONE workgroup reads another CU's fresh data at 30-70 GB/s,
 // chromosome 1's 103 segments of 24 KB would take 35-60 us at the end of the kernel, where every workgroup finishes at the
-// same time; a launch of its own spreads the same bytes over 150 workgroups of 1024 threads.)
-// grid (EVF_TASKS, njobs + 1), 1024 threads; block (task, job):
-//   task 0  scalar row: |F|, |R|, path marker, zero fill (popcount(M) belongs to task 5 / to a separate pass)
-//   task 1  ncc           row 0 of the segments, summed over the workgroups of the chromosome
-//   task 2  mscc.ccbins   row 2
-//   task 3  mscc.fsum     Bf - inclusive prefix of the signed sums of row 1 (GF)
-//   task 4  mscc.rsum     R0 + inclusive prefix of the signed sums of row 3 (GR)
-//   task 5  mappable_len  (fused pass) EE = row 5, popcount(M), runs -> the recurrence of k_autocorr_finish -> row MLEN and
-//                         scalar [2]; P / N / scalars are also left in the job's scratch, where the slow path of k_events_tail
-//                         (tiles flagged for the autocorrelation window kernel) adds to them and redoes the recurrence
-//   rows the batch does not produce are written as zeros by the block of their task.
-// row njobs of the grid: block 0 / 1 plan the two window launches (k_plan_flagged's work: returns at once when nothing
-// was flagged); the other blocks clear the OTHER flag area of the context for the next call (see ev_flag_area).
+// same time.)  The event kernel hands its rows over TRANSFORMED (prefix sums taken, recurrence run, see its flush), so that
+// nothing but column sums is left -- and those are cut into EVF_CHUNKS x rows x chromosomes workgroups (a first version with
+// one workgroup per row, prefix sums here, took 17 us: a workgroup reads fresh data of other CUs at ~30 GB/s).
+// grid (EVF_CHUNKS, EVF_TASKS, njobs + 1), 1024 threads; block (chunk, task, job), 128 columns per chunk:
+//   task 0  (chunk 0) the scalar row: |F|, |R|, popcount(M) with the fused mappable-length pass, path marker, zero fill
+//   task 1  ncc           sum of row 0
+//   task 2  mscc.ccbins   sum of row 2
+//   task 3  mscc.fsum     Bf - sum of row 1 (prefix sums of GF)
+//   task 4  mscc.rsum     R0 + sum of row 3 (prefix sums of GR)
+//   task 5  mappable_len  sum of row 5 (A(|c - d|) per flush)
+//   rows the batch does not produce are written as zeros by the blocks of their task.  Sums modulo 2^32 (all totals are
+//   below: the launcher keeps vectors of 2^32 bits and more off this path).
+// slice njobs of the grid: blocks 0 / 1 plan the two window launches (returns at once when nothing was flagged); the
+// others clear the OTHER flag area of the context for the next call (see ev_flag_area).
 #define EVF_TASKS 6u
+#define EVF_CHUNKS 8u
 struct EvFinishArgs {
     const u32 *slab;
     const unsigned long long *jobsum;   // [6 per job] |F|, |R|, Bf, R0, popcount(M), runs: added up by k_cc_events (EV_JOBSUM)
-    u32 S, out_stride, has_m, do_ncc, fused_mlen, zero_mlen, keep_scalar2, max_lag, lagcap;
-    int32_t c;
+    u32 S, out_stride, has_m, do_ncc, fused_mlen, zero_mlen, keep_scalar2;
     uint4 *zero_area;     // the other flag area (16-byte units), cleared for the next call
     u32 zero_quads;
 };
 
-__device__ __forceinline__ void evf_zero_row(u64 *dst, u32 n, u32 tid)
-{
-    for (u32 k = tid; k < n; k += 1024) dst[k] = 0;
-}
-
-// sum over the workgroups [w0, w1] of row `row` of their segments for this job, columns 4 t4 .. 4 t4 + 3 (four groups of 256
-// threads take every fourth segment with 16-byte loads, SIXTEEN in flight per thread: a block that reads another CU's fresh
-// data is bound by round trips, chromosome 1 has 103 segments), combined in `acc[1024]` (LDS, zeroed here)
-template <bool SIGNED>
-__device__ __forceinline__ void evf_sum_row(const u32 *__restrict__ slab, u32 job, u32 w0, u32 w1, u32 row, unsigned long long *acc,
-                                            u32 tid)
-{
-    acc[tid] = 0;
-    const u32 g = tid >> 8, t4 = tid & 255u;
-    const size_t stride = (size_t)EV_SEG_ROWS * 1024;
-    const u32 *p = slab + (size_t)job * stride + (size_t)row * 1024 + 4 * t4;
-    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (u32 wb = w0 + g; wb <= w1; wb += 64) {
-        uint4 v[16];
-#pragma unroll
-        for (u32 k = 0; k < 16; k++) {
-            const u32 w = wb + 4 * k;
-            v[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(w <= w1 ? w : w1) * stride);   // (clamped: no branch between the loads)
-        }
-#pragma unroll
-        for (u32 k = 0; k < 16; k++) {
-            const bool in = wb + 4 * k <= w1;
-            if (SIGNED) {
-                s0 += in ? (unsigned long long)(long long)(int32_t)v[k].x : 0ull;
-                s1 += in ? (unsigned long long)(long long)(int32_t)v[k].y : 0ull;
-                s2 += in ? (unsigned long long)(long long)(int32_t)v[k].z : 0ull;
-                s3 += in ? (unsigned long long)(long long)(int32_t)v[k].w : 0ull;
-            } else {
-                s0 += in ? v[k].x : 0u;
-                s1 += in ? v[k].y : 0u;
-                s2 += in ? v[k].z : 0u;
-                s3 += in ? v[k].w : 0u;
-            }
-        }
-    }
-    __syncthreads();
-    atomicAdd(&acc[4 * t4 + 0], s0);
-    atomicAdd(&acc[4 * t4 + 1], s1);
-    atomicAdd(&acc[4 * t4 + 2], s2);
-    atomicAdd(&acc[4 * t4 + 3], s3);
-    __syncthreads();
-}
-
 __global__ void __launch_bounds__(1024)
 k_events_finish(const SpJobTable jobs, u32 njobs, const EvFinishArgs a, const PlanLaunch pcc, const PlanLaunch pac)
 {
-    __shared__ unsigned long long acc[1024];
-    __shared__ long long part[256];
-    __shared__ unsigned long long sc[8];
-    const u32 tid = threadIdx.x, task = blockIdx.x, job = blockIdx.y;
+    __shared__ u32 acc[128];
+    const u32 tid = threadIdx.x, chunk = blockIdx.x, task = blockIdx.y, job = blockIdx.z;
     if (job == njobs) {
-        if (task == 0) plan_flagged(pcc);
-        else if (task == 1) plan_flagged(pac);
+        const u32 id = task * EVF_CHUNKS + chunk, nid = EVF_TASKS * EVF_CHUNKS;
+        if (id == 0) plan_flagged(pcc);
+        else if (id == 1) plan_flagged(pac);
         else
-            for (u32 i = (task - 2) * 1024 + tid; i < a.zero_quads; i += (EVF_TASKS - 2) * 1024) a.zero_area[i] = make_uint4(0, 0, 0, 0);
+            for (u32 i = (id - 2) * 1024 + tid; i < a.zero_quads; i += (nid - 2) * 1024) a.zero_area[i] = make_uint4(0, 0, 0, 0);
         return;
     }
     const SpJobDev &jb = jobs.j[job];
-    const u32 w0 = jb.wg_first, w1 = jb.wg_last, S = a.S, n = S + 1;
+    const u32 S = a.S, n = S + 1;
     u64 *const out = jb.out;
     const size_t os = a.out_stride;
-    if (tid < 6) sc[tid] = a.jobsum[6 * job + tid];   // |F|, |R|, Bf, R0, popcount(M), runs of the chromosome (k_cc_events)
-    __syncthreads();
+    const unsigned long long *js = a.jobsum + 6 * job;
     if (task == 0) {
+        if (chunk != 0) return;
         u64 *dst = out + (size_t)PMX_ROW_SCALARS * os;
         for (u32 k = tid; k < a.out_stride; k += 1024) {
-            if (k == 2 && (a.keep_scalar2 || a.fused_mlen)) continue;   // (popcount(M): task 5 / the autocorrelation pass)
-            dst[k] = k < 2 ? sc[k] : (k == 3 ? (u64)PMX_PATH_SPARSE : 0ull);
+            if (k == 2 && a.keep_scalar2 && !a.fused_mlen) continue;   // (popcount(M): a pass of its own writes it)
+            dst[k] = k < 2 ? js[k] : (k == 2 ? (a.fused_mlen ? js[4] : 0ull) : (k == 3 ? (u64)PMX_PATH_SPARSE : 0ull));
         }
         return;
     }
-    if (task == 1 || task == 2) {
-        const u32 dst_row = task == 1 ? PMX_ROW_NCC_CCBINS : PMX_ROW_MSCC_CCBINS;
-        u64 *dst = out + (size_t)dst_row * os;
-        if (task == 1 ? !a.do_ncc : !a.has_m) {
-            evf_zero_row(dst, a.out_stride, tid);
-            return;
-        }
-        evf_sum_row<false>(a.slab, job, w0, w1, task == 1 ? 0u : 2u, acc, tid);
-        if (tid < n) dst[tid] = acc[tid];
+    const u32 dst_row = task == 1 ? PMX_ROW_NCC_CCBINS : task == 2 ? PMX_ROW_MSCC_CCBINS : task == 3 ? PMX_ROW_MSCC_FSUM
+                        : task == 4 ? PMX_ROW_MSCC_RSUM : PMX_ROW_MLEN;
+    const bool produced = task == 1 ? a.do_ncc != 0 : task == 5 ? a.fused_mlen != 0 : a.has_m != 0;
+    const u32 col0 = 128 * chunk;
+    u64 *dst = out + (size_t)dst_row * os;
+    if (!produced) {
+        // a row this batch leaves empty (the mappable-length row only if no pass of its own will write it)
+        if (task != 5 || !a.has_m || a.zero_mlen)
+            for (u32 k = col0 + tid; k < a.out_stride && k < col0 + 128; k += 1024) dst[k] = 0;
+        if (chunk == EVF_CHUNKS - 1 && (task != 5 || !a.has_m || a.zero_mlen))
+            for (u32 k = 128 * EVF_CHUNKS + tid; k < a.out_stride; k += 1024) dst[k] = 0;
         return;
     }
-    if (task == 3 || task == 4) {
-        u64 *dst = out + (size_t)(task == 3 ? PMX_ROW_MSCC_FSUM : PMX_ROW_MSCC_RSUM) * os;
-        if (!a.has_m) {
-            evf_zero_row(dst, a.out_stride, tid);
-            return;
-        }
-        evf_sum_row<true>(a.slab, job, w0, w1, task == 3 ? 1u : 3u, acc, tid);
-        const long long x = (long long)acc[tid];
-        const long long incl = block_exclusive_offset(x, part, tid) + x;
-        if (tid < n) dst[tid] = (u64)(task == 3 ? (long long)sc[2] - incl : (long long)sc[3] + incl);
-        return;
-    }
-    // task 5: the mappable-length row
-    u64 *dst = out + (size_t)PMX_ROW_MLEN * os;
-    if (!a.fused_mlen) {
-        if (!a.has_m || a.zero_mlen) evf_zero_row(dst, a.out_stride, tid);   // (else: a pass of its own writes the row)
-        return;
-    }
-    evf_sum_row<true>(a.slab, job, w0, w1, 5u, acc, tid);
-    const long long a0 = (long long)sc[4], runs = (long long)sc[5];
-    const long long ee = (long long)acc[tid];
-    {
-        // what k_autocorr_pairs + k_reduce_pairs leave in the job's scratch: P = EE (signed), N = 0, popcount(M), runs
-        u64 *P = jb.out2, *N = jb.out2 + a.lagcap, *scal = jb.out2 + 2 * (size_t)a.lagcap;
-        if (tid <= a.max_lag) {
-            P[tid] = (u64)ee;
-            N[tid] = 0;
-        }
-        if (tid == 0) {
-            scal[0] = (u64)a0;
-            scal[1] = (u64)runs;
-        }
-    }
-    // A(k+1) = 2 A(k) - A(k-1) - EE(k): Delta(k) = inclusive prefix of x, x(0) = -runs, x(k) = -EE(k); A(k) = a0 + exclusive
-    // prefix of Delta (autocorr_finish_job)
-    const long long x = tid == 0 ? -runs : (tid <= a.max_lag ? -ee : 0ll);
-    const long long delta = block_exclusive_offset(x, part, tid) + x;
-    const long long A = a0 + block_exclusive_offset(delta, part, tid);
+    if (col0 >= n) return;
+    const u32 src_row = task == 1 ? 0u : task == 2 ? 2u : task == 3 ? 1u : task == 4 ? 3u : 5u;
+    if (tid < 128) acc[tid] = 0;
     __syncthreads();
-    acc[tid] = (unsigned long long)A;
+    // 32 lanes x 16 bytes cover the chunk's 128 columns of one segment row; the 32 groups of 32 lanes take every 32nd segment
+    const u32 q = tid & 31u, g = tid >> 5;
+    const size_t stride = (size_t)EV_SEG_ROWS * 1024;
+    const u32 *p = a.slab + (size_t)job * stride + (size_t)src_row * 1024 + col0 + 4 * q;
+    u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (u32 w = jb.wg_first + g; w <= jb.wg_last; w += 32) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p + (size_t)w * stride);
+        s0 += v.x;
+        s1 += v.y;
+        s2 += v.z;
+        s3 += v.w;
+    }
+    atomicAdd(&acc[4 * q + 0], s0);
+    atomicAdd(&acc[4 * q + 1], s1);
+    atomicAdd(&acc[4 * q + 2], s2);
+    atomicAdd(&acc[4 * q + 3], s3);
     __syncthreads();
-    if (tid == 0) out[(size_t)PMX_ROW_SCALARS * os + 2] = (u64)a0;
-    if (tid < n) {
-        const int32_t k = a.c - (int32_t)tid;
-        dst[tid] = acc[k < 0 ? -k : k];
+    if (tid < 128 && col0 + tid < n) {
+        const u32 t = acc[tid];
+        dst[col0 + tid] = task == 3 ? (u64)(u32)((u32)js[2] - t) : task == 4 ? (u64)(u32)((u32)js[3] + t) : (u64)t;
     }
 }
 
@@ -1235,6 +1280,8 @@ k_events_tail(const u32 *__restrict__ slab, const JT jobs, const EvTailPlan plan
             // ranges (k_plan_flagged) when there is one, else the host's static range)
             const u32 i0 = plan_ac ? plan_ac[PLAN_JOBWG + 2 * job] : plan.ac_first[job];
             const u32 i1 = plan_ac ? plan_ac[PLAN_JOBWG + 2 * job + 1] : plan.ac_last[job] + 1;
+            // (prefix_done: the event pass's share of the row is written already -- k_events_finish --; the window kernel's
+            // sums are put into the scratch on their own and their recurrence is ADDED to the row, mode 2)
             for (u32 k = tid; k <= max_lag; k += EV_TAIL_THREADS) {
                 u64 sp = 0, sn = 0;
 #pragma unroll 4
@@ -1244,8 +1291,8 @@ k_events_tail(const u32 *__restrict__ slab, const JT jobs, const EvTailPlan plan
                     sp += seg[k];
                     sn += seg[1024 + k];
                 }
-                P[k] += sp;
-                N[k] += sn;
+                P[k] = prefix_done ? sp : P[k] + sp;
+                N[k] = prefix_done ? sn : N[k] + sn;
             }
             if (tid < 2) {
                 u64 sc = 0;
@@ -1253,12 +1300,12 @@ k_events_tail(const u32 *__restrict__ slab, const JT jobs, const EvTailPlan plan
                     const u32 w = plan_ac ? plan_ac[PLAN_LIST + i] : i;
                     sc += slab_ac[(size_t)(w + job) * stride + 2 * 1024 + tid];
                 }
-                scal[tid] += sc;
+                scal[tid] = prefix_done ? sc : scal[tid] + sc;
             }
             __threadfence_block();
             __syncthreads();
         }
-        autocorr_finish_job(jb, part, max_lag, lagcap, 1u, c, S, out_stride, EV_TAIL_THREADS);
+        autocorr_finish_job(jb, part, max_lag, lagcap, prefix_done ? 2u : 1u, c, S, out_stride, EV_TAIL_THREADS);
         return;
     }
     if (has_m && blockIdx.y == 0 && !prefix_done) {

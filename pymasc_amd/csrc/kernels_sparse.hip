@@ -685,7 +685,7 @@ template <bool HAS_M, bool DO_NCC, bool CH, typename JT = SpJobTable>
 __global__ void __launch_bounds__(256, CH ? (HAS_M ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
 k_cc_sparse(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
             u32 *__restrict__ slab, const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged,
-            const u32 *__restrict__ plan)
+            const u32 *__restrict__ plan, u32 add_stride = 0)
 {
     if (n_flagged && *n_flagged == 0) return;   // the event kernel took every tile (uniform over the whole grid)
     typedef SpLds<HAS_M> L;
@@ -896,6 +896,29 @@ k_cc_sparse(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t
                 if (tid == 0) {   // popcount(F), popcount(R): bit_array_num_bits_set of mscc.pyx:236-237
                     seg[4 * 1024 + 0] = totF;
                     seg[4 * 1024 + 1] = totR;
+                }
+                if (add_stride) {
+                    // Behind the event pass (max_shift <= 1023, round 4): the rows of the chromosome are written already
+                    // (k_events_finish) and this workgroup ADDS its share of the flagged tiles to them with 64-bit atomics --
+                    // every thread the entries it has just written to the segment itself --, so that no launch is needed
+                    // behind the window kernels (k_events_tail summed their segments until round 3: a launch in every
+                    // step for tiles that the ordinary workload does not have).
+                    const SpJobDev &jd = jobs.j[j];
+                    unsigned long long *out = reinterpret_cast<unsigned long long *>(jd.out);
+                    const u32 dst_row[4] = {PMX_ROW_NCC_CCBINS, PMX_ROW_MSCC_FSUM, PMX_ROW_MSCC_CCBINS, PMX_ROW_MSCC_RSUM};
+#pragma unroll 1
+                    for (u32 r = 0; r < 4; r++) {
+                        if (r == 0 ? !DO_NCC : !HAS_M) continue;
+#pragma unroll 1
+                        for (u32 d = tid; d < jd.d_n; d += 256) {
+                            const u32 v = seg[r * 1024 + d];
+                            if (v) atomicAdd(&out[(size_t)dst_row[r] * add_stride + d], (unsigned long long)v);
+                        }
+                    }
+                    if (tid == 0) {
+                        if (totF) atomicAdd(&out[(size_t)PMX_ROW_SCALARS * add_stride + 0], (unsigned long long)totF);
+                        if (totR) atomicAdd(&out[(size_t)PMX_ROW_SCALARS * add_stride + 1], (unsigned long long)totR);
+                    }
                 }
                 totF = 0;
                 totR = 0;
@@ -1338,10 +1361,13 @@ __device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 fi
     }
 }
 
+__device__ __forceinline__ long long block_exclusive_offset(long long local_sum, long long *part, u32 tid);   // (below)
+
 template <bool CH, typename JT = SpJobTable>
 __global__ void __launch_bounds__(256, CH ? AC_WAVES_CH : AC_WAVES)
 k_autocorr_edges(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab,
-                 const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged, const u32 *__restrict__ plan = nullptr)
+                 const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged, const u32 *__restrict__ plan = nullptr,
+                 u32 add_stride = 0, int32_t add_c = 0, u32 add_shift = 0, u32 add_lag = 0)
 {
     typedef AcLds L;
     if (n_flagged && *n_flagged == 0) return;   // the pair kernel took every tile (uniform over the whole grid)
@@ -1485,6 +1511,47 @@ k_autocorr_edges(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u3
                 if (tid == 0) {
                     seg[2048 + 0] = cursor[4] + cursor[5] + cursor[6] + cursor[7];     // popcount(M) of my tiles
                     seg[2048 + 1] = cursor[8] + cursor[9] + cursor[10] + cursor[11];   // runs starting in my tiles
+                }
+                if (!CH && add_stride) {
+                    // Behind the event pass with the fused mappable-length pairs (max_lag <= 1023, round 4): the recurrence
+                    // A(k+1) = 2 A(k) - A(k-1) - EE(k) is LINEAR in (popcount(M), runs, EE), so this workgroup runs it on its
+                    // own share -- the flagged tiles it took -- and adds A(|c - d|) to the row the event pass has written
+                    // (k_events_finish); no launch behind the window kernels.  64-bit, two's complement: a share may be negative.
+                    const long long a0 = (long long)(cursor[4] + cursor[5] + cursor[6] + cursor[7]);
+                    const long long runs = (long long)(cursor[8] + cursor[9] + cursor[10] + cursor[11]);
+                    long long *const A = reinterpret_cast<long long *>(lds + L::U);     // (tile staging: free between two tiles)
+                    long long *const part = reinterpret_cast<long long *>(lds + L::REC);
+                    __syncthreads();
+                    const u32 k0 = 4 * tid;
+                    long long x[4], dl[4], tX = 0;
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        const u32 k = k0 + q;   // (each thread reads the entries it wrote to the segment itself)
+                        x[q] = k == 0 ? -runs : (k <= add_lag ? (long long)seg[1024 + k] - (long long)seg[k] : 0ll);
+                        tX += x[q];
+                        dl[q] = tX;
+                    }
+                    const long long bX = block_exclusive_offset(tX, part, tid);   // (ends with a barrier)
+                    long long tD = 0, ex[4];
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) {
+                        dl[q] += bX;      // Delta(k), inclusive
+                        ex[q] = tD;
+                        tD += dl[q];
+                    }
+                    const long long bD = block_exclusive_offset(tD, part, tid);
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) A[k0 + q] = a0 + bD + ex[q];
+                    __syncthreads();
+                    const SpJobDev &jd = jobs.j[j];
+                    unsigned long long *out = reinterpret_cast<unsigned long long *>(jd.out);
+                    for (u32 d = tid; d <= add_shift; d += 256) {
+                        const int32_t k = add_c - (int32_t)d;
+                        const long long v = A[k < 0 ? -k : k];
+                        if (v) atomicAdd(&out[(size_t)PMX_ROW_MLEN * add_stride + d], (unsigned long long)v);
+                    }
+                    if (tid == 0 && a0) atomicAdd(&out[(size_t)PMX_ROW_SCALARS * add_stride + 2], (unsigned long long)a0);
+                    __syncthreads();
                 }
                 cntM = 0;
                 cntU = 0;
@@ -1903,11 +1970,15 @@ __device__ __forceinline__ void autocorr_finish_job(const SpJobDev &jb, long lon
     if (mode == 0) {
         for (u32 k = tid; k <= max_lag; k += nthreads) jb.out[k] = (u64)A[k];
     } else {
-        if (tid == 0) jb.out[(size_t)PMX_ROW_SCALARS * out_stride + 2] = (u64)a0;
+        // mode 2: ADDED to the row (the recurrence is linear in (popcount(M), runs, EE): the window kernel's share of a
+        // chromosome on top of what the event pass has written, k_events_tail)
+        u64 *sc2 = jb.out + (size_t)PMX_ROW_SCALARS * out_stride + 2;
+        if (tid == 0) *sc2 = mode == 2 ? *sc2 + (u64)a0 : (u64)a0;
         u64 *dst = jb.out + (size_t)PMX_ROW_MLEN * out_stride;
         for (u32 d = tid; d <= max_shift; d += nthreads) {
             const int32_t k = c - (int32_t)d;
-            dst[d] = (u64)A[k < 0 ? -k : k];
+            const u64 v = (u64)A[k < 0 ? -k : k];
+            dst[d] = mode == 2 ? dst[d] + v : v;
         }
     }
 }
@@ -2618,7 +2689,11 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         return launch_cc_window_chunks(ctx, vjobs, has_m, do_ncc, c, rs, nr, nz, nullptr, nullptr);
 
     // Pass 1 (sparse tiles): the event kernel over every chromosome; tiles whose lists would overflow are flagged.
-    const bool use_events = events_enabled() && !ctx->window_only && !chunked;
+    // (the event pass sums modulo 2^32 -- kernels_events.h, the transformed flush --: vectors of 2^32 bits and more, which no BAM
+    // file can describe, stay on the window kernels)
+    bool small_vectors = true;
+    for (uint32_t i = 0; i < njobs; i++) small_vectors = small_vectors && jobs[i].nbits < (1ull << 32);
+    const bool use_events = events_enabled() && !ctx->window_only && !chunked && small_vectors;
     const bool fuse_mlen = use_events && has_m && fused && njobs <= SP_MAXJOBS && pmx_events_can_fuse_mlen(max_shift, fused_lag);
     unsigned char *d_flags = nullptr, *d_flags_ac = nullptr;
     u32 *d_nflagged = nullptr, *d_plan_cc = nullptr, *d_plan_ac = nullptr, *d_jobstat = nullptr;
@@ -2752,12 +2827,9 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             fa.fused_mlen = fuse_mlen ? 1u : 0u;
             fa.zero_mlen = zero_mlen ? 1u : 0u;
             fa.keep_scalar2 = rs.keep_scalar2;
-            fa.max_lag = fuse_mlen ? fused_lag : 0u;
-            fa.lagcap = (u32)(((size_t)(fuse_mlen ? fused_lag : 0) + 1 + 1023) / 1024 * 1024);
-            fa.c = c;
             fa.zero_area = reinterpret_cast<uint4 *>(d_other_area);
             fa.zero_quads = (u32)(other_dirty / 16);
-            hipLaunchKernelGGL(k_events_finish, dim3(EVF_TASKS, n + 1), dim3(1024), 0, ctx->stream, tab, n, fa, pcc, pac);
+            hipLaunchKernelGGL(k_events_finish, dim3(EVF_CHUNKS, EVF_TASKS, n + 1), dim3(1024), 0, ctx->stream, tab, n, fa, pcc, pac);
             PMX_CHECK_LAUNCH("k_events_finish");
             ctx->flags_cc_dirty[(ctx->flags_cc_area & 1u)] = 0;   // (flags_cc_area already points at the other area: the next pass's)
         }
@@ -2765,7 +2837,8 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         if (rc) return rc;
 #define SP_LAUNCH(HM, NC, CK)                                                                                       \
     hipLaunchKernelGGL((k_cc_sparse<HM, NC, CK>), dim3(nwg), dim3(256), 0, ctx->stream, tabW, n, total, tpw, c, lgG, \
-                       wslab, (const unsigned char *)d_flags, (const u32 *)d_nflagged, (const u32 *)(use_events ? d_plan_cc : nullptr))
+                       wslab, (const unsigned char *)d_flags, (const u32 *)d_nflagged, (const u32 *)(use_events ? d_plan_cc : nullptr), \
+                       use_events ? out_stride : 0u)
         if (chunked) {
             if (has_m && do_ncc) SP_LAUNCH(true, true, true);
             else if (has_m) SP_LAUNCH(true, false, true);
@@ -2786,35 +2859,20 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             PMX_CHECK_LAUNCH("k_reduce_segments");
             continue;
         }
-        EvTailPlan tp;
-        memset(&tp, 0, sizeof tp);
-        for (uint32_t i = 0; i < n; i++) {
-            tp.cc_first[i] = tabW.j[i].wg_first;
-            tp.cc_last[i] = tabW.j[i].wg_last;
-        }
-        const u32 lagcap = (u32)(((size_t)(fuse_mlen ? fused_lag : 0) + 1 + 1023) / 1024 * 1024);
         if (fuse_mlen) {
-            // the autocorrelation window kernel for the flagged tiles (its own slab), same gate
+            // the autocorrelation window kernel for the flagged tiles (its own slab), same gate; like k_cc_sparse it adds its
+            // share to the rows itself: nothing is launched behind the window kernels any more (k_events_tail until round 3)
             rc = pmx_ensure_slab_ac(ctx, (size_t)(nwgA + n) * AC_SEG_ROWS * 1024);
             if (rc) return rc;
             rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl, true);
             if (rc) return rc;
             hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwgA), dim3(256), 0, ctx->stream, tabA, n, totalA, tpwA,
                                lg_slot_lanes(fused_lag + 1), ctx->d_slab_ac, (const unsigned char *)d_flags_ac, (const u32 *)(d_nflagged + 1),
-                               (const u32 *)d_plan_ac);
+                               (const u32 *)d_plan_ac, out_stride, c, max_shift, fused_lag);
             PMX_CHECK_LAUNCH("k_autocorr_edges");
             rc = pmx_prof_end(ctx, &tl);
             if (rc) return rc;
-            for (uint32_t i = 0; i < n; i++) {
-                tp.ac_first[i] = tabA.j[i].wg_first;
-                tp.ac_last[i] = tabA.j[i].wg_last;
-            }
         }
-        hipLaunchKernelGGL(k_events_tail, dim3(n, 4), dim3(EV_TAIL_THREADS), 0, ctx->stream, (const u32 *)ctx->d_slab, tab, tp,
-                           (const u32 *)ctx->d_slab_fb, (const u32 *)ctx->d_slab_ac, (const u32 *)d_nflagged, max_shift, out_stride,
-                           has_m ? 1u : 0u, do_ncc ? 1u : 0u, fuse_mlen ? fused_lag : 0u, lagcap, c, fuse_mlen ? 1u : 0u, 1024u, 1u,
-                           (const u32 *)d_plan_cc, (const u32 *)(fuse_mlen ? d_plan_ac : nullptr), 1u);
-        PMX_CHECK_LAUNCH("k_events_tail");
     }
     return PMX_OK;
 }
