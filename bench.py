@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shard", choices=["auto", "tiles", "chroms"], default="auto",
+                    help="N > 1, strong scaling: equal TILE RANGES of the genome per rank + one all-reduce(sum) of the per-chromosome rows "
+                         "(max_shift <= 1023: pmx_cc_batch_ranges_dev), or whole chromosomes by LPT + all-gather; auto: tiles where supported")
     ap.add_argument("--repeat", type=int, default=3,
                     help="repetitions of the timed region of --steps steps; the line reports the median one (min / median / max in `repetitions`)")
     ap.add_argument("--workload", choices=["hg38", "stress"], default="hg38",
@@ -276,8 +279,17 @@ def main():
     jobs = [(s, i) for s in range(nsamples) for i in range(len(chroms))]
     costs = [chroms[i][1] for (_s, i) in jobs]
     assignment = sharding.lpt_assign(costs, world)
-    mine = assignment[rank]
-    max_slots = max(len(a) for a in assignment)
+    # Tile ranges (round 4): the genome's 64-Kbit tiles in `world` equal stretches -- a rank holds whole chromosomes and a share of
+    # at most two --, partial result blocks, ONE all-reduce(sum) (BASELINE.json's north star).  Needs the event kernel of
+    # max_shift <= 1023 (pmx_cc_batch_ranges_dev); otherwise whole chromosomes by LPT and an all-gather, as in rounds 1-3.
+    job_nbits = [chroms[i][1] + L + S + 100 for (_s, i) in jobs]            # (synth.make_chromosome)
+    tiles_ok = strong and S <= 1023 and 3 <= S and L <= 1024 and args.path == "auto"
+    shard_tiles = world > 1 and (args.shard == "tiles" or (args.shard == "auto" and tiles_ok))
+    if shard_tiles and not tiles_ok:
+        raise SystemExit("--shard tiles needs strong scaling, 3 <= max_shift <= 1023, read_len <= 1024 and --path auto")
+    ranges = sharding.tile_range_assign(job_nbits, world, ffi.RANGE_TILE_BITS) if shard_tiles else None
+    mine = [j for j, _f, _c in ranges[rank]] if shard_tiles else assignment[rank]
+    max_slots = max(len(a) for a in (ranges if shard_tiles else assignment))
 
     e2e = not args.no_end_to_end
     t_gen = time.perf_counter()
@@ -315,6 +327,12 @@ def main():
 
     xtimes = []          # (start, end) events of every step's result exchange on xstream
 
+    if shard_tiles:
+        t_first = [f for _j, f, _c in ranges[rank]]
+        t_count = [c for _j, _f, c in ranges[rank]]
+        d_full = [torch.zeros((len(jobs), ffi.PMX_NROWS, stride), dtype=torch.int64, device=device) for _ in range(2)]
+        my_jobs = torch.tensor(mine, dtype=torch.int64, device=device)
+
     def step():
         # all of this rank's chromosomes in ONE pass of the kernels (pmx_cc_batch_dev) on tstream, then the exchange
         # on xstream (double-buffered result blocks)
@@ -322,14 +340,26 @@ def main():
         if nstep[0] >= 2:
             tstream.wait_event(ev_free[b])
         nstep[0] += 1
-        if vecs:
+        if vecs and shard_tiles:
+            ctx.cc_batch_ranges_dev(pF, pR, pM, pN, t_first, t_count, S, L, step_flags & ~ffi.PMX_FLAG_EVENTS_HINT, pO[b])
+        elif vecs:
             ctx.cc_batch_dev(pF, pR, pM, pN, S, L, step_flags, pO[b])
         ev_done[b].record(tstream)
         with torch.cuda.stream(xstream):
             xstream.wait_event(ev_done[b])
             x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             x0.record(xstream)
-            if world > 1 and backend != "nccl":
+            if shard_tiles:
+                # my shares into a zeroed [jobs, rows, shifts] block, ONE all-reduce(sum): every rank holds every chromosome's rows
+                d_full[b].zero_()
+                if vecs:
+                    d_full[b].index_copy_(0, my_jobs, d_rows[b][:len(mine)])
+                if backend != "nccl":
+                    rows_ = sharding.exchange_partial_rows(d_full[b].cpu())
+                else:
+                    rows_ = sharding.exchange_partial_rows(d_full[b])
+                out = (rows_, rows_.sum(dim=0))
+            elif world > 1 and backend != "nccl":
                 out = sharding.exchange_results(d_rows[b].cpu(), assignment, len(jobs))
             else:
                 out = sharding.exchange_results(d_rows[b], assignment, len(jobs), force_collectives=args.force_collectives)
@@ -384,6 +414,17 @@ def main():
 
     # consistency of the exchange: all-reduced totals == sum of gathered rows (integers, exact)
     assert torch.equal(rows.sum(dim=0), totals), "result exchange mismatch"
+    if shard_tiles:
+        # the shares must add up to whole chromosomes: every block carries ONE path marker (the share that holds tile 0 writes
+        # it), and this rank's whole chromosomes must equal a plain pmx_cc_batch_dev run of them
+        assert bool((rows[:, ffi.PMX_ROW_SCALARS, 3] == ffi.PMX_PATH_SPARSE).all()), "tile-range shares do not add up (path marker)"
+        whole = [k for k, (j, f, c) in enumerate(ranges[rank]) if c == (job_nbits[j] + ffi.RANGE_TILE_BITS - 1) // ffi.RANGE_TILE_BITS]
+        if whole:
+            k = whole[0]
+            chk = torch.zeros((ffi.PMX_NROWS, stride), dtype=torch.int64, device=device)
+            ctx.cc_batch_dev([pF[k]], [pR[k]], [pM[k]] if with_m else None, [pN[k]], S, L, step_flags, [chk.data_ptr()])
+            ctx.sync()
+            assert torch.equal(chk.to(rows.device), rows[mine[k]]), "tile-range rows differ from the whole-chromosome run"
 
     # dominant kernel + roofline from the live HIP-event timings on this rank's stream
     dom = max(ktimes, key=lambda k: ktimes[k][0])
@@ -426,7 +467,8 @@ def main():
 
     # what every rank did, in the line of rank 0 (N > 1): one driver run explains itself -- the share of the genome each rank
     # holds (LPT over whole chromosomes), its kernels' time per step, the result exchange's time on its second stream
-    loads = [sum(costs[j] for j in a) for a in assignment]
+    loads = ([sum(c for _j, _f, c in r) * ffi.RANGE_TILE_BITS for r in ranges] if shard_tiles else
+             [sum(costs[j] for j in a) for a in assignment])
     mine_info = {"rank": rank, "jobs": len(mine), "bp": int(loads[rank]),
                  "kernel_ms_per_step": {ctx.kernel_name(k): round(ktimes[k][0] / args.steps, 4) for k in ktimes if ktimes[k][1]},
                  "exchange_ms_per_step": round(exchange_ms, 4)}
@@ -435,7 +477,10 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_info)
     multi_gpu = {"ranks": world, "lpt_imbalance": (max(loads) / (sum(loads) / world) - 1.0) if sum(loads) else 0.0,
-                 "exchange": "all_gather_into_tensor(rows) + all_reduce(totals) on a second stream, overlapping the next step's kernels",
+                 "sharding": ("tile ranges: the genome's 64-Kbit tiles in equal stretches (pmx_cc_batch_ranges_dev)" if shard_tiles
+                              else "whole chromosomes, longest first (LPT)"),
+                 "exchange": ("ONE all_reduce(sum) of the per-chromosome rows" if shard_tiles else
+                              "all_gather_into_tensor(rows) + all_reduce(totals)") + " on a second stream, overlapping the next step's kernels",
                  "per_rank": per_rank,
                  "measured_on_hardware": bool(world > 1 and backend == "nccl")}
 
@@ -645,8 +690,10 @@ def main():
             "deep_lists_hint": bool(hinted and deep),
             "run_edges_per_64kbit": (round(2 * 65536 * sum(v.n_runs for v in vecs) / max(sum(v.length for v in vecs), 1), 1)
                                      if with_m and vecs else None),
-            "parallelism": f"chromosome jobs of {nsamples} genome(s) LPT-sharded over {world} GPU(s), one process per "
-                           "GPU; all-gather rows + all-reduce totals on a second stream"
+            "parallelism": (f"{nsamples} genome(s) cut into equal tile ranges over {world} GPU(s), one process per GPU; one all-reduce(sum) "
+                            "of the per-chromosome rows on a second stream" if shard_tiles else
+                            f"chromosome jobs of {nsamples} genome(s) LPT-sharded over {world} GPU(s), one process per "
+                            "GPU; all-gather rows + all-reduce totals on a second stream")
                            + (" (1-rank RCCL group, collectives forced)" if args.force_collectives and world == 1 else ""),
             "inputs_resident_in_hbm": True,
             "workload_tag": workload_tag,

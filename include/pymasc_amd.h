@@ -222,6 +222,20 @@ int pmx_cc_dev(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uin
 int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, const uint64_t *const *d_R,
                      const uint64_t *const *d_M, const uint64_t *nbits, uint32_t max_shift,
                      uint32_t read_len, uint32_t flags, uint64_t *const *d_out);
+/* The same for SHARES of chromosomes (round 4: multi-GPU runs cut the genome into equal tile ranges instead of whole
+ * chromosomes): job i computes the part of its chromosome's sums that belongs to the PMX_RANGE_TILE_BITS-bit tiles
+ * [tile_first[i], tile_first[i] + tile_count[i]) -- every pair, run-edge event and mappable position is owned by exactly
+ * one tile (the forward read's / the reverse read's / the lower edge's), so the result blocks of jobs that cover a
+ * chromosome between them ADD UP, row by row and scalar by scalar, to what pmx_cc_batch_dev writes for it (the
+ * north star's all-reduce(sum) of per-shift sums); the path marker is written by the job that holds tile 0.  The
+ * vectors are the WHOLE chromosome's (a tile's events reach max_shift + read_len bits beyond it).  3 <= max_shift
+ * <= 1023, read_len <= 1024, not with FORCE_DENSE / WINDOW_ONLY / SKIP_MLEN: ranges are taken by the event kernel
+ * (dense tiles inside them still go to the window kernels).  Asynchronous. */
+#define PMX_RANGE_TILE_BITS 65536u
+int pmx_cc_batch_ranges_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, const uint64_t *const *d_R,
+                            const uint64_t *const *d_M, const uint64_t *nbits, const uint32_t *tile_first,
+                            const uint32_t *tile_count, uint32_t max_shift, uint32_t read_len, uint32_t flags,
+                            uint64_t *const *d_out);
 /* Same as pmx_cc_dev with host buffers: uploads F, R (and M), runs, downloads the result block. Synchronous. */
 int pmx_calc_correlation(pmx_ctx *ctx, const uint64_t *h_F, const uint64_t *h_R, const uint64_t *h_M,
                          uint64_t nbits, uint32_t max_shift, uint32_t read_len, uint32_t flags,

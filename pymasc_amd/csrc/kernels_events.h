@@ -1194,7 +1194,9 @@ k_events_finish(const SpJobTable jobs, u32 njobs, const EvFinishArgs a, const Pl
         u64 *dst = out + (size_t)PMX_ROW_SCALARS * os;
         for (u32 k = tid; k < a.out_stride; k += 1024) {
             if (k == 2 && a.keep_scalar2 && !a.fused_mlen) continue;   // (popcount(M): a pass of its own writes it)
-            dst[k] = k < 2 ? js[k] : (k == 2 ? (a.fused_mlen ? js[4] : 0ull) : (k == 3 ? (u64)PMX_PATH_SPARSE : 0ull));
+            // (the path marker of a chromosome shared by several tile-range jobs -- ranks -- is written by the one that holds
+            // its first tile, so that the shares add up to it)
+            dst[k] = k < 2 ? js[k] : (k == 2 ? (a.fused_mlen ? js[4] : 0ull) : (k == 3 && jb.tile_first == 0 ? (u64)PMX_PATH_SPARSE : 0ull));
         }
         return;
     }

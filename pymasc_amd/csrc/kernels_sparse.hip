@@ -66,7 +66,9 @@ struct SpJobDev {
     u32 d_off, d_n;        // first shift and number of shifts of this chunk
     u64 *out;              // result block of the job
     u64 *out2;             // autocorrelation: per-job scratch (P, N, scalars, A)
-    u32 flag0, pad_;       // autocorrelation: index of the job's first tile in the dense-tile flag array
+    u32 flag0;             // index of the job's first tile in the dense-tile flag array
+    u32 tile_first;        // event kernel only: the job is the tiles [tile_first, tile_first + ntiles) of its chromosome (a rank's
+                           // share of it, pmx_cc_batch_ranges_dev; 0 with ntiles = all tiles otherwise)
 };
 
 struct SpJobTable {
@@ -111,7 +113,9 @@ __device__ __forceinline__ void load_job(SpJobRegs &r, const SpJobDev &j)
     r.R = j.R;
     r.M = j.M;
     r.nbits = j.nbits;
-    r.tile0 = j.tile0;
+    // (g - tile0 is the tile's index IN THE CHROMOSOME -- addresses, flags --: a job that starts at tile_first of its chromosome
+    // shifts tile0 down by it, modulo 2^32; tile_end stays the end in the launch's tile sequence)
+    r.tile0 = j.tile0 - j.tile_first;
     r.tile_end = j.tile0 + j.ntiles;
     r.aligned16 = j.aligned16;
     r.d_off = j.d_off;
@@ -2208,6 +2212,7 @@ struct VJob {
     const pmx_job *job;
     u32 d_off, d_n;
     u32 flag0;   // autocorrelation: index of the chromosome's first tile in the dense-tile flag array
+    bool ranged; // the event launch of a tile-range job: take job->tile_first / tile_count (every other launch sees the whole chromosome)
 };
 
 static void fill_plan_launch(PlanLaunch &p, const SpJobTable &tab, u32 n, u32 total, u32 nwg, u32 raw_lo, u32 raw_hi,
@@ -2234,6 +2239,11 @@ static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr,
         const uint64_t tile_bits = tile_bits_override ? tile_bits_override : (autocorr ? AC_TB : SP_TB);
         uint64_t nt = (bits + tile_bits - 1) / tile_bits;
         if (nt < 1) nt = 1;
+        uint32_t first = 0;
+        if (vj[i].ranged && jb.tile_count) {   // (validated by the caller: inside the chromosome, event tiles)
+            first = jb.tile_first;
+            nt = jb.tile_count;
+        }
         d.F = (const u32 *)jb.d_F;
         d.R = (const u32 *)jb.d_R;
         d.M = (const u32 *)jb.d_M;
@@ -2248,6 +2258,7 @@ static void plan_launch(pmx_ctx *ctx, const VJob *vj, uint32_t n, bool autocorr,
         d.out = (u64 *)jb.d_out;
         d.out2 = (u64 *)jb.d_out2;
         d.flag0 = vj[i].flag0;
+        d.tile_first = first;
         t += (u32)nt;
     }
     uint64_t want = (uint64_t)ctx->num_cus * wg_per_cu;
@@ -2289,6 +2300,7 @@ static void expand_chunks(const pmx_job *jobs, uint32_t njobs, uint32_t nshifts,
     for (uint32_t i = 0; i < njobs; i++)
         for (uint32_t off = 0; off < nshifts; off += 1024) {
             VJob v;
+            v.ranged = false;
             v.job = &jobs[i];
             v.d_off = off;
             v.d_n = nshifts - off < 1024 ? nshifts - off : 1024;
@@ -2497,6 +2509,7 @@ static int launch_cc_events_big(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njob
     for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS_REF) {
         const uint32_t n = njobs - lo < SP_MAXJOBS_REF ? njobs - lo : SP_MAXJOBS_REF;
         std::vector<VJob> ev(n);
+        for (auto &v : ev) v.ranged = false;
         for (uint32_t i = 0; i < n; i++) {
             ev[i].job = &jobs[lo + i];
             ev[i].d_off = 0;
@@ -2695,6 +2708,12 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
     for (uint32_t i = 0; i < njobs; i++) small_vectors = small_vectors && jobs[i].nbits < (1ull << 32);
     const bool use_events = events_enabled() && !ctx->window_only && !chunked && small_vectors;
     const bool fuse_mlen = use_events && has_m && fused && njobs <= SP_MAXJOBS && pmx_events_can_fuse_mlen(max_shift, fused_lag);
+    for (uint32_t i = 0; i < njobs; i++)
+        if (jobs[i].tile_count && (!use_events || (has_m && fused && !fuse_mlen))) {
+            pmx_set_error("pmx_cc_batch_ranges_dev: tile ranges are taken by the event kernel of max_shift <= 1023 only (not with "
+                          "PMX_FLAG_WINDOW_ONLY, PMX_CC_EVENTS=0 or vectors of 2^32 bits)");
+            return PMX_ERR_INVALID;
+        }
     unsigned char *d_flags = nullptr, *d_flags_ac = nullptr;
     u32 *d_nflagged = nullptr, *d_plan_cc = nullptr, *d_plan_ac = nullptr, *d_jobstat = nullptr;
     size_t flag_bytes_all = 0;     // raw length of a flag array (multiple of 16)
@@ -2751,7 +2770,11 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
                 else per_cu = EV_OCC(false, true, false, false);
 #undef EV_OCC
             }
+            // (tile-range jobs -- a rank's share of a chromosome, pmx_cc_batch_ranges_dev -- exist for this launch only: the window
+            // launches behind it see whole chromosomes and take the tiles it flagged, which lie inside the ranges)
+            for (uint32_t i = 0; i < n; i++) vjobs[lo + i].ranged = true;
             plan_launch(ctx, &vjobs[lo], n, false, per_cu, &tab, &total, &tpw, &nwg, EV_TB);
+            for (uint32_t i = 0; i < n; i++) vjobs[lo + i].ranged = false;
             rc = pmx_ensure_slab(ctx, (size_t)(nwg + n) * EV_SEG_ROWS * 1024 + (size_t)nwg * 4 * 12 * 2 + 64);
             if (rc) return rc;
             rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_EVENTS, &tl);
@@ -2780,6 +2803,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
         // at once when there are none).  Behind the event pass it writes a slab of its own and k_events_tail adds its sums.
         SpJobTable tabW, tabA;
         std::vector<VJob> va(n);
+        for (auto &v : va) v.ranged = false;
         uint32_t totalA = 0, tpwA = 0, nwgA = 0;
         memset(&tabW, 0, sizeof tabW);
         plan_launch(ctx, &vjobs[lo], n, false, chunked ? (has_m ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (has_m ? SP_WAVES : SP_WAVES_NCC), &tabW, &total, &tpw, &nwg);
@@ -2941,6 +2965,7 @@ static int launch_autocorr_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njo
         for (uint32_t lo = 0; lo < njobs; lo += SP_MAXJOBS_REF) {
             const uint32_t n = njobs - lo < SP_MAXJOBS_REF ? njobs - lo : SP_MAXJOBS_REF;
             std::vector<VJob> vj(n);
+            for (auto &v : vj) v.ranged = false;
             for (uint32_t i = 0; i < n; i++) {
                 vj[i].job = &jobs[lo + i];
                 vj[i].d_off = 0;

@@ -1170,9 +1170,39 @@ static int cc_dense_one(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, 
     return PMX_OK;
 }
 
+static int cc_batch_impl(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, const uint64_t *const *d_R,
+                         const uint64_t *const *d_M, const uint64_t *nbits, uint32_t max_shift, uint32_t read_len,
+                         uint32_t flags, uint64_t *const *d_out, const uint32_t *tile_first, const uint32_t *tile_count);
+
 int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, const uint64_t *const *d_R,
                      const uint64_t *const *d_M, const uint64_t *nbits, uint32_t max_shift, uint32_t read_len,
                      uint32_t flags, uint64_t *const *d_out)
+{
+    return cc_batch_impl(ctx, njobs, d_F, d_R, d_M, nbits, max_shift, read_len, flags, d_out, nullptr, nullptr);
+}
+
+int pmx_cc_batch_ranges_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, const uint64_t *const *d_R,
+                            const uint64_t *const *d_M, const uint64_t *nbits, const uint32_t *tile_first,
+                            const uint32_t *tile_count, uint32_t max_shift, uint32_t read_len, uint32_t flags,
+                            uint64_t *const *d_out)
+{
+    REQUIRE(tile_first && tile_count && nbits, "pmx_cc_batch_ranges_dev: NULL argument");
+    REQUIRE(max_shift >= 3 && max_shift <= 1023, "pmx_cc_batch_ranges_dev: tile ranges are for 3 <= max_shift <= 1023");
+    REQUIRE(read_len >= 1 && read_len <= 1024, "pmx_cc_batch_ranges_dev: read_len must be in [1, 1024] (the set-bit kernels)");
+    REQUIRE(!(flags & (PMX_FLAG_FORCE_DENSE | PMX_FLAG_WINDOW_ONLY | PMX_FLAG_SKIP_MLEN)),
+            "pmx_cc_batch_ranges_dev: not with FORCE_DENSE / WINDOW_ONLY / SKIP_MLEN (the event kernel takes the ranges, mappable lengths included)");
+    for (uint32_t i = 0; i < njobs; i++) {
+        const uint64_t ntiles = (nbits[i] + PMX_RANGE_TILE_BITS - 1) / PMX_RANGE_TILE_BITS;
+        REQUIRE(tile_count[i] >= 1 && (uint64_t)tile_first[i] + tile_count[i] <= ntiles,
+                "pmx_cc_batch_ranges_dev: a range must hold 1 .. ceil(nbits / 65536) - tile_first tiles of its chromosome");
+    }
+    // (a hint is needed: the density probe would decide per rank; the event kernel is what takes ranges)
+    return cc_batch_impl(ctx, njobs, d_F, d_R, d_M, nbits, max_shift, read_len, flags | PMX_FLAG_EVENTS_HINT, d_out, tile_first, tile_count);
+}
+
+static int cc_batch_impl(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, const uint64_t *const *d_R,
+                         const uint64_t *const *d_M, const uint64_t *nbits, uint32_t max_shift, uint32_t read_len,
+                         uint32_t flags, uint64_t *const *d_out, const uint32_t *tile_first, const uint32_t *tile_count)
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_F && d_R && nbits && d_out, "pmx_cc_batch_dev: NULL argument");
@@ -1201,7 +1231,7 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             REQUIRE(d_out[i], "pmx_cc_batch_dev: NULL output in the batch");
             wide[i] = (uint64_t *)ctx->d_pad_stage + (size_t)i * PMX_NROWS * kstride;
         }
-        int rc = pmx_cc_batch_dev(ctx, njobs, d_F, d_R, d_M, nbits, 3, read_len, flags, wide.data());
+        int rc = cc_batch_impl(ctx, njobs, d_F, d_R, d_M, nbits, 3, read_len, flags, wide.data(), nullptr, nullptr);
         if (rc) return rc;
         for (uint32_t i = 0; i < njobs; i++)
             PMX_HIP(hipMemcpy2DAsync(d_out[i], stride * sizeof(u64), wide[i], kstride * sizeof(u64), stride * sizeof(u64),
@@ -1267,6 +1297,8 @@ int pmx_cc_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_F, c
             jobs[i].nbits = nbits[lo + i];
             jobs[i].d_out = d_out[lo + i];
             jobs[i].d_out2 = has_m ? (uint64_t *)(ctx->d_scratch + (size_t)i * ac_words) : nullptr;
+            jobs[i].tile_first = tile_first ? tile_first[lo + i] : 0;
+            jobs[i].tile_count = tile_count ? tile_count[lo + i] : 0;
         }
         // fork: the mappable-length pass on the auxiliary stream, beside the set-bit kernel (they share no output word:
         // row MLEN and scalar [2] belong to the autocorrelation, everything else to the cross-correlation)

@@ -162,6 +162,7 @@ struct pmx_job {
     uint64_t nbits;
     uint64_t *d_out;                   // result block [PMX_NROWS][out_stride] (or the lag row, autocorr mode 0)
     uint64_t *d_out2;                  // autocorrelation only: pmx_autocorr_scratch_words(max_lag) u64 of per-job scratch
+    uint32_t tile_first, tile_count;   // pmx_cc_batch_ranges_dev: the 64-Kbit tiles of the chromosome this job takes (count 0: all)
 };
 // Whether the event kernel took the mappable-length pass as well (edge pairs in k_cc_events, the autocorrelation window
 // kernel for the tiles it flagged, the recurrence in k_events_tail).

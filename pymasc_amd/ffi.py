@@ -25,6 +25,7 @@ PMX_NROWS = 6
 PMX_FLAG_SKIP_NCC = 1
 PMX_FLAG_WINDOW_ONLY = 16
 PMX_FLAG_DEEP_LISTS = 32
+RANGE_TILE_BITS = 65536        # PMX_RANGE_TILE_BITS: the unit of pmx_cc_batch_ranges_dev
 PMX_FLAG_EVENTS_HINT = 64     # the caller knows the data fits the event kernel's lists (no density probe, no synchronisation)
 PMX_FLAG_FORCE_DENSE = 2
 PMX_FLAG_FORCE_SPARSE = 4
@@ -54,7 +55,7 @@ EXPORTS = [
     "pmx_bits_count",
     "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_ex", "pmx_feed_reads_delta16", "pmx_bits_set_regions_async", "pmx_bits_build_batch",
     "pmx_bits_build_status",
-    "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
+    "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_cc_batch_ranges_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
     "pmx_mappable_len_batch_dev",
     "pmx_ctx_set_profiling", "pmx_ctx_reset_kernel_times", "pmx_ctx_kernel_time", "pmx_kernel_name",
     "pmx_debug_poison", "pmx_debug_read_slab", "pmx_debug_set_max_workgroups",
@@ -110,6 +111,7 @@ def load_library(path: Optional[str] = None):
     L.pmx_mappable_len_batch_dev.argtypes = [vp, u32, vp, vp, u32, u32, vp]
     L.pmx_cc_dev.argtypes = [vp, vp, vp, vp, u64, u32, u32, u32, vp]
     L.pmx_cc_batch_dev.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, vp]
+    L.pmx_cc_batch_ranges_dev.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, u32, u32, u32, vp]
     L.pmx_calc_correlation.argtypes = [vp, vp, vp, vp, u64, u32, u32, u32, vp]
     L.pmx_mappable_len_dev.argtypes = [vp, vp, u64, u32, u32, vp]
     L.pmx_mappable_len.argtypes = [vp, vp, u64, u32, u32, vp]
@@ -504,6 +506,19 @@ class Context:
         aM = arr(d_M) if d_M is not None else None
         _check(self._L, self._L.pmx_cc_batch_dev(self._h, n, aF, aR, aM, aN, int(max_shift), int(read_len),
                                                  int(flags), aO))
+
+    def cc_batch_ranges_dev(self, d_F, d_R, d_M, nbits, tile_first, tile_count, max_shift: int, read_len: int, flags: int, d_out):
+        """pmx_cc_batch_ranges_dev: job i computes the share of its chromosome's sums that belongs to the RANGE_TILE_BITS-bit tiles
+        [tile_first[i], tile_first[i] + tile_count[i]); the blocks of jobs that cover a chromosome add up to its result."""
+        n = len(d_F)
+        assert len(d_R) == n and len(nbits) == n and len(d_out) == n and (d_M is None or len(d_M) == n)
+        assert len(tile_first) == n and len(tile_count) == n
+        arr = lambda xs: (ctypes.c_uint64 * n)(*[int(x) for x in xs])
+        arr32 = lambda xs: (ctypes.c_uint32 * n)(*[int(x) for x in xs])
+        aF, aR, aN, aO = arr(d_F), arr(d_R), arr(nbits), arr(d_out)
+        aM = arr(d_M) if d_M is not None else None
+        _check(self._L, self._L.pmx_cc_batch_ranges_dev(self._h, n, aF, aR, aM, aN, arr32(tile_first), arr32(tile_count),
+                                                        int(max_shift), int(read_len), int(flags), aO))
 
     def calc_correlation(self, F: np.ndarray, R: np.ndarray, M: Optional[np.ndarray], nbits: int, max_shift: int,
                          read_len: int, flags: int = 0) -> np.ndarray:

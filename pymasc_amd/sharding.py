@@ -29,6 +29,36 @@ def lpt_assign(costs: Sequence[float], world_size: int) -> List[List[int]]:
     return out
 
 
+def tile_range_assign(nbits: Sequence[int], world_size: int, tile_bits: int = 65536) -> List[List[Tuple[int, int, int]]]:
+    """Equal shares of the genome's TILES, not of its chromosomes (round 4): the tiles of all jobs laid end to end are cut into
+    world_size contiguous stretches; rank r gets [(job, first tile, tile count), ...] -- whole chromosomes in the middle of
+    its stretch, a share of one at either end.  Every sum of the hot path is owned by one tile, so the ranks' partial
+    result blocks ADD UP to the chromosome's (pmx_cc_batch_ranges_dev) and ONE all-reduce(sum) of the per-chromosome rows
+    is the whole exchange -- BASELINE.json's north star.  LPT over whole chromosomes leaves 3.6 % imbalance on hg38 at 8
+    ranks; this leaves less than one tile.  Deterministic on every rank."""
+    ntiles = [max(1, (int(b) + tile_bits - 1) // tile_bits) for b in nbits]
+    total = sum(ntiles)
+    out: List[List[Tuple[int, int, int]]] = [[] for _ in range(world_size)]
+    start = 0                                     # first global tile of the current job
+    for j, nt in enumerate(ntiles):
+        for r in range(world_size):
+            lo, hi = total * r // world_size, total * (r + 1) // world_size      # rank r's stretch of the global sequence
+            a, b = max(lo, start), min(hi, start + nt)
+            if b > a:
+                out[r].append((j, a - start, b - a))
+        start += nt
+    return out
+
+
+def exchange_partial_rows(partial: torch.Tensor, group=None, force_collectives: bool = False) -> torch.Tensor:
+    """partial: int64 [njobs, nrows, stride] -- this rank's SHARE of every chromosome's result block (zeros where it holds
+    nothing).  Returns the complete blocks on every rank: one all-reduce(sum) over RCCL / xGMI."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1 or (force_collectives and dist.is_initialized()):
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+    return partial
+
+
 def owner_table(assignment: List[List[int]], njobs: int) -> List[Tuple[int, int]]:
     """job -> (rank, slot on that rank)."""
     table = [(-1, -1)] * njobs

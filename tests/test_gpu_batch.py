@@ -185,3 +185,47 @@ def test_a_call_without_a_hint_takes_one_from_a_sample_of_the_vectors(ctx, densi
     for (nbits, F, R, M), out, f in zip(cases, outs, forced):
         check_block(out, oracle.calc_correlation(F, R, M, nbits, S, L), S, True)
         assert np.array_equal(out[:ffi.PMX_ROW_SCALARS], f[:ffi.PMX_ROW_SCALARS])
+
+
+@pytest.mark.parametrize("with_m,skip_ncc", [(True, False), (False, False), (True, True)])
+def test_tile_ranges_of_a_chromosome_add_up_to_it(ctx, with_m, skip_ncc):
+    """pmx_cc_batch_ranges_dev: every sum of the hot path is owned by one 64-Kbit tile, so the result blocks of jobs that cover
+    a chromosome between them add up to the block pmx_cc_batch_dev writes for it -- rows, popcounts, mappable lengths,
+    path marker (what ranks of a multi-GPU run all-reduce).  Cuts anywhere (tile 1, the last tile, one-tile ranges), a
+    read-dense and an edge-dense stretch inside ranges (those tiles go to the window kernels), a one-tile chromosome."""
+    S, L = 300, 36
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(61)
+    cases = []
+    for i, n in enumerate([400000, 65536 * 3 - 436, 30000]):
+        nbits, F, R, M = synth.make_case(950 + i, n, S, L, 0.006, 0.006, True, mean_on=1500, mean_off=400)
+        if i == 0:
+            F |= synth.random_bits(rng, nbits, 0.08, 140000, 200000)           # read-dense tiles
+            R |= synth.random_bits(rng, nbits, 0.08, 138000, 198000)
+            keep = synth.run_bits(np.random.default_rng(1), nbits, 10**9, 1, 0, 300000)
+            M = (M & keep) | synth.run_bits(rng, nbits, 6, 4, 300000, 340000)   # very short runs: edge-dense tiles
+        cases.append((nbits, F, R, M))
+    flags = ffi.PMX_FLAG_SKIP_NCC if skip_ncc else 0
+    full = run_batch(ctx, cases, S, L, with_m, flags | ffi.PMX_FLAG_EVENTS_HINT)
+    cuts = {0: [0, 1, 2, 5, 7], 1: [0, 2, 3], 2: [0, 1]}      # tile boundaries of the ranges per chromosome
+    keep, aF, aR, aM, aN, aO, first, count, outs, owner = [], [], [], [], [], [], [], [], [], []
+    for j, (nbits, F, R, M) in enumerate(cases):
+        ntiles = (nbits + ffi.RANGE_TILE_BITS - 1) // ffi.RANGE_TILE_BITS
+        assert cuts[j][-1] == ntiles, (j, ntiles)
+        t = [torch.from_numpy(x.view(np.int64)).to(dev) for x in (F, R, M)]
+        keep += t
+        for a, b in zip(cuts[j][:-1], cuts[j][1:]):
+            o = torch.full((ffi.PMX_NROWS, S + 1), -1, dtype=torch.int64, device=dev)
+            aF.append(t[0].data_ptr()); aR.append(t[1].data_ptr()); aM.append(t[2].data_ptr()); aN.append(nbits)
+            aO.append(o.data_ptr()); first.append(a); count.append(b - a); outs.append(o); owner.append(j)
+    torch.cuda.synchronize()
+    ctx.cc_batch_ranges_dev(aF, aR, aM if with_m else None, aN, first, count, S, L, flags, aO)
+    ctx.sync()
+    for j, (nbits, F, R, M) in enumerate(cases):
+        total = sum(o.cpu().numpy().view(np.uint64) for o, w in zip(outs, owner) if w == j)
+        assert np.array_equal(total, full[j]), j
+        check_block(total, oracle.calc_correlation(F, R, M if with_m else None, nbits, S, L, skip_ncc=skip_ncc), S, with_m, skip_ncc)
+    with pytest.raises(ffi.PmxError):          # a range beyond the chromosome's tiles
+        ctx.cc_batch_ranges_dev(aF[:1], aR[:1], aM[:1] if with_m else None, aN[:1], [6], [3], S, L, flags, aO[:1])
+    with pytest.raises(ffi.PmxError):          # beyond 1023 shifts the pair pass over M is not range-aware
+        ctx.cc_batch_ranges_dev(aF[:1], aR[:1], aM[:1] if with_m else None, aN[:1], [0], [1], 2000, L, flags, aO[:1])

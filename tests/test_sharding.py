@@ -305,3 +305,98 @@ def test_failure_on_one_rank_raises_on_all(tmp_path):
         assert p.exitcode == 0
     assert got[1].startswith("PmxError") and "injected kernel failure" in got[1]
     assert got[0].startswith("RuntimeError") and "rank(s): 1" in got[0] and "injected kernel failure" in got[0]
+
+
+# ---- tile-range sharding (round 4): equal shares of the genome's tiles, ONE all-reduce(sum) of per-chromosome rows --------
+TILE = 512            # (a small tile for the CPU rehearsal: the assignment and the exchange do not depend on its size)
+RLENGTHS = [9700, 4000, 7000, 300, 6500]
+
+
+def _range_case(job):
+    from tests import synth
+    return synth.make_case(2000 + job, RLENGTHS[job], S, L, 0.03, 0.03, True, mean_on=60, mean_off=20)
+
+
+def _share_of(job, first, count):
+    """The share of a chromosome's result block that belongs to the tiles [first, first + count): every pair / event is owned
+    by one tile -- the forward read's for ncc, mscc.fsum and mscc.ccbins, the reverse read's for mscc.rsum -- so masking the
+    DRIVER vector to the range gives the share (what pmx_cc_batch_ranges_dev computes on the GPU; mappable_len and the path
+    marker, which no mask expresses, are put with the share that holds tile 0: any split adds up)."""
+    from oracle import model as oracle
+    nbits, F, R, M = _range_case(job)
+    lo, hi = first * TILE, min((first + count) * TILE, nbits)
+    mask = np.zeros_like(F)
+    for b in range(lo, hi):                     # (small vectors)
+        mask[b >> 6] |= np.uint64(1) << np.uint64(b & 63)
+    a = oracle.calc_correlation(F & mask, R, M, nbits, S, L)
+    b = oracle.calc_correlation(F, R & mask, M, nbits, S, L)
+    out = np.zeros((NROWS, S + 1), dtype=np.int64)
+    out[0], out[1], out[3] = a["ncc_ccbins"], a["mscc_forward_sum"], a["mscc_ccbins"]
+    out[2] = b["mscc_reverse_sum"]
+    out[5, 0], out[5, 1] = a["ncc_forward_sum"], b["ncc_reverse_sum"]
+    if first == 0:
+        out[4] = a["mappable_len_by_shift"]
+        out[5, 3] = 2
+    return out
+
+
+def _full_rows(job):
+    from oracle import model as oracle
+    nbits, F, R, M = _range_case(job)
+    ref = oracle.calc_correlation(F, R, M, nbits, S, L)
+    out = np.zeros((NROWS, S + 1), dtype=np.int64)
+    out[0], out[1], out[2], out[3], out[4] = (ref["ncc_ccbins"], ref["mscc_forward_sum"], ref["mscc_reverse_sum"], ref["mscc_ccbins"],
+                                              ref["mappable_len_by_shift"])
+    out[5, 0], out[5, 1], out[5, 3] = ref["ncc_forward_sum"], ref["ncc_reverse_sum"], 2
+    return out
+
+
+def _range_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nbits = [_range_case(j)[0] for j in range(len(RLENGTHS))]
+        mine = sharding.tile_range_assign(nbits, world, TILE)[rank]
+        partial = torch.zeros((len(RLENGTHS), NROWS, S + 1), dtype=torch.int64)
+        for job, first, count in mine:
+            partial[job] += torch.from_numpy(_share_of(job, first, count))
+        q.put((rank, mine, sharding.exchange_partial_rows(partial).numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tile_range_assignment_is_an_exact_cover_with_equal_shares():
+    nbits = [248956422, 242193529, 50818468, 16569, 70000, 65536, 1]
+    ntiles = [max(1, (b + 65535) // 65536) for b in nbits]
+    for world in (1, 2, 3, 8, 64):
+        a = sharding.tile_range_assign(nbits, world)
+        seen = [np.zeros(n, dtype=np.int64) for n in ntiles]
+        for r in a:
+            for job, first, count in r:
+                assert count >= 1
+                seen[job][first:first + count] += 1
+        assert all((s == 1).all() for s in seen)                    # every tile of every chromosome exactly once
+        shares = [sum(c for _, _, c in r) for r in a]
+        assert max(shares) - min(shares) <= 1                       # within one tile of each other
+        for r in a:                                                  # a rank's stretch is contiguous: at most two partial chromosomes
+            assert sum(1 for job, first, count in r if count != ntiles[job]) <= 2
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_tile_ranges_all_reduce_to_the_whole_rows():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_range_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    expect = np.stack([_full_rows(j) for j in range(len(RLENGTHS))])
+    assert any(count != max(1, (_range_case(job)[0] + TILE - 1) // TILE) for _r, mine, _x in got for job, _f, count in mine)   # a chromosome IS split
+    for _rank, _mine, rows in got:
+        np.testing.assert_array_equal(rows, expect)

@@ -88,12 +88,23 @@ def fuzz_feed(ctx, rng, clen, S, L):
     pdt = [np.int32, np.int64][int(rng.integers(0, 2))]
     ldt = [np.uint16, np.int32, np.int64][int(rng.integers(0, 3))]
     packed = rng.random() < 0.3
+    delta16 = rng.random() < 0.35 and nbits < 2**31          # round 4: the two-bytes-per-read form
+    whole = rng.random() < 0.5                               # round 4: the first run writes every word of uncleared vectors
+    if whole:
+        junk = np.full(ffi.nwords(nbits), 0x5a5a5a5aa5a5a5a5, dtype=np.uint64)
+        ctx.bits_upload(d_F, junk, nbits)
+        ctx.bits_upload(d_R, ~junk, nbits)
     keep, fed = [], 0
     for a, b in zip([0] + cuts, cuts + [n]):
         if b > a:
             pp = pos[a:b].astype(pdt)
-            keep.append(ctx.feed_reads(d_F, d_R, nbits, ffi.pack_strand(pp, rev[a:b]) if packed else pp, rlen[a:b].astype(ldt),
-                                       None if packed else rev[a:b], fed, d_st))
+            w = whole and fed == 0
+            if delta16:
+                keep.append(ctx.feed_reads_delta16(d_F, d_R, nbits, ffi.pack_delta16(pos[a:b], rev[a:b]), rlen[a:b].astype(ldt), fed, d_st,
+                                                   whole_vectors=w))
+            else:
+                keep.append(ctx.feed_reads(d_F, d_R, nbits, ffi.pack_strand(pp, rev[a:b]) if packed else pp, rlen[a:b].astype(ldt),
+                                           None if packed else rev[a:b], fed, d_st, whole_vectors=w))
             fed += b - a
     F, R = ctx.bits_download(d_F, nbits), ctx.bits_download(d_R, nbits)
     st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
@@ -103,7 +114,7 @@ def fuzz_feed(ctx, rng, clen, S, L):
           and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == oc._r_rls and int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0
           and int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 0)
     if not ok:
-        print("MISMATCH feed_reads", n, glen, S, L, cuts, pdt, ldt, packed, flush=True)
+        print("MISMATCH feed_reads", n, glen, S, L, cuts, pdt, ldt, packed, delta16, whole, flush=True)
     return 0 if ok else 1
 
 
@@ -134,7 +145,7 @@ def main():
                                              full_range=full)
             skip_ncc = with_m and rng.random() < 0.2
             ref = oracle.calc_correlation(F, R, M, nbits, S, L, skip_ncc=skip_ncc)
-            for flags in (0, ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE, ffi.PMX_FLAG_DEEP_LISTS):
+            for flags in (0, ffi.PMX_FLAG_FORCE_DENSE, ffi.PMX_FLAG_FORCE_SPARSE, ffi.PMX_FLAG_DEEP_LISTS, ffi.PMX_FLAG_EVENTS_HINT):
                 if flags == ffi.PMX_FLAG_FORCE_DENSE and (S + 1) * nbits > 3e8:
                     continue
                 if flags == ffi.PMX_FLAG_FORCE_SPARSE and L > 1024:
