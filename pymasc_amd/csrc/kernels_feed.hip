@@ -37,6 +37,112 @@ __device__ __forceinline__ bool feed_rev(const T *p, const unsigned char *rev, u
 template <typename T>
 __device__ __forceinline__ int64_t feed_len(const T *p, int64_t uniform, uint64_t i) { return p ? (int64_t)p[i] : uniform; }
 
+
+// ---- the two look-backs of the duplicate rules, bounded (round 4) ----
+// "Was this reverse read's bit set by an earlier read of the run" (mscc.pyx:416-418) walks back over the reads whose position
+// allows the same bit; "is there an earlier forward read at this position" (mscc.pyx:388-392) over the run of equal
+// positions.  Ordinarily that is a step or two.  In a pile-up -- 10^5 reads inside one read length: chrM, rDNA, satellites --
+// it was a chain of K dependent loads per read by ONE lane, K^2 in all (round-3 advisor finding).  Now a lane walks
+// FEED_OWN_STEPS steps itself; the lanes that are still undecided are then served one after the other by the whole
+// wavefront, 64 earlier reads per step (coalesced loads, one ballot): K^2 / 64 wave-steps.  Exact in both phases.
+// ALL 64 lanes of a wavefront call these together (`active`: the lane has a read to decide).
+#define FEED_OWN_STEPS 16
+__device__ __forceinline__ uint64_t feed_lane64(uint64_t v, int src)
+{
+    return ((uint64_t)(u32)__shfl((int)(v >> 32), src, 64) << 32) | (u32)__shfl((int)(u32)v, src, 64);
+}
+
+// reverse read i with bit `bit`: true iff an earlier read j < i of the run is a reverse read with the same bit
+template <typename PT, typename LT>
+__device__ __forceinline__ bool feed_reverse_seen(const PT *__restrict__ pos, const LT *__restrict__ rlen, int64_t ulen,
+                                                  const unsigned char *__restrict__ rev, bool packed, uint64_t i, int64_t bit,
+                                                  int64_t maxlen, bool active, u32 lane)
+{
+    const int64_t lowest = bit - maxlen + 1;
+    bool set = false, done = !active;
+    uint64_t j = i;
+    for (int step = 0; step < FEED_OWN_STEPS && !done; step++) {
+        if (j == 0) {
+            done = true;
+            break;
+        }
+        const int64_t pj = feed_ld(pos, j - 1, packed);
+        if (pj < lowest) {
+            done = true;
+            break;
+        }
+        set = feed_rev(pos, rev, j - 1) && pj + feed_len(rlen, ulen, j - 1) - 1 == bit;
+        done = set;
+        j--;
+    }
+    uint64_t pending = __ballot(!done);
+    while (pending) {
+        const int src = (int)__builtin_ctzll(pending);
+        pending &= pending - 1;
+        uint64_t base = feed_lane64(j, src);                         // the reads base - 1, base - 2, ... are still to be looked at
+        const int64_t b = (int64_t)feed_lane64((uint64_t)bit, src), low = (int64_t)feed_lane64((uint64_t)lowest, src);
+        bool found = false;
+        for (;;) {
+            bool hit = false, below = false;
+            if (base > lane) {
+                const uint64_t k = base - 1 - lane;
+                const int64_t pk = feed_ld(pos, k, packed);
+                below = pk < low;
+                hit = !below && feed_rev(pos, rev, k) && pk + feed_len(rlen, ulen, k) - 1 == b;
+            }
+            const uint64_t hits = __ballot(hit), bel = __ballot(below);
+            // (sorted run: the reads below the window are the higher lanes from some lane on; a hit counts in front of them only)
+            const uint64_t in_front = bel ? ((1ull << __builtin_ctzll(bel)) - 1ull) : ~0ull;
+            found = (hits & in_front) != 0;
+            if (found || bel || base <= 64) break;
+            base -= 64;
+        }
+        if ((int)lane == src) set = found;
+    }
+    return set;
+}
+
+// forward read i at position p: true iff an earlier read of the run at the same position is a forward read
+template <typename PT>
+__device__ __forceinline__ bool feed_forward_seen(const PT *__restrict__ pos, const unsigned char *__restrict__ rev, bool packed,
+                                                  uint64_t i, int64_t p, bool active, u32 lane)
+{
+    bool dup = false, done = !active;
+    uint64_t j = i;
+    for (int step = 0; step < FEED_OWN_STEPS && !done; step++) {
+        if (j == 0 || feed_ld(pos, j - 1, packed) != p) {
+            done = true;
+            break;
+        }
+        dup = !feed_rev(pos, rev, j - 1);
+        done = dup;
+        j--;
+    }
+    uint64_t pending = __ballot(!done);
+    while (pending) {
+        const int src = (int)__builtin_ctzll(pending);
+        pending &= pending - 1;
+        uint64_t base = feed_lane64(j, src);
+        const int64_t q = (int64_t)feed_lane64((uint64_t)p, src);
+        bool found = false;
+        for (;;) {
+            bool hit = false, other = false;
+            if (base > lane) {
+                const uint64_t k = base - 1 - lane;
+                other = feed_ld(pos, k, packed) != q;              // the run of equal positions has ended
+                hit = !other && !feed_rev(pos, rev, k);
+            }
+            const uint64_t hits = __ballot(hit), oth = __ballot(other);
+            const uint64_t in_front = oth ? ((1ull << __builtin_ctzll(oth)) - 1ull) : ~0ull;
+            found = (hits & in_front) != 0;
+            if (found || oth || base <= 64) break;
+            base -= 64;
+        }
+        if ((int)lane == src) dup = found;
+    }
+    return dup;
+}
+
 template <typename LT>
 __global__ void __launch_bounds__(256) k_feed_maxlen(const LT *__restrict__ rlen, int64_t ulen, const unsigned char *__restrict__ rev,
                                                      uint64_t n, u64 *__restrict__ state)
@@ -78,43 +184,43 @@ __global__ void __launch_bounds__(256) k_feed_reads(const PT *__restrict__ pos, 
     const bool packed = rev == nullptr;
     u64 fsum = 0, rsum = 0, nf = 0, nr = 0, maxf = 0, e_sort = 0, e_range = 0;
     bool any_f = false;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t p = feed_ld(pos, i, packed), l = feed_len(rlen, ulen, i);
-        const bool rv = feed_rev(pos, rev, i);
-        const int64_t before = i ? feed_ld(pos, i - 1, packed) : prev_last;
-        if (p < before) {                                                               // mscc.pyx:362-363
-            const u64 code = FEED_ERR_BASE - (base + i);
-            e_sort = code > e_sort ? code : e_sort;
+    const u32 lane = threadIdx.x & 63u;
+    // (wave-uniform trips: the look-backs are wavefront-wide, see feed_reverse_seen)
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = i0 + lane;
+        const bool valid = i < n;
+        const int64_t p = valid ? feed_ld(pos, i, packed) : 0, l = valid ? feed_len(rlen, ulen, i) : 0;
+        const bool rv = valid && feed_rev(pos, rev, i);
+        if (valid) {
+            const int64_t before = i ? feed_ld(pos, i - 1, packed) : prev_last;
+            if (p < before) {                                                           // mscc.pyx:362-363
+                const u64 code = FEED_ERR_BASE - (base + i);
+                e_sort = code > e_sort ? code : e_sort;
+            }
         }
         const int64_t bit = rv ? p + l - 1 : p;
-        if (bit < 0 || (uint64_t)bit >= nbits) {
+        const bool in_range = valid && bit >= 0 && (uint64_t)bit < nbits;
+        if (valid && !in_range) {
             const u64 code = FEED_ERR_BASE - (base + i);
             e_range = code > e_range ? code : e_range;
-            continue;
         }
-        if (!rv) {
-            // duplicate: an earlier forward read at this position (sorted input: such reads are the ones right before it)
-            bool dup = p == prev_fwd;
-            for (uint64_t j = i; !dup && j > 0 && feed_ld(pos, j - 1, packed) == p; j--) dup = !feed_rev(pos, rev, j - 1);
+        const bool is_f = in_range && !rv, is_r = in_range && rv;
+        // duplicate: an earlier forward read at this position (sorted input: such reads are the ones right before it)
+        const bool fdup = feed_forward_seen(pos, rev, packed, i, p, is_f && p != prev_fwd, lane) || (is_f && p == prev_fwd);
+        // counts iff its bit is clear: set by an earlier chunk (the vector) or by an earlier read of this chunk
+        const bool r_old = is_r && ((R[bit >> 6] >> (bit & 63)) & 1ull);
+        const bool rdup = feed_reverse_seen(pos, rlen, ulen, rev, packed, i, bit, maxlen, is_r && !r_old, lane) || r_old;
+        if (is_f) {
             any_f = true;
             if ((u64)p > maxf) maxf = (u64)p;
-            if (!dup) {
+            if (!fdup) {
                 fsum += (u64)l;
                 nf++;
                 atomicOr(&F[bit >> 6], 1ull << (bit & 63));
             }
-        } else {
-            bool set = (R[bit >> 6] >> (bit & 63)) & 1ull;                              // by an earlier chunk
-            const int64_t lowest = bit - maxlen + 1;                                    // by an earlier read of this chunk
-            for (uint64_t j = i; !set && j > 0; j--) {
-                const int64_t pj = feed_ld(pos, j - 1, packed);
-                if (pj < lowest) break;
-                set = feed_rev(pos, rev, j - 1) && pj + feed_len(rlen, ulen, j - 1) - 1 == bit;
-            }
-            if (!set) {
-                rsum += (u64)l;
-                nr++;
-            }
+        } else if (is_r && !rdup) {
+            rsum += (u64)l;
+            nr++;
         }
     }
     // wave sums / maxima, one atomic per wave and word
@@ -308,33 +414,28 @@ __global__ void __launch_bounds__(256) k_feed_build(const PT *__restrict__ pos, 
     const uint64_t i_lo = s_idx[0], i_hi = s_idx[1];
     u64 fsum = 0, rsum = 0, nf = 0, nr = 0, maxf = 0, e_sort = 0, e_range = 0;
     bool any_f = false;
-    for (uint64_t i = i_lo + tid; i < i_hi; i += 256) {
-        const int64_t p = feed_ld(pos, i, packed), l = feed_len(rlen, ulen, i);
-        const bool rv = feed_rev(pos, rev, i);
+    for (uint64_t i0 = i_lo + (tid & ~63u); i0 < i_hi; i0 += 256) {   // (wave-uniform trips: the look-backs are wavefront-wide)
+        const uint64_t i = i0 + lane;
+        const bool valid = i < i_hi;
+        const int64_t p = valid ? feed_ld(pos, i, packed) : 0, l = valid ? feed_len(rlen, ulen, i) : 0;
+        const bool rv = valid && feed_rev(pos, rev, i);
         const int64_t bit = rv ? p + l - 1 : p;
-        if (bit < lo || bit >= hi || (uint64_t)bit >= nbits) continue;   // another workgroup's read (or out of range: dropped)
+        const bool mine = valid && bit >= lo && bit < hi && (uint64_t)bit < nbits;   // (else another workgroup's read, or out of range: dropped)
+        const bool is_f = mine && !rv, is_r = mine && rv;
+        // duplicate: an earlier forward read at this position (mscc.pyx:388-392; k_feed_reads)
+        const bool fdup = feed_forward_seen(pos, rev, packed, i, p, is_f && p != prev_fwd, lane) || (is_f && p == prev_fwd);
+        // counts iff its bit is clear: nothing was set before this run (the first of the chromosome), so only an earlier
+        // read of the run can have set it (mscc.pyx:416-418)
+        const bool rdup = feed_reverse_seen(pos, rlen, ulen, rev, packed, i, bit, maxlen, is_r, lane);
         const u64 mask = 1ull << (bit & 63);
-        const u32 w = (u32)(((uint64_t)bit >> 6) - w0);
-        if (!rv) {
-            // duplicate: an earlier forward read at this position (mscc.pyx:388-392; k_feed_reads)
-            bool dup = p == prev_fwd;
-            for (uint64_t j = i; !dup && j > 0 && feed_ld(pos, j - 1, packed) == p; j--) dup = !feed_rev(pos, rev, j - 1);
-            if (!dup) {
-                fsum += (u64)l;
-                nf++;
-                atomicOr(&sF[w], mask);
-            }
-        } else {
-            // counts iff its bit is clear: nothing was set before this run (the first of the chromosome), so only an earlier
-            // read of the run can have set it (mscc.pyx:416-418; the look-back of k_feed_reads)
-            bool set = false;
-            const int64_t lowest = bit - maxlen + 1;
-            for (uint64_t j = i; !set && j > 0; j--) {
-                const int64_t pj = feed_ld(pos, j - 1, packed);
-                if (pj < lowest) break;
-                set = feed_rev(pos, rev, j - 1) && pj + feed_len(rlen, ulen, j - 1) - 1 == bit;
-            }
-            if (!set) {
+        const u32 w = mine ? (u32)(((uint64_t)bit >> 6) - w0) : 0u;
+        if (is_f && !fdup) {
+            fsum += (u64)l;
+            nf++;
+            atomicOr(&sF[w], mask);
+        }
+        if (is_r) {
+            if (!rdup) {
                 rsum += (u64)l;
                 nr++;
             }

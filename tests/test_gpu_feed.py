@@ -424,3 +424,28 @@ def test_whole_vector_feed_pile_ups_and_errors(ctx):
     F, R, st = device_feed(ctx, pos, rlen, rev, nbits, [], np.int64, np.uint16, whole=True)
     assert ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == pos.size - 2
     assert int(st[ffi.PMX_FEED_FIRST_UNSORTED]) == 0
+
+
+@pytest.mark.parametrize("whole", [False, True])
+def test_a_pile_up_of_a_hundred_thousand_reads_inside_one_read_length(ctx, whole):
+    """chrM / rDNA / satellite style: 1.2 x 10^5 reads within 150 bp, both strands, mixed lengths (soft clips), then ordinary
+    reads.  The look-backs of the duplicate rules walked back read by read on ONE lane (K dependent loads per read, K^2 in
+    all: round-3 advisor finding); the wavefront serves long walks together now.  Exact, and bounded in time."""
+    import time
+    S, L, glen = 100, 36, 300000
+    rng = np.random.default_rng(123)
+    pile = np.sort(rng.integers(5000, 5150, size=120000))
+    rest = np.sort(rng.integers(6000, glen, size=20000))
+    pos = np.concatenate([pile, rest]).astype(np.int64)
+    rlen = rng.choice(np.asarray([30, 36, 36, 50, 75, 101]), size=pos.size).astype(np.int64)
+    rev = rng.random(pos.size) < 0.5
+    rev[:60000] = rng.random(60000) < 0.97            # a long stretch that is nearly all reverse: forward look-backs over it
+    wF, wR, wf, wr, nbits = reference_feed(pos, rlen, rev, S, L, glen)
+    ctx.sync()
+    t0 = time.perf_counter()
+    F, R, st = device_feed(ctx, pos, rlen, rev, nbits, [70000], np.int32, np.uint16, whole=whole)
+    dt = time.perf_counter() - t0
+    np.testing.assert_array_equal(F, wF)
+    np.testing.assert_array_equal(R, wR)
+    assert int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]) == wf and int(st[ffi.PMX_FEED_REVERSE_LEN_SUM]) == wr
+    assert dt < 2.0, f"pile-up feed took {dt:.2f} s"
