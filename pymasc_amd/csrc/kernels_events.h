@@ -74,11 +74,14 @@
 #ifndef EV_PRIO_STAGE
 #define EV_PRIO_STAGE 3
 #endif
+// Round 4 (edge events dealt by wave role): the pair loop and the edge loops at DIFFERENT priorities -- same-box A/B, kernel ms:
+// pairs / edges 1 / 1: 0.412, 1 / 0: 0.399, 1 / 2: 0.401, 2 / 1: 0.397-0.400, 0 / 2: 0.400, 2 / 0: 0.408, 0 / 1: 0.404 (staging 3
+// throughout; staging 2: 0.409): again it is the co-resident workgroups falling out of step that pays, whichever way.
 #ifndef EV_PRIO_EVENTS
-#define EV_PRIO_EVENTS 1
+#define EV_PRIO_EVENTS 2
 #endif
 #ifndef EV_PRIO_EDGES
-#define EV_PRIO_EDGES EV_PRIO_EVENTS
+#define EV_PRIO_EDGES 1
 #endif
 #ifndef EV_EDGE_ROLES
 #define EV_EDGE_ROLES 1
@@ -690,6 +693,8 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         EV_STAMP(4)
         if (EV_PRIO_STAGE) __builtin_amdgcn_s_setprio(0);
         __syncthreads();   // B1: lists, M words and edge ranks visible
+        // (tried on top, same-box A/B: the two waves with two pair blocks one level above the others: 0.400 -> 0.412; the two
+        // priorities exchanged in every other "layer" of 256 / 8 / 1 workgroups: +-0)
         if (EV_PRIO_EVENTS) __builtin_amdgcn_s_setprio(EV_PRIO_EVENTS);
         EV_STAMP(5)
         if (LATE_FETCH) {
