@@ -685,15 +685,15 @@ __device__ __forceinline__ u32 lds_window(const u32 *lds, u32 byte_addr, u32 shi
 #ifndef SP_ROLES
 #define SP_ROLES 0                 // 1: waves 0-1 carry (ncc, mscc.ccbins), waves 2-3 (mscc.fsum, mscc.rsum) -- A/B build
 #endif
-template <bool HAS_M, bool DO_NCC, bool CH, typename JT = SpJobTable>
-__global__ void __launch_bounds__(256, CH ? (HAS_M ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
-k_cc_sparse(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
-            u32 *__restrict__ slab, const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged,
-            const u32 *__restrict__ plan, u32 add_stride = 0)
+// The body of k_cc_sparse as a device function (lds: SpLds<HAS_M>::TOTAL dwords; bx: the workgroup's index in ITS launch
+// plan), so that the launch behind the event pass can carry it next to the autocorrelation window kernel's body in ONE grid
+// (k_windows_flagged, round 4); k_cc_sparse itself is the wrapper below the body.
+template <bool HAS_M, bool DO_NCC, bool CH, typename JT>
+__device__ __forceinline__ void cc_sparse_body(u32 *const lds, const u32 bx, const JT &jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
+                                               int32_t c, u32 lgG, u32 *__restrict__ slab, const unsigned char *__restrict__ tile_flags,
+                                               const u32 *__restrict__ plan, u32 add_stride)
 {
-    if (n_flagged && *n_flagged == 0) return;   // the event kernel took every tile (uniform over the whole grid)
     typedef SpLds<HAS_M> L;
-    __shared__ __align__(16) u32 lds[L::TOTAL];
     u32 *const cursor = lds + L::MISC;   // [0] = F records, [1] = R records of the current tile
     u32 *const acc = lds + L::ACC;
     u32 *const stage = lds + L::STAGE;
@@ -703,8 +703,8 @@ k_cc_sparse(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t
 
     // tile range of this workgroup: equal shares of the tile sequence, or -- behind the event kernel -- the range
     // k_plan_flagged cut for it (equal shares of the FLAGGED tiles, see there)
-    const u32 g0 = plan ? plan[2 * blockIdx.x] : blockIdx.x * tiles_per_wg;
-    const u32 g1 = plan ? plan[2 * blockIdx.x + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
+    const u32 g0 = plan ? plan[2 * bx] : bx * tiles_per_wg;
+    const u32 g1 = plan ? plan[2 * bx + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
     if (g0 >= g1) return;
 
     for (u32 i = tid; i < 40; i += 256) lds[L::ZERO + i] = 0;
@@ -884,7 +884,7 @@ k_cc_sparse(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t
         // 24-plane accumulators could overflow)
         if (leaving || q2 >= SP_L2LIMIT) {
             const u32 j = leaving ? leave_job : ji;
-            u32 *seg = slab + (size_t)(blockIdx.x + j) * SP_SEG_ROWS * 1024;
+            u32 *seg = slab + (size_t)(bx + j) * SP_SEG_ROWS * 1024;
             acc_to_segment(acc, L::NCOUNTERS, HAS_M ? 8u : 0u, seg, seg_written, tid);   // counter 3 (rsum) is bit-reversed
             q2 = 0;
             seg_written = true;
@@ -1100,9 +1100,20 @@ k_cc_sparse(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t
 #ifdef SP_STAMPS
     if ((tid & 63) == 0) {
         unsigned long long *dbg = reinterpret_cast<unsigned long long *>(slab + (size_t)(gridDim.x + njobs) * SP_SEG_ROWS * 1024);
-        for (int i = 0; i < SP_NSTAMP; i++) dbg[((size_t)blockIdx.x * 4 + (tid >> 6)) * SP_NSTAMP + i] = stamp_acc[i];
+        for (int i = 0; i < SP_NSTAMP; i++) dbg[((size_t)bx * 4 + (tid >> 6)) * SP_NSTAMP + i] = stamp_acc[i];
     }
 #endif
+}
+
+template <bool HAS_M, bool DO_NCC, bool CH, typename JT = SpJobTable>
+__global__ void __launch_bounds__(256, CH ? (HAS_M ? SP_WAVES_CH : SP_WAVES_CH_NCC) : (HAS_M ? SP_WAVES : SP_WAVES_NCC))
+k_cc_sparse(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, int32_t c, u32 lgG,
+            u32 *__restrict__ slab, const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged,
+            const u32 *__restrict__ plan, u32 add_stride = 0)
+{
+    if (n_flagged && *n_flagged == 0) return;   // the event kernel took every tile (uniform over the whole grid)
+    __shared__ __align__(16) u32 lds[SpLds<HAS_M>::TOTAL];
+    cc_sparse_body<HAS_M, DO_NCC, CH, JT>(lds, blockIdx.x, jobs, njobs, total_tiles, tiles_per_wg, c, lgG, slab, tile_flags, plan, add_stride);
 }
 
 // dst[job][row][d_off + i] = sum over the workgroups that touched the job of slab[(wg + job)][src_row][i], i < d_n
@@ -1367,15 +1378,13 @@ __device__ __forceinline__ void build_edge_records(u32 *lds, uint4 *recs, u32 fi
 
 __device__ __forceinline__ long long block_exclusive_offset(long long local_sum, long long *part, u32 tid);   // (below)
 
-template <bool CH, typename JT = SpJobTable>
-__global__ void __launch_bounds__(256, CH ? AC_WAVES_CH : AC_WAVES)
-k_autocorr_edges(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab,
-                 const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged, const u32 *__restrict__ plan = nullptr,
-                 u32 add_stride = 0, int32_t add_c = 0, u32 add_shift = 0, u32 add_lag = 0)
+// (body / wrapper: see cc_sparse_body)
+template <bool CH, typename JT>
+__device__ __forceinline__ void autocorr_edges_body(u32 *const lds, const u32 bx, const JT &jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg,
+                                                    u32 lgG, u32 *__restrict__ slab, const unsigned char *__restrict__ tile_flags,
+                                                    const u32 *__restrict__ plan, u32 add_stride, int32_t add_c, u32 add_shift, u32 add_lag)
 {
     typedef AcLds L;
-    if (n_flagged && *n_flagged == 0) return;   // the pair kernel took every tile (uniform over the whole grid)
-    __shared__ __align__(16) u32 lds[L::TOTAL];
     u32 *const cursor = lds + L::MISC;
     u32 *const acc = lds + L::ACC;
     u32 *const stage = lds + L::STAGE;
@@ -1383,8 +1392,8 @@ k_autocorr_edges(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u3
     const u32 tid = threadIdx.x;
     const SlotGeom sg = slot_geom(lgG, tid);
 
-    const u32 g0 = plan ? plan[2 * blockIdx.x] : blockIdx.x * tiles_per_wg;      // (see k_cc_sparse)
-    const u32 g1 = plan ? plan[2 * blockIdx.x + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
+    const u32 g0 = plan ? plan[2 * bx] : bx * tiles_per_wg;      // (see k_cc_sparse)
+    const u32 g1 = plan ? plan[2 * bx + 1] : (g0 + tiles_per_wg < total_tiles ? g0 + tiles_per_wg : total_tiles);
     if (g0 >= g1) return;
 
     for (u32 i = tid; i < 40; i += 256) lds[L::ZERO + i] = 0;
@@ -1497,7 +1506,7 @@ k_autocorr_edges(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u3
         }
         if (leaving || q2 >= SP_L2LIMIT) {
             const u32 j = leaving ? leave_job : ji;
-            u32 *seg = slab + (size_t)(blockIdx.x + j) * AC_SEG_ROWS * 1024;
+            u32 *seg = slab + (size_t)(bx + j) * AC_SEG_ROWS * 1024;
             acc_to_segment(acc, 2, 0u, seg, seg_written, tid);
             q2 = 0;
             seg_written = true;
@@ -1599,6 +1608,54 @@ k_autocorr_edges(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u3
             g = gnext;
         }
     }
+}
+
+template <bool CH, typename JT = SpJobTable>
+__global__ void __launch_bounds__(256, CH ? AC_WAVES_CH : AC_WAVES)
+k_autocorr_edges(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 lgG, u32 *__restrict__ slab,
+                 const unsigned char *__restrict__ tile_flags, const u32 *__restrict__ n_flagged, const u32 *__restrict__ plan = nullptr,
+                 u32 add_stride = 0, int32_t add_c = 0, u32 add_shift = 0, u32 add_lag = 0)
+{
+    if (n_flagged && *n_flagged == 0) return;   // the pair kernel took every tile (uniform over the whole grid)
+    __shared__ __align__(16) u32 lds[AcLds::TOTAL];
+    autocorr_edges_body<CH, JT>(lds, blockIdx.x, jobs, njobs, total_tiles, tiles_per_wg, lgG, slab, tile_flags, plan, add_stride, add_c,
+                                add_shift, add_lag);
+}
+
+// Both window kernels behind the event pass (max_shift <= 1023, mappable-length pairs fused) in ONE launch: workgroups
+// [0, nwg_cc) run the cross-correlation windows over the tiles flagged for them, the others the autocorrelation windows over
+// theirs; each half returns at once when its counter of flagged tiles is zero (the usual case: the launch is then one empty
+// grid instead of two -- a dependent launch costs 3-6 us of stream time even when it does nothing, tools/launch_cost.hip).
+// Registers and LDS are the larger of the two bodies'; the occupancy is k_cc_sparse's (SP_WAVES <= AC_WAVES).
+struct WinCcArgs {
+    u32 total_tiles, tiles_per_wg, lgG;
+    int32_t c;
+    u32 *slab;
+    const unsigned char *tile_flags;
+    const u32 *plan;
+};
+struct WinAcArgs {
+    u32 total_tiles, tiles_per_wg, lgG;
+    u32 add_shift, add_lag;
+    u32 *slab;
+    const unsigned char *tile_flags;
+    const u32 *plan;
+};
+template <bool DO_NCC>
+__global__ void __launch_bounds__(256, SP_WAVES < AC_WAVES ? SP_WAVES : AC_WAVES)
+k_windows_flagged(const SpJobTable jobs_cc, const SpJobTable jobs_ac, u32 njobs, u32 nwg_cc, const WinCcArgs w, const WinAcArgs a,
+                  const u32 *__restrict__ n_flagged, u32 add_stride)
+{
+    const bool cc_half = blockIdx.x < nwg_cc;   // (uniform over the workgroup)
+    if (n_flagged[cc_half ? 0 : 1] == 0) return;
+    constexpr u32 LDS_DWORDS = SpLds<true>::TOTAL > AcLds::TOTAL ? SpLds<true>::TOTAL : AcLds::TOTAL;
+    __shared__ __align__(16) u32 lds[LDS_DWORDS];
+    if (cc_half)
+        cc_sparse_body<true, DO_NCC, false, SpJobTable>(lds, blockIdx.x, jobs_cc, njobs, w.total_tiles, w.tiles_per_wg, w.c, w.lgG, w.slab,
+                                                        w.tile_flags, w.plan, add_stride);
+    else
+        autocorr_edges_body<false, SpJobTable>(lds, blockIdx.x - nwg_cc, jobs_ac, njobs, a.total_tiles, a.tiles_per_wg, a.lgG, a.slab,
+                                               a.tile_flags, a.plan, add_stride, w.c, a.add_shift, a.add_lag);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2800,7 +2857,7 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             if (rc) return rc;
         }
         // Pass 2 (window kernel): every tile, or -- behind the event pass -- only the tiles it flagged (the whole grid returns
-        // at once when there are none).  Behind the event pass it writes a slab of its own and k_events_tail adds its sums.
+        // at once when there are none).  Behind the event pass it adds its sums to the rows k_events_finish has written.
         SpJobTable tabW, tabA;
         std::vector<VJob> va(n);
         for (auto &v : va) v.ranged = false;
@@ -2857,6 +2914,31 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
             PMX_CHECK_LAUNCH("k_events_finish");
             ctx->flags_cc_dirty[(ctx->flags_cc_area & 1u)] = 0;   // (flags_cc_area already points at the other area: the next pass's)
         }
+        if (use_events && fuse_mlen) {
+            // both window kernels for the flagged tiles in ONE launch (k_windows_flagged); each adds its shares to the rows
+            // itself, nothing is launched behind it (k_events_tail until round 3).  Timed as the window kernel.
+            rc = pmx_ensure_slab_ac(ctx, (size_t)(nwgA + n) * AC_SEG_ROWS * 1024);
+            if (rc) return rc;
+            rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, true);
+            if (rc) return rc;
+            WinCcArgs wa;
+            wa.total_tiles = total; wa.tiles_per_wg = tpw; wa.lgG = lgG; wa.c = c;
+            wa.slab = wslab; wa.tile_flags = d_flags; wa.plan = d_plan_cc;
+            WinAcArgs aa;
+            aa.total_tiles = totalA; aa.tiles_per_wg = tpwA; aa.lgG = lg_slot_lanes(fused_lag + 1);
+            aa.add_shift = max_shift; aa.add_lag = fused_lag;
+            aa.slab = ctx->d_slab_ac; aa.tile_flags = d_flags_ac; aa.plan = d_plan_ac;
+            if (do_ncc)
+                hipLaunchKernelGGL(k_windows_flagged<true>, dim3(nwg + nwgA), dim3(256), 0, ctx->stream, tabW, tabA, n, nwg, wa, aa,
+                                   (const u32 *)d_nflagged, out_stride);
+            else
+                hipLaunchKernelGGL(k_windows_flagged<false>, dim3(nwg + nwgA), dim3(256), 0, ctx->stream, tabW, tabA, n, nwg, wa, aa,
+                                   (const u32 *)d_nflagged, out_stride);
+            PMX_CHECK_LAUNCH("k_windows_flagged");
+            rc = pmx_prof_end(ctx, &tl);
+            if (rc) return rc;
+            continue;
+        }
         rc = pmx_prof_begin(ctx, PMX_KERNEL_CC_SPARSE, &tl, use_events);
         if (rc) return rc;
 #define SP_LAUNCH(HM, NC, CK)                                                                                       \
@@ -2882,20 +2964,6 @@ int pmx_launch_cc_sparse_batch(pmx_ctx *ctx, const pmx_job *jobs, uint32_t njobs
                                (u32)SP_SEG_ROWS, rs, (const u32 *)nullptr);
             PMX_CHECK_LAUNCH("k_reduce_segments");
             continue;
-        }
-        if (fuse_mlen) {
-            // the autocorrelation window kernel for the flagged tiles (its own slab), same gate; like k_cc_sparse it adds its
-            // share to the rows itself: nothing is launched behind the window kernels any more (k_events_tail until round 3)
-            rc = pmx_ensure_slab_ac(ctx, (size_t)(nwgA + n) * AC_SEG_ROWS * 1024);
-            if (rc) return rc;
-            rc = pmx_prof_begin(ctx, PMX_KERNEL_AUTOCORR, &tl, true);
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_autocorr_edges<false>, dim3(nwgA), dim3(256), 0, ctx->stream, tabA, n, totalA, tpwA,
-                               lg_slot_lanes(fused_lag + 1), ctx->d_slab_ac, (const unsigned char *)d_flags_ac, (const u32 *)(d_nflagged + 1),
-                               (const u32 *)d_plan_ac, out_stride, c, max_shift, fused_lag);
-            PMX_CHECK_LAUNCH("k_autocorr_edges");
-            rc = pmx_prof_end(ctx, &tl);
-            if (rc) return rc;
         }
     }
     return PMX_OK;
