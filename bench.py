@@ -577,12 +577,40 @@ def main():
             lens = [v.length for v in vecs]
 
             stamps = []
+            trace_acc = {}
+
+            def _timed(obj, nm):
+                f = getattr(obj, nm)
+                if getattr(f, "_timed", False):
+                    return
+
+                def g(*a, **kw):
+                    t = time.perf_counter()
+                    try:
+                        return f(*a, **kw)
+                    finally:
+                        e = trace_acc.setdefault(nm, [0, 0.0])
+                        e[0] += 1
+                        e[1] += time.perf_counter() - t
+                g._timed = True
+                setattr(obj, nm, g)
 
             def calc_step():
                 t0 = time.perf_counter()
                 calc = CCHipCalculator(S, L, names, lens, bwfeeder=TrackFeeder(tracks) if with_m else None, context=ctx)
                 if os.environ.get("BENCH_EARLY_BATCH"):      # (A/B: launch the kernels of every N queued chromosomes during the feed)
                     calc.early_batch = int(os.environ["BENCH_EARLY_BATCH"])
+                if os.environ.get("BENCH_CALC_TRACE"):       # (where a genome's host time goes, per method: stderr)
+                    for nm in ("_run_cc", "_materialize", "_calc_correlation", "_load_mappability", "_to_device", "_fill_result"):
+                        _timed(calc, nm)
+                    _timed(ctx, "bits_download")
+                    _timed(ctx, "cc_batch_dev")
+                    _timed(ctx, "feed_reads_delta16")
+                    _timed(ctx, "bits_set_regions_async")
+                if os.environ.get("BENCH_TRACK"):            # (A/B: "plain" = track cleared and OR-ed into on the context's stream,
+                    mode = os.environ["BENCH_TRACK"]         #  "side" = that on the side stream, "build" = built whole on the context's stream)
+                    calc.track_side_stream = mode in ("side", "both")
+                    calc.track_builder = mode in ("build", "both")
                 tc = time.perf_counter()
                 for v in vecs:
                     calc.feed_reads(v.name, *reads[v.name])
@@ -603,8 +631,8 @@ def main():
                 calc.close()
                 stamps.append((tc - t0, t1 - tc, tf - t1, t2 - tf, time.perf_counter() - t2))
                 return whole
-            calc_step()
-            calc_step()     # (two untimed genomes: staging slots and vector pool have reached their sizes)
+            for _ in range(4):      # (untimed genomes: staging slots and vector pool reach their sizes, and the card -- idle while the
+                calc_step()         #  host packed the reads above -- is back at its clocks: the first timed genomes ran 10-20 % slower)
             fence()
             if os.environ.get("BENCH_CALC_PROFILE"):      # where the host time of the calculator leg goes (stderr)
                 import cProfile
@@ -621,12 +649,18 @@ def main():
             import gc
             gc.collect()
             gc.disable()
+            trace_acc.clear()
+            del stamps[:]
             t1 = time.perf_counter()
             for _ in range(n_e2e):
                 whole = calc_step()
             fence()
             dtc = (time.perf_counter() - t1) / n_e2e
             gc.enable()
+            if trace_acc:
+                ncall = len(stamps)
+                print("[calc trace] ms per genome (inclusive):", {k: (v[0] // ncall, round(1e3 * v[1] / ncall, 3)) for k, v in trace_acc.items()},
+                      file=sys.stderr)
             print("[calc leg] construct / feed (host, paced by the copies) / finishup / get_whole_result / close (ms), every call:",
                   [[round(x * 1e3, 2) for x in st] for st in stamps], file=sys.stderr)
             # rows equal to the resident-vector run (job order = this rank's slot order at one rank)

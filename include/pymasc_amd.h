@@ -151,6 +151,8 @@ int pmx_host_free(pmx_ctx *ctx, void *h);
 #define PMX_FEED_READS               8   /* reads fed since the clear                                                  */
 #define PMX_FEED_MAX_REVERSE_LEN     9   /* longest reverse read seen (look-back bound of the reverse rule)            */
 #define PMX_FEED_CHUNK_FORWARD_POS  10   /* internal: 1 + last forward position of the call in progress                */
+#define PMX_FEED_REGIONS_UNSORTED   11   /* 0, or PMX_FEED_ERR_BASE - index of the first interval that breaks the order
+                                           * PMX_REGIONS_SORTED promises (pmx_bits_set_regions_ex)                        */
 #define PMX_FEED_WORDS              16
 #define PMX_FEED_ERR_BASE (1ull << 62)
 /* feed_forward_read / feed_reverse_read (mscc.pyx:370-418) for a run of n reads of one chromosome in FILE ORDER:
@@ -189,6 +191,24 @@ int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t 
  * clipped and recorded in d_state[PMX_FEED_FIRST_OUT_OF_RANGE] (d_state may be NULL).  Asynchronous. */
 int pmx_bits_set_regions_async(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
                                uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state);
+/* The same with flags (round 4).  PMX_REGIONS_CLEAR: the vector is cleared first, in the same stream order (n may be 0).
+ * PMX_REGIONS_SIDE: clear, copy and kernel run on a SIDE stream of the context, behind everything queued on the context's
+ * stream at the time of the call and beside what is queued after it: a chromosome's mappability vector is built while the
+ * next chromosome's reads are fed (the feeders pmx_feed_reads* never wait for the side stream; a genome's feed was paced by
+ * one queue of small kernels, 25 x (feed + regions)).  Until the next call of any OTHER entry point on this context --
+ * pmx_cc_batch_dev, pmx_bits_count, pmx_ctx_sync, ... all of which first make the context's stream wait for the side stream
+ * -- only the feeders may be called, and not on d_words. */
+#define PMX_REGIONS_CLEAR 1u
+#define PMX_REGIONS_SIDE 2u
+/* PMX_REGIONS_SORTED: the intervals are in BigWig order -- h_first[i] + first_offset <= h_last[i] < h_first[i + 1] +
+ * first_offset -- and the call BUILDS the vector: every word is written once by the workgroup that owns it, zeros included
+ * (no clear, no atomics; whatever the vector held is gone, PMX_REGIONS_CLEAR is implied; n may be 0).  The order is checked
+ * on the device: a violation is recorded in d_state[PMX_FEED_REGIONS_UNSORTED] (d_state must not be NULL) and leaves the
+ * vector undefined -- a caller that cannot vouch for the order checks it first (two comparisons per interval) and uses
+ * the plain call otherwise, as pymasc_amd/calculator.py does. */
+#define PMX_REGIONS_SORTED 4u
+int pmx_bits_set_regions_ex(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
+                            uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state, uint32_t flags);
 /* (The three feeders above and below stage their host arrays in one device slot, each array padded to 16 bytes.  Arrays
  * that lie in host memory in that same layout -- back to back in argument order, each padded to 16 bytes, ideally in
  * page-locked memory from pmx_host_alloc -- are copied in ONE piece; anything else array by array.) */

@@ -159,6 +159,10 @@ class CCHipCalculator:
         # feeders' kernels and copies keep the stream busy while a genome arrives, and an early pass only moves time from
         # the fetch into the feed (hg38: feed 3.7 -> 4.15 ms, fetch 1.75 -> 1.2 ms).  For callers whose reads arrive slowly.
         self.early_batch = 0
+        # how a chromosome's mappability vector is made (A/B knobs; same bits either way): on the context's side stream, beside
+        # the next chromosome's reads; built whole from intervals in BigWig order instead of cleared and OR-ed into
+        self.track_side_stream = True
+        self.track_builder = True
         self._resident_bytes = 0
         # result arena: one slot per reference = a result block + a feed state, filled by the queued kernels and read
         # back in ONE copy when results are asked for
@@ -365,7 +369,7 @@ class CCHipCalculator:
         self._last_pos = max(self._last_pos, last)
 
     # ---- per-chromosome calculation ---------------------------------------------------------------
-    def _load_mappability(self, chrom: str, nbits: int):
+    def _load_mappability(self, chrom: str, nbits: int, slot: int):
         """mscc.pyx:327-349 -> (device vector, pool capacity), queued, not waited for; None without a feeder; KeyError if
         the track is missing."""
         if not self._bwfeeder:
@@ -378,10 +382,19 @@ class CCHipCalculator:
             arr = np.asarray(iv, dtype=np.int64).reshape(-1, 2)
             first, last = arr[:, 0].copy(), arr[:, 1].copy()
         self._logging_info("Loading {} mappability to bit array...".format(chrom))
-        vec = self._vector(nbits)
-        if first.size:
-            # set(begin + 1, end), mscc.pyx:343-344 (the + 1 is applied on the device; an end beyond the vector is clipped)
-            self._inflight.append(self._ctx.bits_set_regions_async(vec[0], nbits, first, last, 1, None))
+        vec = self._vector(nbits, clear=False)
+        # set(begin + 1, end), mscc.pyx:343-344 (the + 1 is applied on the device; an end beyond the vector is clipped).  The
+        # vector is cleared and filled on the context's side stream: this chromosome's track is built while the next one's
+        # reads are fed (one queue of small kernels paced the feed of a genome); the batched pass waits for it.
+        # BigWig intervals come sorted and disjoint (begin_i < end_i <= begin_(i+1)): the vector is then BUILT, every word
+        # written once by the workgroup that owns it, instead of cleared and OR-ed into (include/pymasc_amd.h:
+        # PMX_REGIONS_SORTED).  Checked here -- two comparisons per interval, a few microseconds per chromosome --, because
+        # the reference takes intervals in any order (set(begin + 1, end) per interval, mscc.pyx:343-344): anything else goes
+        # the general way.  (The device checks again and records a violation in the chromosome's feed state.)
+        first, last = np.asarray(first), np.asarray(last)
+        in_order = self.track_builder and bool((first < last).all()) and (first.size < 2 or bool((first[1:] >= last[:-1]).all()))
+        self._inflight.append(self._ctx.bits_set_regions_async(vec[0], nbits, first, last, 1, self._state_ptr(slot), clear=True,
+                                                               side=self.track_side_stream, sorted_disjoint=in_order))
         self._n_runs = int(first.size)   # two run edges per interval: the other density the event kernel's lists depend on
         return vec
 
@@ -396,7 +409,7 @@ class CCHipCalculator:
         slot = self._cur_slot
 
         try:
-            m_vec = self._load_mappability(chrom, nbits)
+            m_vec = self._load_mappability(chrom, nbits, slot)
         except KeyError as e:
             self._logging_info("Mappability for '{}' not found. "
                                "Skip calc mappability sensitive CC.".format(e.args[0] if e.args else chrom))
@@ -455,14 +468,16 @@ class CCHipCalculator:
         if known is not None and len(known) > S:      # cached table long enough: no track load, no kernel
             result.mappable_len = tuple(int(x) for x in known[:S + 1])
             return
+        slot = self._new_slot()
         try:
-            m_vec = self._load_mappability(chrom, nbits)
+            m_vec = self._load_mappability(chrom, nbits, slot)
             if m_vec is None:
                 raise KeyError(chrom)
         except KeyError:
+            self._free_slots.append(slot)       # (nothing was queued: the slot is as clean as it came)
             return
         self._logging_info("Calc {} mappable length...".format(chrom))
-        self._readless.append((chrom, self._new_slot(), m_vec))
+        self._readless.append((chrom, slot, m_vec))
 
     def _run_cc(self):
         """_calc_correlation's loop (mscc.pyx:288-317) for every chromosome queued since the last fetch: one batched pass per
@@ -525,34 +540,42 @@ class CCHipCalculator:
             p.vecs = ()
         raw = raw.reshape(-1, self._slot_words)
         nrow = ffi.PMX_NROWS * (KS + 1)
+        # (all values lie far below 2^63: the same words seen as int64, no copy; the feed states as Python ints in one go)
+        raw_i64 = raw.view(np.int64)
+        states = raw[:, nrow:nrow + ffi.PMX_FEED_WORDS].tolist()
         c = L - 1
         error: Optional[BaseException] = None
         new_ncc: List[NCCResult] = []
         new_mscc: List[MSCCResult] = []
-        ncc_rows: List[np.ndarray] = []
-        mscc_rows: List[Tuple[np.ndarray, ...]] = []
+        ncc_slots: List[int] = []
+        mscc_slots: List[int] = []
+        known_rows: List[Tuple[int, np.ndarray]] = []      # (index into new_mscc, cached mappable length by shift)
         for p in pending:
             out = raw[p.slot, :nrow].reshape(ffi.PMX_NROWS, KS + 1)
-            st = raw[p.slot, nrow:]
+            st = states[p.slot]
+            if st[ffi.PMX_FEED_REGIONS_UNSORTED] and error is None:      # (cannot happen: _load_mappability checks the order)
+                error = RuntimeError("mappability interval {} of {} is out of order".format(
+                    ffi.PMX_FEED_ERR_BASE - st[ffi.PMX_FEED_REGIONS_UNSORTED], p.chrom))
             if p.kind == "mlen":
                 self._mscc[p.chrom].mappable_len = tuple(out.reshape(-1)[:S + 1].tolist())
                 continue
             # what the device found in the chunks fed in bulk: raised once everything fetched has been stored
-            if int(st[ffi.PMX_FEED_FIRST_UNSORTED]) and error is None:
+            if st[ffi.PMX_FEED_FIRST_UNSORTED] and error is None:
                 error = ReadUnsortedError("read {} of {} is below its predecessor".format(
-                    ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_UNSORTED]), p.chrom))
-            if int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) and error is None:
+                    ffi.PMX_FEED_ERR_BASE - st[ffi.PMX_FEED_FIRST_UNSORTED], p.chrom))
+            if st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE] and error is None:
                 error = IndexError("read {} of {} beyond its bit array ({} bits)".format(
-                    ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]), p.chrom, p.glen + self._array_extend_size))
+                    ffi.PMX_FEED_ERR_BASE - st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE], p.chrom, p.glen + self._array_extend_size))
             # the per-shift rows go into the result objects as int64 ARRAYS (the reference's models take lists or arrays,
             # PyMaSC/result.py:34,77,95-101, and its own placeholders hold arrays, :207-208): one copy of the block per
             # chromosome instead of a Python int per shift -- 0.6 ms per hg38 genome at 1000 shifts, 80 ms for config 5
-            i64 = out.astype(np.int64)
-            f_rls, r_rls = int(st[ffi.PMX_FEED_FORWARD_LEN_SUM]), int(st[ffi.PMX_FEED_REVERSE_LEN_SUM])
+            # (one copy of the chromosome's block: the result objects must not keep the whole fetched arena alive)
+            i64 = raw_i64[p.slot, :nrow].reshape(ffi.PMX_NROWS, KS + 1).copy()
+            f_rls, r_rls = st[ffi.PMX_FEED_FORWARD_LEN_SUM], st[ffi.PMX_FEED_REVERSE_LEN_SUM]
             self._forward_read_len_sum += f_rls
             self._reverse_read_len_sum += r_rls
             if not self.skip_ncc:
-                fsum, rsum = int(out[ffi.PMX_ROW_SCALARS, 0]), int(out[ffi.PMX_ROW_SCALARS, 1])
+                fsum, rsum = i64[ffi.PMX_ROW_SCALARS, :2].tolist()
                 self._forward_sum += fsum
                 self._reverse_sum += rsum
                 res = self._ncc[p.chrom] = NCCResult(
@@ -560,12 +583,12 @@ class CCHipCalculator:
                     forward_read_len_sum=f_rls, reverse_read_len_sum=r_rls,
                     ccbins=i64[ffi.PMX_ROW_NCC_CCBINS, :S + 1])
                 new_ncc.append(res)
-                ncc_rows.append(out[ffi.PMX_ROW_NCC_CCBINS, :S + 1])
+                ncc_slots.append(p.slot)
             if p.has_m:
                 by_shift = out[ffi.PMX_ROW_MLEN].tolist() if p.known is None else [int(p.known[abs(c - d)]) for d in range(S + 1)]
-                mscc_rows.append((out[ffi.PMX_ROW_MSCC_CCBINS, :S + 1], out[ffi.PMX_ROW_MSCC_FSUM, :S + 1],
-                                  out[ffi.PMX_ROW_MSCC_RSUM, :S + 1],
-                                  out[ffi.PMX_ROW_MLEN, :S + 1] if p.known is None else np.array(by_shift[:S + 1], dtype=np.uint64)))
+                if p.known is not None:
+                    known_rows.append((len(mscc_slots), np.array(by_shift[:S + 1], dtype=np.int64)))
+                mscc_slots.append(p.slot)
                 # the reference stores mappable_len by LAG: d < L -> index L-1-d, L <= d < 2L-1 skipped
                 # (same value by symmetry), d >= 2L-1 appended (mscc.pyx:271,292-298)
                 head = by_shift[:min(L, S + 1)][::-1]
@@ -580,8 +603,16 @@ class CCHipCalculator:
                     ccbins=i64[ffi.PMX_ROW_MSCC_CCBINS, :S + 1], mappable_len=mlen)
                 new_mscc.append(mres)
         # NCCResult.calc_cc / MSCCResult.calc_cc (mscc.pyx:320-323), all chromosomes at once, from the rows as fetched
-        calc_cc_batch(new_ncc, new_mscc, np.stack(ncc_rows).astype(np.int64) if ncc_rows else None,
-                      tuple(np.stack([r[k] for r in mscc_rows]).astype(np.int64) for k in range(4)) if mscc_rows else None)
+        # (the integer rows of all chromosomes in one gather per row kind from the fetched arena)
+        blocks = raw_i64[:, :nrow].reshape(-1, ffi.PMX_NROWS, KS + 1)
+        ncc_bins = blocks[ncc_slots, ffi.PMX_ROW_NCC_CCBINS, :S + 1] if ncc_slots else None
+        mscc_rows = None
+        if mscc_slots:
+            mscc_rows = tuple(blocks[mscc_slots, row, :S + 1] for row in
+                              (ffi.PMX_ROW_MSCC_CCBINS, ffi.PMX_ROW_MSCC_FSUM, ffi.PMX_ROW_MSCC_RSUM, ffi.PMX_ROW_MLEN))
+            for k, row in known_rows:
+                mscc_rows[3][k] = row
+        calc_cc_batch(new_ncc, new_mscc, ncc_bins, mscc_rows)
         if error is not None:
             raise error
 

@@ -318,6 +318,101 @@ __global__ void __launch_bounds__(256) k_set_regions_t(u64 *__restrict__ words, 
     }
 }
 
+// ---- a whole vector from SORTED, DISJOINT intervals, owner-computes (round 4; pmx_bits_set_regions_ex, PMX_REGIONS_SORTED) ----
+// BigWig order: begin_i + offset <= end_i < begin_(i+1) + offset.  k_set_regions_t gives an interval to a wavefront: two atomic
+// ORs and a run of scattered 8-byte stores per interval into a vector that had to be cleared first (22 us + 7 us per
+// chromosome of a genome's feed, which the GPU's work paces).  Here the vector's words are dealt to the workgroups, RB_WORDS
+// each; a workgroup finds the intervals that reach into its bits with two searches of the sorted ends, marks in LDS where a
+// run of ones starts and where it stops (XOR: two marks on one bit -- a run that ends where the next begins -- cancel), turns
+// the marks into the bits with a prefix XOR (within a word by shifts; across its 1024 words by ballots) and writes every word
+// of its range once, plainly, zeros included: no clear, no atomics on the vector.  The order is CHECKED (every interval once,
+// by index): a violation is recorded in err_order (FEED_ERR_BASE - index; the vector's content is then undefined, and the
+// caller must use the general setter); out-of-range intervals are clipped and recorded as k_set_regions_t records them.
+#define RB_WORDS 1024u
+template <typename PT>
+__device__ __forceinline__ uint64_t feed_lower_bound(const PT *__restrict__ pos, uint64_t n, int64_t target, bool packed, u32 lane);   // (below)
+template <typename T>
+__global__ void __launch_bounds__(256) k_regions_build(u64 *__restrict__ words, uint64_t nbits, const T *__restrict__ from,
+                                                       const T *__restrict__ to, uint64_t n, int64_t offset, u64 *__restrict__ err_range,
+                                                       u64 *__restrict__ err_order)
+{
+    __shared__ __align__(16) u64 marks[RB_WORDS];
+    __shared__ uint64_t s_idx[2];
+    __shared__ u32 s_par[4];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint64_t nwords = (nbits + 63) / 64;
+    const uint64_t w0 = (uint64_t)blockIdx.x * RB_WORDS;
+    const uint64_t w1 = w0 + RB_WORDS < nwords ? w0 + RB_WORDS : nwords;
+    const int64_t lo = (int64_t)(w0 * 64), hi = (int64_t)(w1 * 64);
+    for (u32 i = tid; i < RB_WORDS; i += 256) marks[i] = 0;
+    // the intervals that reach into [lo, hi): from the first whose end is >= lo up to the first whose begin is >= hi
+    if (wv < 2) {
+        const uint64_t idx = wv == 0 ? feed_lower_bound(to, n, lo, false, lane) : feed_lower_bound(from, n, hi - offset, false, lane);
+        if (lane == 0) s_idx[wv] = idx;
+    }
+    __syncthreads();
+    const uint64_t i_lo = s_idx[0], i_hi = s_idx[1];
+    for (uint64_t i = i_lo + tid; i < i_hi; i += 256) {
+        int64_t a = (int64_t)from[i] + offset, b = (int64_t)to[i];
+        if (b < a) continue;                           // (an order violation, recorded below)
+        if (a < 0) a = 0;
+        if (b >= (int64_t)nbits) b = (int64_t)nbits - 1;
+        const int64_t sa = a > lo ? a : lo, e1 = b + 1;   // ones on [sa, e1)
+        if (sa >= hi || e1 <= sa) continue;
+        atomicXor(&marks[(u32)((uint64_t)(sa - lo) >> 6)], 1ull << (sa & 63));
+        if (e1 < hi) atomicXor(&marks[(u32)((uint64_t)(e1 - lo) >> 6)], 1ull << (e1 & 63));
+    }
+    // every interval once, by index: order against its successor, emptiness, range
+    {
+        const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+        const uint64_t ia = (uint64_t)blockIdx.x * per, ib = ia + per < n ? ia + per : n;
+        u64 e_order = 0, e_range = 0;
+        for (uint64_t i = ia + tid; i < ib; i += 256) {
+            const int64_t a = (int64_t)from[i] + offset, b = (int64_t)to[i];
+            const bool bad = b < a || (i + 1 < n && (int64_t)from[i + 1] + offset <= b);
+            if (bad && FEED_ERR_BASE - i > e_order) e_order = FEED_ERR_BASE - i;
+            if (b >= a && (a < 0 || b >= (int64_t)nbits) && FEED_ERR_BASE - i > e_range) e_range = FEED_ERR_BASE - i;
+        }
+        if (e_order && err_order) atomicMax(err_order, e_order);
+        if (e_range && err_range) atomicMax(err_range, e_range);
+    }
+    __syncthreads();
+    // marks -> bits: four consecutive words per thread
+    u64 f[4];
+    u32 par = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        const u64 m = marks[4 * tid + k];
+        u64 x = m;
+        x ^= x << 1;
+        x ^= x << 2;
+        x ^= x << 4;
+        x ^= x << 8;
+        x ^= x << 16;
+        x ^= x << 32;           // bit j: parity of the marks on bits 0 .. j of the word
+        f[k] = par ? ~x : x;    // ... and of the thread's words before it
+        par ^= (u32)__popcll(m) & 1u;
+    }
+    const uint64_t bal = __ballot(par != 0);
+    u32 carry = (u32)__popcll(bal & ((1ull << lane) - 1ull)) & 1u;   // the lanes before mine
+    if (lane == 0) s_par[wv] = (u32)__popcll(bal) & 1u;
+    __syncthreads();
+    for (u32 k = 0; k < wv; k++) carry ^= s_par[k];                   // the waves before mine
+    const uint64_t w = w0 + 4ull * tid;
+    if (carry) {
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) f[k] = ~f[k];
+    }
+    if (w + 3 < w1) {
+        reinterpret_cast<ulonglong2 *>(words + w)[0] = make_ulonglong2(f[0], f[1]);
+        reinterpret_cast<ulonglong2 *>(words + w)[1] = make_ulonglong2(f[2], f[3]);
+    } else {
+#pragma unroll
+        for (u32 k = 0; k < 4; k++)
+            if (w + k < w1) words[w + k] = f[k];
+    }
+}
+
 // bitarray[pos] = 1 for positions of either width; out-of-range positions are dropped and recorded in err
 template <typename T>
 __global__ void __launch_bounds__(256) k_set_positions_t(u64 *__restrict__ words, uint64_t nbits, const T *__restrict__ pos,
@@ -646,16 +741,16 @@ int pmx_launch_feed_expand16(pmx_ctx *ctx, const void *d_words, const void *d_se
     return PMX_OK;
 }
 
-int pmx_launch_set_regions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to, uint32_t width,
+int pmx_launch_set_regions_on(pmx_ctx *ctx, hipStream_t stream, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to, uint32_t width,
                              uint64_t n, int64_t offset, uint64_t *d_err)
 {
     if (n == 0) return PMX_OK;
     const int g = feed_grid(ctx, n, 4);
     if (width == 4)
-        hipLaunchKernelGGL(k_set_regions_t<uint32_t>, dim3(g), dim3(256), 0, ctx->stream, (u64 *)d_words, nbits, (const uint32_t *)d_from,
+        hipLaunchKernelGGL(k_set_regions_t<uint32_t>, dim3(g), dim3(256), 0, stream, (u64 *)d_words, nbits, (const uint32_t *)d_from,
                            (const uint32_t *)d_to, n, offset, (u64 *)d_err);
     else if (width == 8)
-        hipLaunchKernelGGL(k_set_regions_t<int64_t>, dim3(g), dim3(256), 0, ctx->stream, (u64 *)d_words, nbits, (const int64_t *)d_from,
+        hipLaunchKernelGGL(k_set_regions_t<int64_t>, dim3(g), dim3(256), 0, stream, (u64 *)d_words, nbits, (const int64_t *)d_from,
                            (const int64_t *)d_to, n, offset, (u64 *)d_err);
     else {
         pmx_set_error("set_regions: interval ends must be 4 (uint32) or 8 (int64) bytes wide");
@@ -663,6 +758,37 @@ int pmx_launch_set_regions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, co
     }
     PMX_CHECK_LAUNCH("k_set_regions_t");
     return PMX_OK;
+}
+
+int pmx_launch_regions_build_on(pmx_ctx *ctx, hipStream_t stream, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to,
+                                uint32_t width, uint64_t n, int64_t offset, uint64_t *d_err_range, uint64_t *d_err_order)
+{
+    (void)ctx;
+    const uint64_t nwords = (nbits + 63) / 64;
+    if (nwords == 0) return PMX_OK;
+    const uint64_t g = (nwords + RB_WORDS - 1) / RB_WORDS;
+    if (g > 0x7fffffffull) {
+        pmx_set_error("regions_build: vector too long");
+        return PMX_ERR_INVALID;
+    }
+    if (width == 4)
+        hipLaunchKernelGGL(k_regions_build<uint32_t>, dim3((u32)g), dim3(256), 0, stream, (u64 *)d_words, nbits, (const uint32_t *)d_from,
+                           (const uint32_t *)d_to, n, offset, (u64 *)d_err_range, (u64 *)d_err_order);
+    else if (width == 8)
+        hipLaunchKernelGGL(k_regions_build<int64_t>, dim3((u32)g), dim3(256), 0, stream, (u64 *)d_words, nbits, (const int64_t *)d_from,
+                           (const int64_t *)d_to, n, offset, (u64 *)d_err_range, (u64 *)d_err_order);
+    else {
+        pmx_set_error("regions_build: interval ends must be 4 (uint32) or 8 (int64) bytes wide");
+        return PMX_ERR_INVALID;
+    }
+    PMX_CHECK_LAUNCH("k_regions_build");
+    return PMX_OK;
+}
+
+int pmx_launch_set_regions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to, uint32_t width,
+                             uint64_t n, int64_t offset, uint64_t *d_err)
+{
+    return pmx_launch_set_regions_on(ctx, ctx->stream, d_words, nbits, d_from, d_to, width, n, offset, d_err);
 }
 
 int pmx_launch_set_positions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_pos, uint32_t width, uint64_t n,

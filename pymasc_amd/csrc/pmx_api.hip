@@ -122,6 +122,16 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->jobtab_next = 0;
     ctx->copy_stream = nullptr;
     ctx->copy_stream2 = nullptr;
+    ctx->side_stream = nullptr;
+    ctx->side_done = ctx->side_copied = ctx->side_fork = nullptr;
+    ctx->side_pending = false;
+    for (int i = 0; i < PMX_SIDE_SLOTS; i++) {
+        ctx->d_side[i] = nullptr;
+        ctx->side_words[i] = 0;
+        ctx->side_slot_done[i] = nullptr;
+        ctx->side_slot_used[i] = false;
+    }
+    ctx->side_next = 0;
     ctx->feed_copied = nullptr;
     ctx->d_build_err = nullptr;
     ctx->build_err_cap = 0;
@@ -145,7 +155,12 @@ int pmx_ctx_create(int device, void *hip_stream, pmx_ctx **out)
     ctx->user_stream = ctx->stream;
     bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->feed_copied, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&ctx->feed_copied, hipEventDisableTiming) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->side_copied, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < PMX_SIDE_SLOTS; i++) ok = hipEventCreateWithFlags(&ctx->side_slot_done[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < PMX_FEED_SLOTS; i++) ok = hipEventCreateWithFlags(&ctx->feed_done[i], hipEventDisableTiming) == hipSuccess;
     if (!ok || hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -162,6 +177,7 @@ int pmx_ctx_sync(pmx_ctx *ctx)
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx, "pmx_ctx_sync: ctx is NULL");
+    PMX_JOIN_SIDE(ctx);
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
 }
@@ -174,6 +190,7 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->copy_stream2) (void)hipStreamSynchronize(ctx->copy_stream2);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     for (int i = 0; i < PMX_FEED_SLOTS; i++) {
         if (ctx->d_feed[i]) (void)hipFree(ctx->d_feed[i]);
         if (ctx->feed_done[i]) (void)hipEventDestroy(ctx->feed_done[i]);
@@ -181,6 +198,14 @@ int pmx_ctx_destroy(pmx_ctx *ctx)
     if (ctx->feed_copied) (void)hipEventDestroy(ctx->feed_copied);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->copy_stream2) (void)hipStreamDestroy(ctx->copy_stream2);
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+    for (int i = 0; i < PMX_SIDE_SLOTS; i++) {
+        if (ctx->d_side[i]) (void)hipFree(ctx->d_side[i]);
+        if (ctx->side_slot_done[i]) (void)hipEventDestroy(ctx->side_slot_done[i]);
+    }
+    if (ctx->side_copied) (void)hipEventDestroy(ctx->side_copied);
+    if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->d_build_err) (void)hipFree(ctx->d_build_err);
     for (int i = 0; i < PMX_JOBTAB_SLOTS; i++) {
         if (ctx->d_jobtab[i]) (void)hipFree(ctx->d_jobtab[i]);
@@ -403,6 +428,15 @@ static int ensure_out_stage(pmx_ctx *ctx, size_t words)
     return PMX_OK;
 }
 
+// the context's stream waits for whatever pmx_bits_set_regions_ex(PMX_REGIONS_SIDE) has queued on the side stream
+int pmx_side_join(pmx_ctx *ctx)
+{
+    if (!ctx->side_pending) return PMX_OK;
+    ctx->side_pending = false;
+    PMX_HIP(hipStreamWaitEvent(ctx->user_stream, ctx->side_done, 0));
+    return PMX_OK;
+}
+
 static int get_event(pmx_ctx *ctx, hipEvent_t *ev)
 {
     if (!ctx->event_pool.empty()) {
@@ -517,6 +551,7 @@ __global__ void __launch_bounds__(256) k_debug_poison_lds(u32 pattern, u32 *sink
 int pmx_debug_poison(pmx_ctx *ctx, uint32_t pattern, uint32_t mask)
 {
     REQUIRE(ctx, "pmx_debug_poison: ctx is NULL");
+    PMX_JOIN_SIDE(ctx);
     const int byte = (int)(pattern & 0xff);
     if ((mask & 1) && ctx->d_slab) PMX_HIP(hipMemsetAsync(ctx->d_slab, byte, ctx->slab_words * sizeof(u32), ctx->stream));
     if ((mask & 2) && ctx->d_slab2) PMX_HIP(hipMemsetAsync(ctx->d_slab2, byte, ctx->slab2_words * sizeof(u32), ctx->stream));
@@ -579,6 +614,7 @@ int pmx_bits_free(pmx_ctx *ctx, uint64_t *d_words)
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx, "pmx_bits_free: ctx is NULL");
+    PMX_JOIN_SIDE(ctx);
     if (!d_words) return PMX_OK;
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     PMX_HIP(hipFree(d_words));
@@ -589,6 +625,7 @@ int pmx_bits_clear(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits)
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words, "pmx_bits_clear: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     PMX_HIP(hipMemsetAsync(d_words, 0, words_for(nbits) * sizeof(uint64_t), ctx->stream));
     return PMX_OK;
 }
@@ -597,6 +634,7 @@ int pmx_bits_upload(pmx_ctx *ctx, uint64_t *d_words, const uint64_t *h_words, ui
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && h_words, "pmx_bits_upload: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     PMX_HIP(hipMemcpyAsync(d_words, h_words, words_for(nbits) * sizeof(uint64_t), hipMemcpyHostToDevice,
                            ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -607,6 +645,7 @@ int pmx_bits_download(pmx_ctx *ctx, const uint64_t *d_words, uint64_t *h_words, 
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && h_words, "pmx_bits_download: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     PMX_HIP(hipMemcpyAsync(h_words, d_words, words_for(nbits) * sizeof(uint64_t), hipMemcpyDeviceToHost,
                            ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -617,6 +656,7 @@ int pmx_bits_set_positions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, 
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && (d_pos || n == 0), "pmx_bits_set_positions_dev: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     return pmx_launch_set_positions(ctx, d_words, nbits, d_pos, n);
 }
 
@@ -624,6 +664,7 @@ int pmx_bits_set_positions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, cons
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && (h_pos || n == 0), "pmx_bits_set_positions: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     if (n == 0) return PMX_OK;
     // positions are range-checked by the kernel itself (the smallest bad index comes back with the synchronisation this
     // entry point does anyway); on PMX_ERR_INVALID the bits of the valid positions have been set
@@ -653,6 +694,7 @@ int pmx_bits_set_regions_dev(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, co
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && ((d_from && d_to) || n == 0), "pmx_bits_set_regions_dev: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     return pmx_launch_set_regions(ctx, d_words, nbits, d_from, d_to, n);
 }
 
@@ -661,6 +703,7 @@ int pmx_bits_set_regions(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const 
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && ((h_from && h_to) || n == 0), "pmx_bits_set_regions: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     if (n == 0) return PMX_OK;
     for (uint64_t i = 0; i < n; i++) {
         if (h_to[i] < h_from[i]) continue;
@@ -688,6 +731,7 @@ int pmx_bits_count(pmx_ctx *ctx, const uint64_t *d_words, uint64_t nbits, uint64
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_words && h_count, "pmx_bits_count: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     int rc = pmx_ensure_scratch(ctx, 4096);
     if (rc) return rc;
     PMX_HIP(hipMemsetAsync(ctx->d_scratch, 0, sizeof(u64), ctx->stream));
@@ -808,6 +852,67 @@ static int feed_copy(pmx_ctx *ctx, unsigned char *d, const FeedPart *parts, uint
     return PMX_OK;
 }
 
+// ---- the side stream (pmx_bits_set_regions_ex with PMX_REGIONS_SIDE) ----
+// One task = one vector: wait for the mark on the context's stream, clear, copy the intervals (copy_stream2) into a staging slot
+// of the side ring, set the regions -- all on side_stream.  Nothing here touches ctx->stream, the feeders' ring or their events.
+// (A worker thread issuing these calls was tried: the caller spends its time waiting for the feeders' staging slots anyway --
+// the GPU paces a genome's feed --, so it bought nothing.)
+static int side_run(pmx_ctx *ctx, const pmx_side_task &t)
+{
+    PMX_HIP(hipStreamWaitEvent(ctx->side_stream, t.fork, 0));
+    const bool build = (t.flags & PMX_REGIONS_SORTED) != 0;   // (writes every word itself)
+    if ((t.flags & PMX_REGIONS_CLEAR) && !build)
+        PMX_HIP(hipMemsetAsync(t.d_words, 0, ((t.nbits + 63) / 64) * sizeof(uint64_t), ctx->side_stream));
+    if (t.n == 0 && !build) return PMX_OK;
+    const size_t o_last = align16((size_t)t.n * t.width_bytes);
+    const uint32_t slot = ctx->side_next;
+    ctx->side_next = (slot + 1) % PMX_SIDE_SLOTS;
+    if (ctx->side_slot_used[slot]) PMX_HIP(hipEventSynchronize(ctx->side_slot_done[slot]));
+    const size_t words = (2 * o_last + 7) / 8 + 8;
+    if (ctx->side_words[slot] < words) {
+        if (ctx->d_side[slot]) PMX_HIP(hipFree(ctx->d_side[slot]));
+        ctx->d_side[slot] = nullptr;
+        ctx->side_words[slot] = 0;
+        const size_t want = words + words / 4;
+        PMX_HIP(hipMalloc((void **)&ctx->d_side[slot], want * sizeof(uint64_t)));
+        ctx->side_words[slot] = want;
+    }
+    unsigned char *d = (unsigned char *)ctx->d_side[slot];
+    const FeedPart parts[2] = {{0, t.h_first, (size_t)t.n * t.width_bytes}, {o_last, t.h_last, (size_t)t.n * t.width_bytes}};
+    int rc = feed_copy(ctx, d, parts, 2, ctx->copy_stream2);
+    if (rc) return rc;
+    PMX_HIP(hipEventRecord(ctx->side_copied, ctx->copy_stream2));
+    PMX_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_copied, 0));
+    if (build)
+        rc = pmx_launch_regions_build_on(ctx, ctx->side_stream, t.d_words, t.nbits, d, d + o_last, t.width_bytes, t.n, t.first_offset,
+                                         t.d_state + PMX_FEED_FIRST_OUT_OF_RANGE, t.d_state + PMX_FEED_REGIONS_UNSORTED);
+    else
+        rc = pmx_launch_set_regions_on(ctx, ctx->side_stream, t.d_words, t.nbits, d, d + o_last, t.width_bytes, t.n, t.first_offset,
+                                       t.d_state ? t.d_state + PMX_FEED_FIRST_OUT_OF_RANGE : nullptr);
+    if (rc) return rc;
+    PMX_HIP(hipEventRecord(ctx->side_slot_done[slot], ctx->side_stream));
+    ctx->side_slot_used[slot] = true;
+    return PMX_OK;
+}
+
+static int side_submit(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last, uint32_t width_bytes,
+                       uint64_t n, int64_t first_offset, uint64_t *d_state, uint32_t flags)
+{
+    pmx_side_task t;
+    t.d_words = d_words; t.nbits = nbits; t.h_first = h_first; t.h_last = h_last; t.width_bytes = width_bytes;
+    t.n = n; t.first_offset = first_offset; t.d_state = d_state; t.flags = flags;
+    t.fork = ctx->side_fork;
+    // behind everything queued on the context's stream so far (the vector's memory may come from a pool whose last user is a
+    // kernel queued there), beside everything queued after
+    PMX_HIP(hipEventRecord(t.fork, ctx->stream));
+    const int rc = side_run(ctx, t);
+    // the end of the side work so far: what pmx_side_join makes the context's stream wait for (recorded after a failure too --
+    // whatever was queued is then still waited for)
+    ctx->side_pending = true;
+    PMX_HIP(hipEventRecord(ctx->side_done, ctx->side_stream));
+    return rc;
+}
+
 extern "C" {
 
 int pmx_feed_reads(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const void *h_pos, uint32_t pos_bytes,
@@ -896,6 +1001,8 @@ int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t 
     if (rc) return rc;
     rc = feed_publish(ctx);
     if (rc) return rc;
+    // (the expansion stays on the context's stream: on the copy stream it held up the next copy, on a stream of its own it ran
+    // beside the builder kernels and slowed them by what it gained -- the feed is paced by the GPU's work, not by the queues)
     rc = pmx_launch_feed_expand16(ctx, d, d + o_start, d + o_base, nseg, n, d + o_pos);
     if (rc) return rc;
     rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d + o_pos, 4, d + o_len, len_bytes, uniform_len, nullptr, n, reads_before, d_state,
@@ -904,11 +1011,46 @@ int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t 
     return feed_release(ctx, slot);
 }
 
+int pmx_bits_set_regions_ex(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
+                            uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state, uint32_t flags)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    REQUIRE(ctx && d_words && ((h_first && h_last) || n == 0), "pmx_bits_set_regions_ex: NULL argument");
+    REQUIRE(width_bytes == 4 || width_bytes == 8, "pmx_bits_set_regions_ex: interval ends must be 4 or 8 bytes wide");
+    REQUIRE(!(flags & ~(PMX_REGIONS_CLEAR | PMX_REGIONS_SIDE | PMX_REGIONS_SORTED)), "pmx_bits_set_regions_ex: unknown flag");
+    REQUIRE(!(flags & PMX_REGIONS_SORTED) || d_state, "pmx_bits_set_regions_ex: PMX_REGIONS_SORTED needs d_state (order violations are recorded there)");
+    if (flags & PMX_REGIONS_SORTED) flags |= PMX_REGIONS_CLEAR;
+    if (flags & PMX_REGIONS_SIDE) {
+        if (n == 0 && !(flags & PMX_REGIONS_CLEAR)) return PMX_OK;
+        return side_submit(ctx, d_words, nbits, h_first, h_last, width_bytes, n, first_offset, d_state, flags);
+    }
+    PMX_JOIN_SIDE(ctx);
+    if (flags & PMX_REGIONS_SORTED) {
+        const size_t o_last = align16((size_t)n * width_bytes);
+        unsigned char *d = nullptr;
+        uint32_t slot = 0;
+        int rc = feed_acquire(ctx, 2 * o_last, &d, &slot);
+        if (rc) return rc;
+        const FeedPart parts[2] = {{0, h_first, (size_t)n * width_bytes}, {o_last, h_last, (size_t)n * width_bytes}};
+        rc = feed_copy(ctx, d, parts, 2, ctx->copy_stream2);
+        if (rc) return rc;
+        rc = feed_publish(ctx, ctx->copy_stream2);
+        if (rc) return rc;
+        rc = pmx_launch_regions_build_on(ctx, ctx->stream, d_words, nbits, d, d + o_last, width_bytes, n, first_offset,
+                                         d_state + PMX_FEED_FIRST_OUT_OF_RANGE, d_state + PMX_FEED_REGIONS_UNSORTED);
+        if (rc) return rc;
+        return feed_release(ctx, slot);
+    }
+    if (flags & PMX_REGIONS_CLEAR) PMX_HIP(hipMemsetAsync(d_words, 0, ((nbits + 63) / 64) * sizeof(uint64_t), ctx->stream));
+    return pmx_bits_set_regions_async(ctx, d_words, nbits, h_first, h_last, width_bytes, n, first_offset, d_state);
+}
+
 int pmx_bits_set_regions_async(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
                                uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state)
 {
     if (ctx) (void)hipSetDevice(ctx->device);
     REQUIRE(ctx && d_words && ((h_first && h_last) || n == 0), "pmx_bits_set_regions_async: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     REQUIRE(width_bytes == 4 || width_bytes == 8, "pmx_bits_set_regions_async: interval ends must be 4 or 8 bytes wide");
     if (n == 0) return PMX_OK;
     const size_t o_last = align16((size_t)n * width_bytes);
@@ -933,6 +1075,7 @@ int pmx_bits_build_batch(pmx_ctx *ctx, uint32_t njobs, const pmx_build_job *jobs
 {
     if (ctx) (void)hipSetDevice(ctx->device);
     REQUIRE(ctx && (jobs || njobs == 0), "pmx_bits_build_batch: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     REQUIRE(pos_bytes == 4 || pos_bytes == 8, "pmx_bits_build_batch: positions must be 4 or 8 bytes wide");
     if (njobs == 0) return PMX_OK;
     // one error word per job of the batches since the last status call
@@ -990,6 +1133,7 @@ int pmx_bits_build_status(pmx_ctx *ctx)
 {
     if (ctx) (void)hipSetDevice(ctx->device);
     REQUIRE(ctx, "pmx_bits_build_status: ctx is NULL");
+    PMX_JOIN_SIDE(ctx);
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     const size_t n = ctx->build_err_jobs;
     if (n == 0) return PMX_OK;
@@ -1027,6 +1171,7 @@ int pmx_mappable_len_dev(pmx_ctx *ctx, const uint64_t *d_M, uint64_t nbits, uint
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_M && d_out, "pmx_mappable_len_dev: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     int rc = check_shift_args(nbits, max_shift, "pmx_mappable_len_dev");
     if (rc) return rc;
     REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
@@ -1046,6 +1191,7 @@ int pmx_mappable_len_batch_dev(pmx_ctx *ctx, uint32_t njobs, const uint64_t *con
 {
     if (ctx) (void)hipSetDevice(ctx->device);
     REQUIRE(ctx && (njobs == 0 || (d_M && nbits && d_out)), "pmx_mappable_len_batch_dev: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
             "pmx_mappable_len_batch_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
     if (njobs == 0) return PMX_OK;
@@ -1206,6 +1352,7 @@ static int cc_batch_impl(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && d_F && d_R && nbits && d_out, "pmx_cc_batch_dev: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     REQUIRE(read_len >= 1 && read_len <= 65535, "pmx_cc_batch_dev: read_len must be in [1, 65535]");
     REQUIRE(!((flags & PMX_FLAG_FORCE_DENSE) && (flags & PMX_FLAG_FORCE_SPARSE)),
             "pmx_cc_batch_dev: FORCE_DENSE and FORCE_SPARSE are exclusive");
@@ -1373,6 +1520,7 @@ int pmx_cc_dev(pmx_ctx *ctx, const uint64_t *d_F, const uint64_t *d_R, const uin
                uint32_t max_shift, uint32_t read_len, uint32_t flags, uint64_t *d_out)
 {
     REQUIRE(ctx && d_F && d_R && d_out, "pmx_cc_dev: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     return pmx_cc_batch_dev(ctx, 1, &d_F, &d_R, d_M ? &d_M : nullptr, &nbits, max_shift, read_len, flags, &d_out);
 }
 
@@ -1381,6 +1529,7 @@ int pmx_calc_correlation(pmx_ctx *ctx, const uint64_t *h_F, const uint64_t *h_R,
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && h_F && h_R && h_out, "pmx_calc_correlation: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     int rc = check_shift_args(nbits, max_shift, "pmx_calc_correlation");
     if (rc) return rc;
     const uint64_t nw = words_for(nbits);
@@ -1407,6 +1556,7 @@ int pmx_mappable_len(pmx_ctx *ctx, const uint64_t *h_M, uint64_t nbits, uint32_t
 {
     if (ctx) (void)hipSetDevice(ctx->device);   // the caller may have switched devices (one context per GPU)
     REQUIRE(ctx && h_M && h_out, "pmx_mappable_len: NULL argument");
+    PMX_JOIN_SIDE(ctx);
     int rc = check_shift_args(nbits, max_shift, "pmx_mappable_len");
     if (rc) return rc;
     const uint64_t nw = words_for(nbits);

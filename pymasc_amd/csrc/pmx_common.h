@@ -38,6 +38,19 @@ struct pmx_timed_launch {
     hipEvent_t start, stop;
 };
 
+#define PMX_SIDE_SLOTS 4    // staging slots of the side stream's work
+struct pmx_side_task {
+    uint64_t *d_words;
+    uint64_t nbits;
+    const void *h_first, *h_last;
+    uint32_t width_bytes;
+    uint64_t n;
+    int64_t first_offset;
+    uint64_t *d_state;
+    uint32_t flags;
+    hipEvent_t fork;
+};
+
 #ifndef PMX_FEED_SLOTS
 #define PMX_FEED_SLOTS 6
 #endif
@@ -103,6 +116,18 @@ struct pmx_ctx {
     hipEvent_t jobtab_mark[PMX_JOBTAB_SLOTS][2];          // where the context's two streams stood when the NEXT table was uploaded
     bool jobtab_used[PMX_JOBTAB_SLOTS], jobtab_marked[PMX_JOBTAB_SLOTS];
     uint32_t jobtab_next;
+    // pmx_bits_set_regions_ex(PMX_REGIONS_SIDE): clear, copy (copy_stream2, a staging ring of its own) and kernel on a stream
+    // beside the context's.  side_fork: where the context's stream stood when the work was queued (the side stream waits for
+    // it); side_done: the end of the side work (pmx_side_join: the context's stream waits for it -- every entry point but the
+    // read feeders does that first).
+    hipStream_t side_stream;
+    hipEvent_t side_fork, side_done, side_copied;
+    bool side_pending;
+    uint64_t *d_side[PMX_SIDE_SLOTS];
+    size_t side_words[PMX_SIDE_SLOTS];
+    hipEvent_t side_slot_done[PMX_SIDE_SLOTS];
+    bool side_slot_used[PMX_SIDE_SLOTS];
+    uint32_t side_next;
     hipStream_t user_stream;     // `stream` as given at creation (launchers may point `stream` at aux_stream for a while)
     u64 *d_build_err;            // pmx_bits_build_batch: one range-error word per job since the last pmx_bits_build_status
     size_t build_err_cap, build_err_jobs;
@@ -125,6 +150,13 @@ int pmx_launch_density_probe(pmx_ctx *ctx, const pmx_probe_jobs *jobs, uint32_t 
 // profiling helpers (pmx_api.hip)
 int pmx_prof_begin(pmx_ctx *ctx, int kernel_id, pmx_timed_launch *tl, bool fallback = false);
 int pmx_prof_end(pmx_ctx *ctx, pmx_timed_launch *tl);
+int pmx_side_join(pmx_ctx *ctx);   // the context's stream waits for the side stream's work (no-op when there is none)
+#define PMX_JOIN_SIDE(ctx)                   \
+    do {                                     \
+        const int rcj_ = pmx_side_join(ctx); \
+        if (rcj_) return rcj_;               \
+    } while (0)
+
 int pmx_ensure_scratch(pmx_ctx *ctx, size_t words);
 // copies `bytes` of a job table to the device buffer of the context's current stream (stream-ordered; the source may be
 // reused at once); *d receives the device address
@@ -146,6 +178,12 @@ uint32_t pmx_feed_build_blocks(uint64_t nbits);
 int pmx_launch_feed_expand16(pmx_ctx *ctx, const void *d_words, const void *d_seg_start, const void *d_seg_base, uint32_t nseg,
                              uint64_t n, void *d_pos32);
 int pmx_launch_set_regions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to, uint32_t width,
+                             uint64_t n, int64_t offset, uint64_t *d_err);
+// the whole vector from sorted, disjoint intervals (k_regions_build): no clear needed, violations recorded in d_err_order
+int pmx_launch_regions_build_on(pmx_ctx *ctx, hipStream_t stream, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to,
+                                uint32_t width, uint64_t n, int64_t offset, uint64_t *d_err_range, uint64_t *d_err_order);
+// (the same on an explicit stream: the side work never touches ctx->stream)
+int pmx_launch_set_regions_on(pmx_ctx *ctx, hipStream_t stream, uint64_t *d_words, uint64_t nbits, const void *d_from, const void *d_to, uint32_t width,
                              uint64_t n, int64_t offset, uint64_t *d_err);
 int pmx_launch_set_positions_w(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *d_pos, uint32_t width, uint64_t n,
                                uint64_t *d_err);

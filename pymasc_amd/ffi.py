@@ -35,7 +35,11 @@ PMX_FLAG_SKIP_MLEN = 8
 PMX_FEED_FORWARD_LEN_SUM, PMX_FEED_REVERSE_LEN_SUM, PMX_FEED_FORWARD_KEPT, PMX_FEED_REVERSE_KEPT = 0, 1, 2, 3
 PMX_FEED_FIRST_UNSORTED, PMX_FEED_FIRST_OUT_OF_RANGE, PMX_FEED_LAST_POS, PMX_FEED_LAST_FORWARD_POS = 4, 5, 6, 7
 PMX_FEED_READS, PMX_FEED_MAX_REVERSE_LEN, PMX_FEED_CHUNK_FORWARD_POS, PMX_FEED_WORDS = 8, 9, 10, 16
+PMX_FEED_REGIONS_UNSORTED = 11   # first interval that breaks the order PMX_REGIONS_SORTED promises
 PMX_FEED_ERR_BASE = 1 << 62
+PMX_REGIONS_CLEAR = 1        # pmx_bits_set_regions_ex: clear the vector first
+PMX_REGIONS_SIDE = 2         # ... on the context's side stream, beside the read feeders
+PMX_REGIONS_SORTED = 4       # ... sorted, disjoint intervals: the vector is built (every word written once, no clear)
 PMX_FEED_WHOLE_VECTORS = 1   # pmx_feed_reads_ex / pmx_feed_reads_delta16: the first run of a chromosome writes every word
 PMX_PATH_DENSE = 1
 PMX_PATH_SPARSE = 2
@@ -53,7 +57,7 @@ EXPORTS = [
     "pmx_bits_alloc", "pmx_bits_free", "pmx_bits_clear", "pmx_bits_upload", "pmx_bits_download",
     "pmx_bits_set_positions", "pmx_bits_set_positions_dev", "pmx_bits_set_regions", "pmx_bits_set_regions_dev",
     "pmx_bits_count",
-    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_ex", "pmx_feed_reads_delta16", "pmx_bits_set_regions_async", "pmx_bits_build_batch",
+    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_ex", "pmx_feed_reads_delta16", "pmx_bits_set_regions_async", "pmx_bits_set_regions_ex", "pmx_bits_build_batch",
     "pmx_bits_build_status",
     "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_cc_batch_ranges_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
     "pmx_mappable_len_batch_dev",
@@ -106,6 +110,7 @@ def load_library(path: Optional[str] = None):
     L.pmx_feed_reads_delta16.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp, u32, vp, u32, u64, vp, u32]
     L.pmx_feed_reads_ex.argtypes = [vp, vp, vp, u64, vp, u32, vp, u32, vp, u64, u64, vp, u32]
     L.pmx_bits_set_regions_async.argtypes = [vp, vp, u64, vp, vp, u32, u64, ctypes.c_int64, vp]
+    L.pmx_bits_set_regions_ex.argtypes = [vp, vp, u64, vp, vp, u32, u64, ctypes.c_int64, vp, u32]
     L.pmx_bits_build_batch.argtypes = [vp, u32, vp, u32]
     L.pmx_bits_build_status.argtypes = [vp]
     L.pmx_mappable_len_batch_dev.argtypes = [vp, u32, vp, vp, u32, u32, vp]
@@ -436,16 +441,20 @@ class Context:
         return pos, readlen, rev
 
     def bits_set_regions_async(self, d_words: int, nbits: int, first: np.ndarray, last: np.ndarray, first_offset: int = 0,
-                               d_state: Optional[int] = None):
-        """set(first + first_offset, last) per interval, no synchronisation (uint32 or int64 arrays)."""
+                               d_state: Optional[int] = None, clear: bool = False, side: bool = False, sorted_disjoint: bool = False):
+        """set(first + first_offset, last) per interval, no synchronisation (uint32 or int64 arrays).  clear: the vector is
+        cleared first; side: on the context's side stream, beside the read feeders; sorted_disjoint: the intervals are in
+        BigWig order and the whole vector is BUILT from them (d_state required: a violation is recorded in
+        d_state[PMX_FEED_REGIONS_UNSORTED]) -- pmx_bits_set_regions_ex, include/pymasc_amd.h."""
         first, last = np.asarray(first), np.asarray(last)
         if first.dtype != last.dtype or first.dtype not in (np.dtype(np.uint32), np.dtype(np.int64)):
             first, last = first.astype(np.int64), last.astype(np.int64)
         first, last = np.ascontiguousarray(first), np.ascontiguousarray(last)
         assert first.size == last.size
-        _check(self._L, self._L.pmx_bits_set_regions_async(self._h, ctypes.c_void_p(d_words), int(nbits), first.ctypes.data,
-                                                           last.ctypes.data, first.dtype.itemsize, first.size, int(first_offset),
-                                                           ctypes.c_void_p(d_state) if d_state else None))
+        flags = (PMX_REGIONS_CLEAR if clear else 0) | (PMX_REGIONS_SIDE if side else 0) | (PMX_REGIONS_SORTED if sorted_disjoint else 0)
+        _check(self._L, self._L.pmx_bits_set_regions_ex(self._h, ctypes.c_void_p(d_words), int(nbits), first.ctypes.data,
+                                                        last.ctypes.data, first.dtype.itemsize, first.size, int(first_offset),
+                                                        ctypes.c_void_p(d_state) if d_state else None, flags))
         return first, last
 
     class _BuildJob(ctypes.Structure):

@@ -232,16 +232,35 @@ def calc_cc_batch(ncc: List["NCCResult"], mscc: List["MSCCResult"], ncc_bins: Op
             denom = glen - np.arange(bins.shape[1], dtype=np.float64)[None, :]
             fmean = np.array([float(r.forward_sum) for r in ncc])[:, None] / glen
             rmean = np.array([float(r.reverse_sum) for r in ncc])[:, None] / glen
-            geo = ((fmean * (1 - fmean)) * (rmean * (1 - rmean))) ** 0.5
-            rows((bins / denom - fmean * rmean) / geo, bins.sum(axis=1) == 0, ncc)
+            geo = ((fmean * (1 - fmean)) * (rmean * (1 - rmean))) ** 0.5       # (one value per chromosome)
+            # (bins / denom - fmean * rmean) / geo, in place: a [chromosomes, shifts] float64 temporary is 200 KB for a genome
+            # at 1000 shifts -- above the allocator's mmap threshold, so every temporary of the plain expression costs a
+            # mapping and its page faults; the same operations in the same order on one buffer
+            cc = np.divide(bins, denom, out=denom)
+            cc -= fmean * rmean
+            cc /= geo
+            rows(cc, bins.sum(axis=1) == 0, ncc)
             ncc = []
         if mscc_rows is not None and len(mscc):
             bins = np.asarray(mscc_rows[0], dtype=np.int64)
             tot = np.asarray(mscc_rows[3], dtype=np.float64)
-            fmean = np.asarray(mscc_rows[1], dtype=np.float64) / tot
-            rmean = np.asarray(mscc_rows[2], dtype=np.float64) / tot
-            geo = ((fmean * (1 - fmean)) * (rmean * (1 - rmean))) ** 0.5
-            rows((bins / tot - fmean * rmean) / geo, bins.sum(axis=1) == 0, mscc)
+            fmean = np.asarray(mscc_rows[1], dtype=np.float64)
+            fmean /= tot
+            rmean = np.asarray(mscc_rows[2], dtype=np.float64)
+            rmean /= tot
+            # geo = ((fmean * (1 - fmean)) * (rmean * (1 - rmean))) ** 0.5 and (bins / tot - fmean * rmean) / geo: the same
+            # operations in the same order (IEEE products commute; x ** 0.5 IS numpy's sqrt), on three buffers instead of ten
+            geo = np.subtract(1, fmean)
+            geo *= fmean
+            tmp = np.subtract(1, rmean)
+            tmp *= rmean
+            geo *= tmp
+            np.sqrt(geo, out=geo)
+            cc = np.divide(bins, tot, out=tmp)
+            fmean *= rmean
+            cc -= fmean
+            cc /= geo
+            rows(cc, bins.sum(axis=1) == 0, mscc)
             mscc = []
         for group in _by_shape(ncc):
             S1 = group[0].max_shift + 1

@@ -170,8 +170,22 @@ class FakeContext:
         pos, rev = ffi.unpack_delta16(reads)
         return self.feed_reads(d_F, d_R, nbits, pos, readlen, rev, reads_before, d_state, whole_vectors)
 
-    def bits_set_regions_async(self, p, nbits, first, last, first_offset=0, d_state=None):
+    def bits_set_regions_async(self, p, nbits, first, last, first_offset=0, d_state=None, clear=False, side=False,
+                               sorted_disjoint=False):
         w = self._mem[p]
+        if sorted_disjoint:      # PMX_REGIONS_SORTED: the order is checked, a violation recorded (the vector is then undefined)
+            a = np.asarray(first).astype(np.int64) + first_offset
+            b = np.asarray(last).astype(np.int64)
+            bad = (b < a)
+            bad[:-1] |= a[1:] <= b[:-1]
+            if bad.any():
+                st = self._mem[d_state]
+                st[ffi.PMX_FEED_REGIONS_UNSORTED] = max(int(st[ffi.PMX_FEED_REGIONS_UNSORTED]), ffi.PMX_FEED_ERR_BASE - int(np.flatnonzero(bad)[0]))
+                w[:(nbits + 63) // 64] = np.uint64(0x5555aaaa5555aaaa)
+                return first, last
+            clear = True
+        if clear:
+            w[:(nbits + 63) // 64] = 0
         for a, b in zip(np.asarray(first).tolist(), np.asarray(last).tolist()):
             a += first_offset
             b = min(b, nbits - 1)

@@ -180,6 +180,118 @@ def test_set_regions_async_matches_oracle(ctx, dt, offset):
     del keep
 
 
+def _intervals(rng, nbits, n, max_len, max_gap):
+    """n sorted, disjoint (begin, end] BigWig pairs inside [0, nbits): set(begin + 1, end)."""
+    gaps = rng.integers(0, max_gap + 1, size=n)          # (gap 0: a run that ends where the next begins)
+    lens = rng.integers(1, max_len + 1, size=n)
+    begin = np.cumsum(gaps + np.concatenate([[0], lens[:-1]]))
+    end = begin + lens
+    keep = end < nbits
+    return begin[keep], end[keep]
+
+
+@pytest.mark.parametrize("dt", [np.uint32, np.int64])
+@pytest.mark.parametrize("nbits,n,max_len,max_gap", [(300000, 900, 300, 60), (65536 * 3 + 17, 40, 9000, 3), (1000, 30, 20, 20),
+                                                     (65536 * 5, 3, 200000, 1000), (64 * 1024, 2000, 3, 40), (4_000_000, 60000, 90, 40)])
+def test_a_vector_built_from_sorted_intervals_matches_oracle(ctx, dt, nbits, n, max_len, max_gap):
+    """PMX_REGIONS_SORTED (k_regions_build): every word written by its owner over whatever the vector held; runs that touch,
+    runs across several workgroups' words, single bits, the vector's first and last bit."""
+    rng = np.random.default_rng(nbits % 1000 + n)
+    begin, end = _intervals(rng, nbits, n, max_len, max_gap)
+    if begin.size:       # ... up to the very last bit, and from the very first (begin + 1 = 0 cannot be said in uint32: bit 1)
+        end[-1] = nbits - 1
+    d = ctx.bits_alloc(nbits)
+    ctx.bits_upload(d, np.full(ffi.nwords(nbits), 0xdeadbeefcafef00d, dtype=np.uint64), nbits)
+    d_st = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    keep = ctx.bits_set_regions_async(d, nbits, begin.astype(dt), end.astype(dt), 1, d_st, sorted_disjoint=True)
+    got = ctx.bits_download(d, nbits)
+    np.testing.assert_array_equal(got, oracle.bits_from_intervals([(int(b), int(e)) for b, e in zip(begin, end)], nbits))
+    st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+    assert int(st[ffi.PMX_FEED_REGIONS_UNSORTED]) == 0 and int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 0
+    # offset 0 (set(first, last)), bit 0 included
+    if dt is np.int64 and begin.size:
+        first = begin + 1
+        first[0] = 0
+        ctx.bits_set_regions_async(d, nbits, first.astype(dt), end.astype(dt), 0, d_st, sorted_disjoint=True)
+        want = oracle.bits_from_intervals([(int(a) - 1, int(e)) for a, e in zip(first, end)], nbits)
+        np.testing.assert_array_equal(ctx.bits_download(d, nbits), want)
+    ctx.bits_free(d)
+    ctx.bits_free(d_st)
+    del keep
+
+
+def test_sorted_builder_without_intervals_beyond_the_vector_and_out_of_order(ctx):
+    nbits = 200000
+    d = ctx.bits_alloc(nbits)
+    d_st = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    junk = np.full(ffi.nwords(nbits), 0xffffffffffffffff, dtype=np.uint64)
+    # no intervals: zeros over whatever was there
+    ctx.bits_upload(d, junk, nbits)
+    ctx.bits_set_regions_async(d, nbits, np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint32), 1, d_st, sorted_disjoint=True)
+    assert not ctx.bits_download(d, nbits).any()
+    # an interval that runs beyond the vector is clipped and recorded, as by the general setter
+    ctx.bits_upload(d, junk, nbits)
+    b_, e_ = np.array([10, 5000, nbits - 50], dtype=np.uint32), np.array([20, 70000, nbits + 500], dtype=np.uint32)
+    ctx.bits_set_regions_async(d, nbits, b_, e_, 1, d_st, sorted_disjoint=True)
+    want = oracle.bits_from_intervals([(10, 20), (5000, 70000), (nbits - 50, nbits - 1)], nbits)
+    np.testing.assert_array_equal(ctx.bits_download(d, nbits), want)
+    st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+    assert ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 2 and int(st[ffi.PMX_FEED_REGIONS_UNSORTED]) == 0
+    # order violations are recorded (first index): overlap, wrong order, an empty interval
+    for b_, e_, first_bad in (([10, 15, 400], [20, 30, 500], 0), ([300, 10, 600], [350, 20, 700], 0),
+                              ([10, 50, 70, 90], [20, 60, 70, 95], 2), ([10, 30], [20, 40], None)):
+        ctx.bits_clear(d_st, ffi.PMX_FEED_WORDS * 64)
+        ctx.bits_set_regions_async(d, nbits, np.array(b_, dtype=np.uint32), np.array(e_, dtype=np.uint32), 1, d_st, sorted_disjoint=True)
+        st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+        if first_bad is None:
+            assert int(st[ffi.PMX_FEED_REGIONS_UNSORTED]) == 0
+        else:
+            assert ffi.PMX_FEED_ERR_BASE - int(st[ffi.PMX_FEED_REGIONS_UNSORTED]) == first_bad
+    ctx.bits_free(d)
+    ctx.bits_free(d_st)
+
+
+@pytest.mark.parametrize("side", [False, True])
+def test_regions_cleared_and_set_beside_the_read_feeders(ctx, side):
+    """pmx_bits_set_regions_ex: PMX_REGIONS_CLEAR on vectors full of somebody else's bits, PMX_REGIONS_SIDE while reads are fed to
+    other vectors on the context's stream; the first other entry point (here: the download) waits for the side stream."""
+    rng = np.random.default_rng(19)
+    glen, S, L = 900000, 300, 36
+    nbits = glen + L + S + 100
+    tracks, keep, fed = [], [], []
+    for k in range(6):
+        d_M = ctx.bits_alloc(nbits)
+        ctx.bits_upload(d_M, np.full(ffi.nwords(nbits), 0xdeadbeefcafef00d, dtype=np.uint64), nbits)
+        n_iv = 0 if k == 3 else 4000                       # (no intervals at all: the vector is still cleared)
+        starts = np.sort(rng.integers(0, nbits - 300, size=n_iv))
+        ends = starts + rng.integers(1, 250, size=n_iv)
+        if k % 2:     # (the general setter: intervals in any order, overlapping)
+            keep.append(ctx.bits_set_regions_async(d_M, nbits, starts.astype(np.uint32), ends.astype(np.uint32), 1, None, clear=True, side=side))
+        else:         # (the builder: BigWig order)
+            starts, ends = _intervals(rng, nbits, n_iv, 250, 200)
+            d_ms = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+            keep.append(ctx.bits_set_regions_async(d_M, nbits, starts.astype(np.uint32), ends.astype(np.uint32), 1, d_ms, side=side,
+                                                   sorted_disjoint=True))
+        tracks.append((d_M, starts, ends))
+        # ... and a chromosome's reads on the context's own stream meanwhile
+        pos, rlen, rev = make_reads(rng, 20000, glen, lens=(L,))
+        d_F, d_R = garbage_vectors(ctx, nbits)
+        d_st = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+        keep.append(ctx.feed_reads(d_F, d_R, nbits, pos.astype(np.int32), rlen.astype(np.int32), rev, 0, d_st, whole_vectors=True))
+        fed.append((d_F, d_R, d_st, pos, rlen, rev))
+    for d_M, starts, ends in tracks:
+        got = ctx.bits_download(d_M, nbits)
+        np.testing.assert_array_equal(got, oracle.bits_from_intervals([(int(s), int(e)) for s, e in zip(starts, ends)], nbits))
+        ctx.bits_free(d_M)
+    for d_F, d_R, d_st, pos, rlen, rev in fed:
+        F, R, _fr, _rr, _nb = reference_feed(pos, rlen, rev, S, L, glen)
+        np.testing.assert_array_equal(ctx.bits_download(d_F, nbits), F)
+        np.testing.assert_array_equal(ctx.bits_download(d_R, nbits), R)
+        for d in (d_F, d_R, d_st):
+            ctx.bits_free(d)
+    del keep
+
+
 @pytest.mark.parametrize("dt", [np.uint32, np.int64])
 def test_build_batch_matches_oracle_and_reports_range_errors(ctx, dt):
     rng = np.random.default_rng(21)

@@ -437,3 +437,38 @@ def test_bulk_feed_in_two_bytes_per_read():
         a, b = one.get_result(c).chrom, two.get_result(c).chrom
         assert list(a.ccbins) == list(b.ccbins) and (a.forward_sum, a.reverse_sum) == (b.forward_sum, b.reverse_sum)
         assert (a.forward_read_len_sum, a.reverse_read_len_sum) == (b.forward_read_len_sum, b.reverse_read_len_sum)
+
+
+def test_track_intervals_out_of_order_or_overlapping_go_the_general_way():
+    """The reference ORs intervals in whatever order they come (set(begin + 1, end) per interval, mscc.pyx:343-344): only tracks
+    in BigWig order are handed to the builder (PMX_REGIONS_SORTED), the others to the general setter -- same results."""
+    names, lens, tracks, reads = _small_mscc_setup(seed=21)
+    S, L = 90, 36
+    rng = np.random.default_rng(5)
+    messy = {}
+    for c, iv in tracks.items():
+        iv = list(iv)
+        iv += [(b + 3, e + 40, v) for b, e, v in iv[::5]]        # overlapping copies
+        rng.shuffle(iv)                                          # ... in any order
+        messy[c] = iv
+
+    class Spy(FakeContext):
+        def __init__(self):
+            super().__init__()
+            self.sorted_calls = []
+
+        def bits_set_regions_async(self, *a, **kw):
+            self.sorted_calls.append(bool(kw.get("sorted_disjoint")))
+            return super().bits_set_regions_async(*a, **kw)
+
+    for which, want_sorted in ((tracks, True), (messy, False)):
+        ctx = Spy()
+        calc = CCHipCalculator(S, L, names, lens, bwfeeder=DictFeeder(which), context=ctx)
+        ocalc = oracle.OracleCalculator(S, L, names, lens, mappability={
+            c: [x for x in iv if np.float32(x[2]) >= 1] for c, iv in which.items()})
+        feed_all(calc, reads)
+        feed_all(ocalc, reads)
+        calc.finishup_calculation()
+        ocalc.finishup_calculation()
+        assert_matches_oracle(calc, ocalc, names)
+        assert ctx.sorted_calls and all(s == want_sorted for s in ctx.sorted_calls)
