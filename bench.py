@@ -631,8 +631,15 @@ def main():
                 calc.close()
                 stamps.append((tc - t0, t1 - tc, tf - t1, t2 - tf, time.perf_counter() - t2))
                 return whole
-            for _ in range(4):      # (untimed genomes: staging slots and vector pool reach their sizes, and the card -- idle while the
-                calc_step()         #  host packed the reads above -- is back at its clocks: the first timed genomes ran 10-20 % slower)
+            # (the interpreter's generational garbage collector walks every live object of this process -- torch included --
+            # whenever its allocation counters trip: ~45 ms once every few calls here, nothing to do with the path measured;
+            # it is paused for the timed calls, as for any micro-benchmark of Python-level code.  Collected BEFORE the untimed
+            # genomes: the card idles through a collection, and the first genomes after an idle stretch run 10-20 % slower)
+            import gc
+            gc.collect()
+            gc.disable()
+            for _ in range(4):      # (untimed genomes: staging slots and vector pool reach their sizes, the card is back at its clocks)
+                calc_step()
             fence()
             if os.environ.get("BENCH_CALC_PROFILE"):      # where the host time of the calculator leg goes (stderr)
                 import cProfile
@@ -643,12 +650,6 @@ def main():
                 fence()
                 pr.disable()
                 pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
-            # (the interpreter's generational garbage collector walks every live object of this process -- torch included --
-            # whenever its allocation counters trip: ~45 ms once every few calls here, nothing to do with the path measured;
-            # it is paused for the timed calls, as for any micro-benchmark of Python-level code)
-            import gc
-            gc.collect()
-            gc.disable()
             trace_acc.clear()
             del stamps[:]
             t1 = time.perf_counter()

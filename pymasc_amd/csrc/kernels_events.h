@@ -175,6 +175,21 @@ __device__ __forceinline__ bool ev_role_mlo(u32 tid, u32 lo) { return BIG ? tid 
 template <bool BIG>
 __device__ __forceinline__ u32 ev_role_mlo_index(u32 tid) { return BIG ? tid : (tid & 63u); }
 
+// EV_BIG_NT: the tile bodies of the max_shift > 1023 instantiations are streamed with non-temporal loads -- every word is used
+// once, and the lines that ARE reused (the halos, the slab segments the flushes add to) stay in the L2 longer.  Same-box A/B on
+// BASELINE config 5: 3.10 -> 3.045 ms per step (0 = plain loads).
+#ifndef EV_BIG_NT
+#define EV_BIG_NT 1
+#endif
+typedef u32 ev_v4u __attribute__((ext_vector_type(4)));
+template <bool GUARD, bool NT>
+__device__ __forceinline__ uint4 ev_ld_body(const u32 *__restrict__ p, int64_t j, uint64_t nbits)
+{
+    if (GUARD || !NT) return ld_quad<GUARD>(p, j, nbits);
+    const ev_v4u v = __builtin_nontemporal_load(reinterpret_cast<const ev_v4u *>(p + j));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <bool HAS_M, bool GUARD, bool BIG>
 __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, const u32 *__restrict__ R,
                                          const u32 *__restrict__ M, int64_t d0, uint64_t nbits, u32 tid, u32 nhr, u32 lo,
@@ -188,11 +203,11 @@ __device__ __forceinline__ void ev_fetch(EvRegs &er, const u32 *__restrict__ F, 
             er.f[q] = make_uint4(0, 0, 0, 0);
             er.r[q] = make_uint4(0, 0, 0, 0);
         } else {
-            er.f[q] = ld_quad<GUARD>(F, j, nbits);
-            er.r[q] = ld_quad<GUARD>(R, j, nbits);
+            er.f[q] = ev_ld_body<GUARD, BIG && EV_BIG_NT>(F, j, nbits);
+            er.r[q] = ev_ld_body<GUARD, BIG && EV_BIG_NT>(R, j, nbits);
         }
         if (HAS_M) {
-            er.m[q] = ld_quad<GUARD>(M, j, nbits);
+            er.m[q] = ev_ld_body<GUARD, BIG && EV_BIG_NT>(M, j, nbits);
             const int64_t j0 = d0 + (int64_t)q * SP_TBW + 4 * (int64_t)(tid & ~63u) - 1;   // uniform over the wave
             er.wb[q] = GUARD ? ld_dword_guarded(M, j0, nbits) : M[j0];
         } else {
@@ -371,7 +386,10 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
     u32 *const lds = BIG ? ev_dyn_lds : ev_static_lds;
     const u32 HN = BIG ? hn_arg : 1024u;      // entries per histogram row
     const u32 LO = BIG ? lo_arg : EV_LO;      // dwords of M staged below the tile
-    const u32 HI = BIG ? hi_arg : EV_HI;      // ... and above it (BIG with the mappable-length pairs: max_lag bits, a multiple of 4 dwords)
+    const u32 HI = BIG ? (hi_arg & 0xffffu) : EV_HI;   // ... and above it (BIG with the mappable-length pairs: max_lag bits, a multiple of 4 dwords)
+    // BIG with the mappable-length pairs: their row of lags lives in LDS behind the sub-groups' blocks when the launcher found
+    // room for it without giving up a resident wavefront (bit 16 of hi_arg; ev_big_plan), else in the slab (atomics in the L2)
+    const bool EE_LDS = BIG && DO_MLEN && (hi_arg >> 16) != 0;
     const u32 BIAS = LO * 32u;                // list positions are relative to the first staged bit of M
     const u32 sg = NSG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0u;
     u32 *const hN = lds;
@@ -380,6 +398,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
     u32 *const hEE = lds + L::o_ee(HN);
     u32 *const xch = lds + L::o_xch(HN);
     u32 *const sgb = lds + L::o_sg(HN) + sg * L::sg_words(LO, HI);
+    u32 *const hEEb = lds + L::total(HN, LO, NSG, HI);   // (EE_LDS: HN / 2 dwords, two signed 16-bit cells each, as rows GF and GR)
     u32 *const MT = sgb + L::MT0 + 4;
     unsigned short *const idxF = reinterpret_cast<unsigned short *>(sgb + L::IDXF);
     unsigned short *const idxR = reinterpret_cast<unsigned short *>(sgb + L::IDXR);
@@ -395,11 +414,13 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
     {
 #pragma nounroll
         for (u32 i = gt; i < L::o_sg(HN); i += NT) lds[i] = 0;
+        if (EE_LDS)
+            for (u32 i = gt; i < HN / 2; i += NT) hEEb[i] = 0;
     }
 
     FIRST_JOB(ji, JT, jobs, njobs, g0)
     u32 jn = ji;
-    if (BIG && DO_MLEN) ev_zero_row5(slab, blockIdx.x + ji, HN, gt, NT);
+    if (BIG && DO_MLEN && !EE_LDS) ev_zero_row5(slab, blockIdx.x + ji, HN, gt, NT);
     EvRegs er;
     SpJobRegs pj;   // job of the tiles being prefetched (index jn), held in scalar registers
     load_job(pj, jobs.j[ji]);
@@ -663,7 +684,10 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
         }
         if (NSG > 1) {
             // the listed reads of every sub-group (flush bookkeeping), and the end of the iteration's job
-            if (tid == 0) xch[sg] = (act && !dense) ? (nF | (nRt << 16)) : 0u;
+            if (tid == 0) {
+                xch[sg] = (act && !dense) ? (nF | (nRt << 16)) : 0u;
+                if (DO_MLEN) xch[4 + sg] = (act && do_edges) ? nE : 0u;   // (the bound of the row of lags in LDS, EE_LDS)
+            }
             const u32 end = pj.tile_end < g1 ? pj.tile_end : g1;   // (pj is still the job of tile g here)
             if (gnext > end) gnext = end;
         }
@@ -720,8 +744,15 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                         // CU, hence one L2 -- the add is done there.  At device scope every add is a memory-side operation on a
                         // line of its own: 37 M of them per config-5 step cost the kernel +0.65 ms (measured).
 #ifndef EV_ABL_NOEE
-                        if (h0) __hip_atomic_fetch_add(&gEE[(e0 & EV_POS) - pos], (u32)(((int32_t)(e0 ^ ent) >> 31) | 1), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                        // (EE_LDS, uniform: the row is in LDS -- config 5's 37 M adds per step each cost 32 bytes of write traffic
+                        // between the L2 and the memory side, 1.0 GB of the step's 5.9)
+                        if (EE_LDS) {
+                            const u32 k = (e0 & EV_POS) - pos;
+                            if (h0) atomicAdd(&hEEb[k >> 1], (u32)(((int32_t)(e0 ^ ent) >> 31) | 1) << ((k & 1u) << 4));
+                        } else if (h0) {
+                            __hip_atomic_fetch_add(&gEE[(e0 & EV_POS) - pos], (u32)(((int32_t)(e0 ^ ent) >> 31) | 1), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
 #endif
                         e = h0 ? e + 1 : nE;
                         e0 = LE[e];
@@ -932,13 +963,17 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                 const u32 v = xch[k];
                 accF += v & 0xffffu;
                 accR += v >> 16;
+                if (DO_MLEN) accE += xch[4 + k];
             }
             accF = __builtin_amdgcn_readfirstlane(accF);
             accR = __builtin_amdgcn_readfirstlane(accR);
+            accE = __builtin_amdgcn_readfirstlane(accE);
         }
         const bool leaving = jn != ji || gnext >= g1;
         // another iteration could overflow a 16-bit cell (bounds in the comment of EvLds): flush now
-        const bool risk = HAS_M && (BIG ? (accF + NSG * EV_CAPF > 32767u || 3u * (accR + NSG * EV_CAPR) > 32767u)
+        // (EE_LDS: a cell of the row of lags takes at most one pair per listed edge)
+        const bool risk = HAS_M && (BIG ? (accF + NSG * EV_CAPF > 32767u || 3u * (accR + NSG * EV_CAPR) > 32767u ||
+                                           (EE_LDS && accE + NSG * L::POOL > 32767u))
                                         : (accF + L::POOL > 32767u || (DO_MLEN && accE + EV_CAPE(BIG) > 32767u)));
         if (NSG == 1 && leaving && tid == 0) {
             // tiles flagged in this job: one atomic per workgroup and job, not per tile (47 k adds to one word serialise in L2
@@ -984,6 +1019,23 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                             v.y += o.y;
                         }
                         *dst = v;
+                    }
+                    if (DO_MLEN && EE_LDS) {
+#pragma nounroll
+                        for (u32 k = gt; k < HN / 2; k += NT) {   // the pairs of run edges by lag: two signed cells per dword
+                            const u32 w = hEEb[k];
+                            hEEb[k] = 0;
+                            const int32_t lo16 = (int32_t)(short)(w & 0xffffu);
+                            const int32_t hi16 = (int32_t)(short)((w - (u32)lo16) >> 16);
+                            uint2 *dst = reinterpret_cast<uint2 *>(seg + (size_t)5 * HN + 2 * k);
+                            uint2 v = make_uint2((u32)lo16, (u32)hi16);
+                            if (add) {
+                                const uint2 o = *dst;
+                                v.x += o.x;
+                                v.y += o.y;
+                            }
+                            *dst = v;
+                        }
                     }
                 } else {
                     // max_shift <= 1023 (round 4): the rows leave the workgroup TRANSFORMED -- the inclusive prefix sums of GF and GR,
@@ -1125,7 +1177,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
             if (leaving) seg_written = false;
         }
         if (jn != ji) {
-            if (BIG && DO_MLEN) ev_zero_row5(slab, blockIdx.x + jn, HN, gt, NT);   // (the barrier at the top of the loop follows)
+            if (BIG && DO_MLEN && !EE_LDS) ev_zero_row5(slab, blockIdx.x + jn, HN, gt, NT);   // (the barrier at the top of the loop follows)
             job_mode = 0;
             next_skip = false;
             unreported = 0;

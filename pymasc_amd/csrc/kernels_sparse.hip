@@ -30,6 +30,7 @@
 // No global atomics anywhere.
 #include "pmx_common.h"
 
+#include <stdio.h>
 #include <string.h>
 #include <type_traits>
 #include <vector>
@@ -2379,6 +2380,7 @@ static bool events_enabled()
 // ---- the event kernel beyond 1023 shifts (BIG instantiations) ----
 struct EvBigPlan {
     u32 hn, lo, nsg, lds_bytes, wg_per_cu, hi;
+    u32 ee_lds;   // the row of lags of the fused mappable-length pairs fits into LDS behind the sub-groups' blocks
 };
 
 static bool events_big_enabled()
@@ -2430,8 +2432,28 @@ static bool ev_big_plan(uint32_t max_shift, EvBigPlan *p, uint32_t fused_lag = 0
             p->nsg = nsg;
             p->lds_bytes = bytes - 16;
             p->wg_per_cu = per_cu;
+            p->ee_lds = 0;
         }
     }
+    // the row of lags of the fused mappable-length pairs (hn 16-bit cells) in LDS, if that costs no resident workgroup
+    // (PMX_EV_EE_LDS=0 in the environment: always in the slab -- A/B, tests)
+    static const bool ee_ok = [] {
+        const char *e = getenv("PMX_EV_EE_LDS");
+        return !(e && e[0] == '0');
+    }();
+    if (best_waves && fused_lag && ee_ok) {
+        const u32 bytes = p->lds_bytes + 16 + hn * 2;
+        u32 per_cu = bytes <= lds_cu ? lds_cu / (bytes + 256) : 0;
+        if (per_cu * p->nsg > 4) per_cu = 4 / p->nsg;
+        if (per_cu >= p->wg_per_cu) {
+            p->lds_bytes = bytes - 16;
+            p->ee_lds = 1;
+        }
+    }
+    static const bool dbg = getenv("PMX_DEBUG_PLAN") != nullptr;
+    if (dbg && best_waves)
+        fprintf(stderr, "[ev_big_plan] max_shift %u fused_lag %u: hn %u lo %u hi %u nsg %u lds %u B x %u per CU, row of lags in LDS: %u\n", max_shift,
+                fused_lag, p->hn, p->lo, p->hi, p->nsg, p->lds_bytes, p->wg_per_cu, p->ee_lds);
     return best_waves != 0;
 }
 
@@ -2474,7 +2496,8 @@ static int ev_big_launch(pmx_ctx *ctx, const EvBigPlan &pl, const SpJobTableRef 
         if (dev >= 0) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256 * NSG), pl.lds_bytes, ctx->stream, tab, n, total, tpw, c, max_shift, nhr, fused_lag,
-                       pl.hn, pl.lo, pl.hi, ctx->d_slab, d_flags, d_flags_ac ? d_flags_ac : d_flags, d_nflagged, d_jobstat);
+                       pl.hn, pl.lo, pl.hi | (DO_MLEN && pl.ee_lds ? 1u << 16 : 0u), ctx->d_slab, d_flags, d_flags_ac ? d_flags_ac : d_flags, d_nflagged,
+                       d_jobstat);
     PMX_CHECK_LAUNCH("k_cc_events (max_shift > 1023)");
     return PMX_OK;
 }

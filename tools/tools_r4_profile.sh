@@ -50,6 +50,18 @@ for k in ours:
         fr = p["FETCH_SIZE"] * 1024.0
         wr = p.get("WRITE_SIZE", 0.0) * 1024.0
         traffic["kernels"][k.split("<")[0]] = {"fetch_raw": fr, "fetch_corrected": 2 * fr, "write": wr, "hbm_bytes": 2 * fr + wr}
+# the whole step: every kernel's HBM bytes per dispatch x its dispatches per step (steps of the pass = dispatches of the dominant
+# kernel / its launches per step, both from the bench line), against the algorithmic bytes of a step
+rl = bench_line["roofline"]
+lps = rl["launches"] / float(bench_line["steps"])
+dom = [k for k in ours if k.split("<")[0] == rl["kernel"].split("+")[0]]
+if dom and "FETCH_SIZE" in per[dom[0]]:
+    steps_in_pass = sum(agg[k]["FETCH_SIZE"][1] for k in dom) / lps
+    step_bytes = sum((2 * per[k].get("FETCH_SIZE", 0.0) + per[k].get("WRITE_SIZE", 0.0)) * 1024.0 * agg[k]["FETCH_SIZE"][1] for k in ours) / steps_in_pass
+    alg = rl["algorithmic_bytes_per_launch"] * lps
+    traffic["step"] = {"hbm_bytes": step_bytes, "algorithmic_bytes": alg, "ratio": step_bytes / alg, "steps_in_pass": steps_in_pass,
+                       "dispatches_per_step": {k.split("<")[0]: agg[k]["FETCH_SIZE"][1] / steps_in_pass for k in ours},
+                       "note": "all kernels of the library (names k_*) in the pass; runtime fills / copies are not counted"}
 json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
 CLK, NSIMD, NCU = 2.4e9, 1024, 256
 summ = {**ident, "how": "rocprofv3 --kernel-trace --pmc <SQ counters>, three separate passes of `python3 bench.py --steps 3 --warmup 1 "
@@ -80,5 +92,6 @@ for k, e in summ["kernels"].items():
     print(k, "us=%.1f valu=%.3f lds=%.3f issuing=%.2f waiting=%.2f" % (e["avg_duration_us"], e["valu_issue_util"], e["lds_pipe_util"],
                                                                      e["wave_cycles_issuing"], e["wave_cycles_waiting"]))
 print(json.dumps(traffic["kernels"]))
+print("step:", json.dumps(traffic.get("step")))
 PY
 rm -rf $out/stats $out/pmc[0-9]   # (raw rocprofv3 output: only the summaries travel back)
