@@ -33,8 +33,9 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # (defaults: 100 steps of ~0.43 ms are a 43-ms timed region, three of them; regions of 20 steps spread by 4 % on one box)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shard", choices=["auto", "tiles", "chroms"], default="auto",
                     help="N > 1, strong scaling: equal TILE RANGES of the genome per rank + one all-reduce(sum) of the per-chromosome rows "
                          "(max_shift <= 1023: pmx_cc_batch_ranges_dev), or whole chromosomes by LPT + all-gather; auto: tiles where supported")

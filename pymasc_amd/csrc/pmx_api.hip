@@ -1416,6 +1416,7 @@ static int cc_batch_impl(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_
         return PMX_OK;
     }
     // no hint from the caller: take one from a sample of the vectors (one small launch, one synchronisation)
+    bool probed = false;
     static const bool probe_enabled = [] {   // PMX_DENSITY_PROBE=0: never (A/B, tests of the unhinted event path)
         const char *e = getenv("PMX_DENSITY_PROBE");
         return !(e && e[0] == '0');
@@ -1427,6 +1428,7 @@ static int cc_batch_impl(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_
         int rc = auto_density_hint(ctx, njobs, d_F, d_R, d_M, nbits, max_shift, has_m, &hint);
         if (rc) return rc;
         flags |= hint;
+        probed = true;
     }
     const uint32_t chunk = pmx_cc_batch_jobs(max_shift);
     const size_t ac_words = pmx_autocorr_scratch_words(max_lag);
@@ -1462,7 +1464,10 @@ static int cc_batch_impl(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_
             const char *e = getenv("PMX_AUTOCORR_FORK_BIG");
             return e && e[0] == '1';
         }();
-        const bool fork = fork_enabled && (max_shift <= 1023 || (pmx_events_take_big(max_shift) && !ctx->window_only &&
+        // (not behind the density probe either: its synchronisation has drained the stream, so the forked chain and the window
+        // kernel would START together -- the window kernel's workgroups own fixed tile ranges, and the ones that find their CU
+        // taken for the first 0.1 ms double up elsewhere for the whole launch: 6.6 -> 10.2 ms at 5 % reads per strand, measured)
+        const bool fork = fork_enabled && !probed && (max_shift <= 1023 || (pmx_events_take_big(max_shift) && !ctx->window_only &&
                                                                  (fork_big || pmx_events_big_subgroups(max_shift, has_m ? 1 : 0) == 1)));
         int rc;
         if (do_mlen && !ctx->window_only && pmx_events_can_fuse_mlen(max_shift, max_lag)) {

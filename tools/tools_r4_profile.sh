@@ -57,11 +57,14 @@ lps = rl["launches"] / float(bench_line["steps"])
 dom = [k for k in ours if k.split("<")[0] == rl["kernel"].split("+")[0]]
 if dom and "FETCH_SIZE" in per[dom[0]]:
     steps_in_pass = sum(agg[k]["FETCH_SIZE"][1] for k in dom) / lps
-    step_bytes = sum((2 * per[k].get("FETCH_SIZE", 0.0) + per[k].get("WRITE_SIZE", 0.0)) * 1024.0 * agg[k]["FETCH_SIZE"][1] for k in ours) / steps_in_pass
+    # (the kernels of a STEP: the vectors are built once, before the steps, by the k_set_* / k_feed_* / k_regions_* kernels)
+    in_step = [k for k in ours if not k.startswith(("k_set_", "k_feed", "k_regions", "k_count"))]
+    step_bytes = sum((2 * per[k].get("FETCH_SIZE", 0.0) + per[k].get("WRITE_SIZE", 0.0)) * 1024.0 * agg[k]["FETCH_SIZE"][1] for k in in_step) / steps_in_pass
     alg = rl["algorithmic_bytes_per_launch"] * lps
     traffic["step"] = {"hbm_bytes": step_bytes, "algorithmic_bytes": alg, "ratio": step_bytes / alg, "steps_in_pass": steps_in_pass,
-                       "dispatches_per_step": {k.split("<")[0]: agg[k]["FETCH_SIZE"][1] / steps_in_pass for k in ours},
-                       "note": "all kernels of the library (names k_*) in the pass; runtime fills / copies are not counted"}
+                       "dispatches_per_step": {k.split("<")[0]: agg[k]["FETCH_SIZE"][1] / steps_in_pass for k in in_step},
+                       "note": "all kernels of the library (names k_*) a step launches; the builders of the resident vectors (k_set_*), which run "
+                               "once before the steps, and runtime fills / copies are not counted"}
 json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
 CLK, NSIMD, NCU = 2.4e9, 1024, 256
 summ = {**ident, "how": "rocprofv3 --kernel-trace --pmc <SQ counters>, three separate passes of `python3 bench.py --steps 3 --warmup 1 "
