@@ -1484,7 +1484,13 @@ static int cc_batch_impl(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_
         }
         bool forked = false;
         rc = PMX_OK;
-        if (do_mlen && !fork) {
+        // Behind the probe, window kernels alone: the chain is forked LATE -- queued on the auxiliary stream behind the window
+        // kernel's launch (but not behind its completion: the mark is recorded in front of it).  The window kernel starts
+        // alone and owns the CUs; the chain's kernels move in as its workgroups drain, under its tail.
+        const bool late_fork = fork_enabled && probed && do_mlen && ctx->window_only && max_shift <= 1023;
+        if (late_fork) {
+            PMX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        } else if (do_mlen && !fork) {
             rc = pmx_launch_autocorr_edges_batch(ctx, jobs.data(), n, max_lag, 1, read_len, max_shift, stride);
             if (rc) return rc;
         } else if (do_mlen) {
@@ -1509,6 +1515,14 @@ static int cc_batch_impl(pmx_ctx *ctx, uint32_t njobs, const uint64_t *const *d_
             return rc;
         }
         rc = pmx_launch_cc_sparse_batch(ctx, jobs.data(), n, max_shift, read_len, do_ncc, stride, !do_mlen);
+        if (late_fork && !rc) {
+            PMX_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+            hipStream_t main_stream = ctx->stream;
+            ctx->stream = ctx->aux_stream;
+            rc = pmx_launch_autocorr_edges_batch(ctx, jobs.data(), n, max_lag, 1, read_len, max_shift, stride);
+            ctx->stream = main_stream;
+            forked = true;
+        }
         if (forked) {
             const hipError_t er = join();
             if (!rc && er != hipSuccess) {

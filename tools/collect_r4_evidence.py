@@ -20,6 +20,12 @@ for w, sfx in (("default", ""), ("stress", "_stress")):
     for r in csv.DictReader(open("profiles/r4_kernel_stats%s.csv" % sfx)):
         if r["Name"].startswith(("void k_", "k_")):
             print("     ", r["Name"][:48], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1))
+for f in ("default", "ncc", "stress", "stress_ncc", "nohint"):
+    shutil.copy(G + "bench_%s.json" % f, "profiles/r4_bench_%s.json" % f)
+    b = json.load(open("profiles/r4_bench_%s.json" % f))
+    print("bench", f, b["build_id"], round(b["ms_per_step"], 4), b["kernel_ms_per_step"], round(b["roofline"]["frac"], 4), b["repetitions"]["ms_per_step_min_median_max"],
+          "e2e", round(b["end_to_end"]["ms_per_step"], 3) if b.get("end_to_end") else None,
+          "calc", round(b["end_to_end_calculator"]["ms_per_step"], 3) if b.get("end_to_end_calculator") else None)
 for kind in ("density", "edges"):
     old = json.load(open("profiles/r3_sweep_%s.json" % kind))
     old["what"] = old["what"].replace("tools/gpu_r3_sweeps.sh", "tools/gpu_r4_sweeps.sh").replace(

@@ -118,6 +118,43 @@ def fuzz_feed(ctx, rng, clen, S, L):
     return 0 if ok else 1
 
 
+def fuzz_regions(ctx, rng, M, nbits):
+    """pmx_bits_set_regions_ex (round 4): the case's mappability vector rebuilt from its own runs of ones, as BigWig (begin, end]
+    pairs in order -- PMX_REGIONS_SORTED over a vector full of somebody else's bits, on the side stream or not -- and, now and
+    then, the same intervals in disorder through the general setter (clear first) and through the builder (must be flagged)."""
+    bits = np.unpackbits(M.view(np.uint8), bitorder="little")[:nbits].astype(np.int8)
+    edges = np.diff(np.concatenate([[0], bits, [0]]))
+    first = np.flatnonzero(edges == 1)            # first set bit of a run
+    last = np.flatnonzero(edges == -1) - 1        # its last set bit
+    begin, end = first - 1, last                  # set(begin + 1, end)
+    dt = [np.uint32, np.int64][int(rng.integers(0, 2))]
+    off = 1
+    if begin.size and begin[0] < 0:
+        if dt is np.uint32:
+            dt = np.int64
+    d = ctx.bits_alloc(nbits)
+    d_st = ctx.bits_alloc(ffi.PMX_FEED_WORDS * 64)
+    ctx.bits_upload(d, np.full(ffi.nwords(nbits), 0xa5a5a5a55a5a5a5a, dtype=np.uint64), nbits)
+    side = bool(rng.random() < 0.5)
+    keep = [ctx.bits_set_regions_async(d, nbits, begin.astype(dt), end.astype(dt), off, d_st, side=side, sorted_disjoint=True)]
+    got = ctx.bits_download(d, nbits)
+    st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+    ok = np.array_equal(got, M[:ffi.nwords(nbits)]) and int(st[ffi.PMX_FEED_REGIONS_UNSORTED]) == 0 and int(st[ffi.PMX_FEED_FIRST_OUT_OF_RANGE]) == 0
+    if ok and begin.size > 2 and rng.random() < 0.3:
+        perm = rng.permutation(begin.size)
+        if not np.array_equal(perm, np.arange(begin.size)):
+            keep.append(ctx.bits_set_regions_async(d, nbits, begin[perm].astype(dt), end[perm].astype(dt), off, d_st, clear=True, side=side))
+            ok = np.array_equal(ctx.bits_download(d, nbits), M[:ffi.nwords(nbits)])
+            keep.append(ctx.bits_set_regions_async(d, nbits, begin[perm].astype(dt), end[perm].astype(dt), off, d_st, sorted_disjoint=True))
+            st = ctx.bits_download(d_st, ffi.PMX_FEED_WORDS * 64)
+            ok = ok and int(st[ffi.PMX_FEED_REGIONS_UNSORTED]) != 0
+    ctx.bits_free(d)
+    ctx.bits_free(d_st)
+    if not ok:
+        print("MISMATCH set_regions_ex", nbits, begin.size, dt, side, flush=True)
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -162,6 +199,8 @@ def main():
                     bad += 1
             if rng.random() < 0.15:
                 bad += fuzz_feed(ctx, rng, clen, S, L)
+            if with_m and rng.random() < 0.25:
+                bad += fuzz_regions(ctx, rng, M, nbits)
             if with_m and rng.random() < 0.3:
                 lag = int(rng.choice([S, 300, 1023, 1024, 4000]))
                 if (lag + 1) * nbits < 1.5e9:
