@@ -74,6 +74,30 @@ def build_io(force=False, verbose=False):
     return IO_LIB
 
 
+INGEST_LIB = os.path.join(HERE, "libpymasc_ingest.so")
+
+
+def ingest_sources():
+    return sorted(glob.glob(os.path.join(CSRC, "ingest", "*.hip")))
+
+
+def build_ingest(force=False, verbose=False):
+    """libpymasc_ingest.so (include/pymasc_amd_ingest.h): BGZF inflate + BAM record decode on the device, hipcc for gfx950.
+    A library of its own: libpymasc_hip.so's build id (source_hash) covers the cross-correlation kernels only."""
+    deps = ingest_sources() + [os.path.join(HERE, "..", "include", "pymasc_amd_ingest.h")]
+    if not force and os.path.exists(INGEST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(INGEST_LIB) for d in deps):
+        return INGEST_LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP", "-Wall", "-Wno-unused-function", "-pthread",
+           "-o", INGEST_LIB] + ingest_sources()
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return INGEST_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_io(force="--force" in sys.argv, verbose=True))
+    print(build_ingest(force="--force" in sys.argv, verbose=True))

@@ -123,18 +123,19 @@ __device__ __forceinline__ u32 br_take(BitRd &r, u32 n)
     return v;
 }
 
-// 256 bytes of the ring -> the member's output (dword stores; the first and last group of a member byte by byte)
-__device__ __forceinline__ void inf_flush(const u8 *ring, u8 *__restrict__ out, u64 g0, u64 gstart, u64 gend, u32 lane)
+// 256 bytes of the ring -> the member's output (dword stores; the first and last group of a member byte by byte).
+// Positions are relative to `ob`, the member's first output byte rounded down to 256.
+__device__ __forceinline__ void inf_flush(const u8 *ring, u8 *__restrict__ ob, u32 g0, u32 pstart, u32 pend, u32 lane)
 {
     __syncthreads();
-    const u64 g = g0 + 4u * lane;
-    const u32 v = *reinterpret_cast<const u32 *>(ring + ((u32)g & (INF_RING - 1u)));
-    if (g >= gstart && g + 4u <= gend) {
-        *reinterpret_cast<u32 *>(out + g) = v;
+    const u32 g = g0 + 4u * lane;
+    const u32 v = *reinterpret_cast<const u32 *>(ring + (g & (INF_RING - 1u)));
+    if (g >= pstart && g + 4u <= pend) {
+        *reinterpret_cast<u32 *>(ob + g) = v;
     } else {
 #pragma unroll
         for (u32 b = 0; b < 4; b++)
-            if (g + b >= gstart && g + b < gend) out[g + b] = (u8)(v >> (8u * b));
+            if (g + b >= pstart && g + b < pend) ob[g + b] = (u8)(v >> (8u * b));
     }
 }
 
@@ -213,12 +214,20 @@ __device__ __forceinline__ bool inf_slow(u64 bb, const u32 *cnt, const u16 *syms
 
 __constant__ u8 INF_CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-#define INF_FAIL(code)                       \
-    {                                        \
-        if (lane == 0) status[m] = (code);   \
-        return;                              \
+// (every lane stores the same word: an `if (lane == 0)` in front of a return makes the compiler treat everything that
+// reaches the function's single exit as divergent, and the whole decoder state moves to vector registers -- 388 exec-mask
+// tests instead of 141 in the kernel)
+#define INF_FAIL(code)        \
+    {                         \
+        status[m] = (code);   \
+        return;               \
     }
 
+// The decoder is bound by SCALAR instruction issue (one per cycle and CU, shared by every resident wavefront), not by
+// latency: what counts is the number of scalar instructions per output byte.  Hence: the input-limit test only where the
+// reader takes a dword, no output-limit test per literal (the ring takes the byte anyway, the flush stores nothing beyond
+// ISIZE, and the count is checked at every flush and at the end), 32-bit positions relative to the member's 256-byte
+// aligned start, literal bytes written by all lanes (same address, same value: no exec-mask handling).
 __global__ void __launch_bounds__(64)
 k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *__restrict__ mem, u32 nmem, u32 *__restrict__ status)
 {
@@ -229,39 +238,48 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
     const u64 in_off = mem[m].in_off;
     const u64 gstart = mem[m].out_off;
     const u32 clen = mem[m].clen, isize = mem[m].isize;
-    const u64 gend = gstart + isize;
-    u64 gpos = gstart, flushed = gstart & ~255ull;
+    u8 *__restrict__ ob = out + (gstart & ~255ull);
+    const u32 pstart = (u32)(gstart & 255ull), pend = pstart + isize;   // positions relative to ob
+    u32 pos = pstart, flushed = 0;
     BitRd r;
     r.base = reinterpret_cast<const u32 *>(in + (in_off & ~3ull));
     r.lane = lane;
     const u32 skew = (u32)(in_off & 3ull);
     br_seek(r, skew);
     const u32 wlimit = (skew + clen + 3u) / 4u + 2u;   // dwords the reader may have taken (it looks ahead up to 8 bytes)
+#define INF_REFILL()                                           \
+    if (r.bc < 32u) {                                          \
+        br_refill(r);                                          \
+        if (r.ci * 64u + r.widx > wlimit) INF_FAIL(INF_ERR_INPUT) \
+    }
+#define INF_FLUSH_TO(p)                                           \
+    while (flushed + 256u <= (p)) {                               \
+        if (flushed + 256u > pend + 255u) INF_FAIL(INF_ERR_OUTPUT) \
+        inf_flush(S.ring, ob, flushed, pstart, pend, lane);       \
+        flushed += 256u;                                          \
+    }
 
     for (;;) {
-        br_refill(r);
+        INF_REFILL()
         const u32 bfinal = br_take(r, 1), btype = br_take(r, 2);
         if (btype == 3u) INF_FAIL(INF_ERR_BTYPE)
         if (btype == 0u) {
             // stored block: to the next byte boundary, LEN, NLEN, LEN bytes
             br_take(r, r.bc & 7u);
-            br_refill(r);
+            INF_REFILL()
             const u32 LEN = (u32)r.bb & 0xffffu, NLEN = (u32)(r.bb >> 16) & 0xffffu;
             r.bb >>= 32;
             r.bc -= 32u;
             if ((LEN ^ NLEN) != 0xffffu) INF_FAIL(INF_ERR_STORED)
             const u32 bp = (r.ci * 64u + r.widx) * 4u - (r.bc >> 3);   // the next unread byte (relative to r.base)
             if (bp + LEN > skew + clen) INF_FAIL(INF_ERR_INPUT)
-            if (gpos + LEN > gend) INF_FAIL(INF_ERR_OUTPUT)
+            if (pos + LEN > pend) INF_FAIL(INF_ERR_OUTPUT)
             const u8 *ib = reinterpret_cast<const u8 *>(r.base);
             for (u32 k = 0; k < LEN; k += 64u) {
                 const u32 n = LEN - k < 64u ? LEN - k : 64u;
-                if (lane < n) S.ring[((u32)gpos + lane) & (INF_RING - 1u)] = ib[bp + k + lane];
-                gpos += n;
-                while (flushed + 256u <= gpos) {
-                    inf_flush(S.ring, out, flushed, gstart, gend, lane);
-                    flushed += 256u;
-                }
+                if (lane < n) S.ring[(pos + lane) & (INF_RING - 1u)] = ib[bp + k + lane];
+                pos += n;
+                INF_FLUSH_TO(pos)
             }
             __syncthreads();
             br_seek(r, bp + LEN);
@@ -272,7 +290,7 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                 if (lane < 30u) S.lens[288u + lane] = 5;
                 __syncthreads();
             } else {
-                br_refill(r);
+                INF_REFILL()
                 hlit = br_take(r, 5) + 257u;
                 hdist = br_take(r, 5) + 1u;
                 const u32 hclen = br_take(r, 4) + 4u;
@@ -280,22 +298,21 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                 if (lane < 19u) S.cl[lane] = 0;
                 __syncthreads();
                 for (u32 i = 0; i < hclen; i++) {
-                    br_refill(r);
-                    const u32 v = br_take(r, 3);
-                    if (lane == 0) S.cl[INF_CL_ORDER[i]] = (u8)v;
+                    INF_REFILL()
+                    S.cl[INF_CL_ORDER[i]] = (u8)br_take(r, 3);
                 }
                 __syncthreads();
                 if (!inf_build<7>(S.cl, 19u, S.distT, S.cntD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
                 const u32 total = hlit + hdist;
                 u32 i = 0, prev = 0;
                 while (i < total) {
-                    br_refill(r);
+                    INF_REFILL()
                     const u32 e = RFL(S.distT[(u32)r.bb & 127u]);
                     if (!e) INF_FAIL(INF_ERR_CODE)
                     const u32 s = e & 511u;
                     br_take(r, e >> 9);
                     if (s < 16u) {
-                        if (lane == 0) S.lens[i] = (u8)s;
+                        S.lens[i] = (u8)s;
                         prev = s;
                         i++;
                     } else {
@@ -314,7 +331,6 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                         i += rep;
                         prev = val;
                     }
-                    if (r.ci * 64u + r.widx > wlimit) INF_FAIL(INF_ERR_INPUT)
                 }
                 __syncthreads();
                 if (RFL(S.lens[256]) == 0u) INF_FAIL(INF_ERR_TABLE)   // no end-of-block code
@@ -323,8 +339,7 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
             if (!inf_build<INF_DP>(S.lens + hlit, hdist, S.distT, S.cntD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
 
             for (;;) {
-                br_refill(r);
-                if (r.ci * 64u + r.widx > wlimit) INF_FAIL(INF_ERR_INPUT)
+                INF_REFILL()
                 u32 sym, l;
                 const u32 e = RFL(S.litT[(u32)r.bb & ((1u << INF_LP) - 1u)]);
                 if (e) {
@@ -336,67 +351,60 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                 r.bb >>= l;
                 r.bc -= l;
                 if (sym < 256u) {
-                    if (gpos >= gend) INF_FAIL(INF_ERR_OUTPUT)
-                    if (lane == 0) S.ring[(u32)gpos & (INF_RING - 1u)] = (u8)sym;
-                    gpos++;
-                    if (((u32)gpos & 255u) == 0u) {
-                        inf_flush(S.ring, out, flushed, gstart, gend, lane);
-                        flushed += 256u;
+                    S.ring[pos & (INF_RING - 1u)] = (u8)sym;
+                    pos++;
+                    if ((pos & 255u) == 0u) INF_FLUSH_TO(pos)
+                } else if (sym == 256u) {
+                    break;
+                } else {
+                    sym -= 257u;
+                    if (sym > 28u) INF_FAIL(INF_ERR_DIST)
+                    u32 len;
+                    if (sym < 8u) {
+                        len = 3u + sym;
+                    } else if (sym == 28u) {
+                        len = 258u;
+                    } else {
+                        const u32 eb = (sym >> 2) - 1u;
+                        len = 3u + ((4u + (sym & 3u)) << eb) + br_take(r, eb);
                     }
-                    continue;
-                }
-                if (sym == 256u) break;
-                sym -= 257u;
-                if (sym > 28u) INF_FAIL(INF_ERR_DIST)
-                u32 len;
-                if (sym < 8u) {
-                    len = 3u + sym;
-                } else if (sym == 28u) {
-                    len = 258u;
-                } else {
-                    const u32 eb = (sym >> 2) - 1u;
-                    len = 3u + ((4u + (sym & 3u)) << eb) + br_take(r, eb);
-                }
-                br_refill(r);
-                u32 ds, dl;
-                const u32 de = RFL(S.distT[(u32)r.bb & ((1u << INF_DP) - 1u)]);
-                if (de) {
-                    ds = de & 511u;
-                    dl = de >> 9;
-                } else if (!inf_slow(r.bb, S.cntD, S.symD, ds, dl)) {
-                    INF_FAIL(INF_ERR_CODE)
-                }
-                r.bb >>= dl;
-                r.bc -= dl;
-                if (ds > 29u) INF_FAIL(INF_ERR_DIST)
-                u32 dist;
-                if (ds < 4u) {
-                    dist = 1u + ds;
-                } else {
-                    const u32 eb = (ds >> 1) - 1u;
-                    dist = 1u + ((2u + (ds & 1u)) << eb) + br_take(r, eb);
-                }
-                if ((u64)dist > gpos - gstart) INF_FAIL(INF_ERR_DIST)
-                if (gpos + len > gend) INF_FAIL(INF_ERR_OUTPUT)
-                // the copy: lane i takes byte i of the match (a distance shorter than the match repeats with period dist);
-                // every source byte lies below gpos, every destination at or above it
-                __syncthreads();
-                const u32 gp = (u32)gpos;
-                if (dist <= INF_NEAR) {
-                    for (u32 i = lane; i < len; i += 64u) {
-                        const u32 j = dist >= len ? i : i % dist;
-                        S.ring[(gp + i) & (INF_RING - 1u)] = S.ring[(gp - dist + j) & (INF_RING - 1u)];
+                    INF_REFILL()
+                    u32 ds, dl;
+                    const u32 de = RFL(S.distT[(u32)r.bb & ((1u << INF_DP) - 1u)]);
+                    if (de) {
+                        ds = de & 511u;
+                        dl = de >> 9;
+                    } else if (!inf_slow(r.bb, S.cntD, S.symD, ds, dl)) {
+                        INF_FAIL(INF_ERR_CODE)
                     }
-                } else {
-                    // further back than the ring: from the member's output in HBM (flushed up to the last 256-byte boundary
-                    // by this wavefront's own, earlier stores; read past the first-level cache)
-                    const volatile u8 *src = out + (gpos - dist);
-                    for (u32 i = lane; i < len; i += 64u) S.ring[(gp + i) & (INF_RING - 1u)] = src[i];
-                }
-                gpos += len;
-                while (flushed + 256u <= gpos) {
-                    inf_flush(S.ring, out, flushed, gstart, gend, lane);
-                    flushed += 256u;
+                    r.bb >>= dl;
+                    r.bc -= dl;
+                    if (ds > 29u) INF_FAIL(INF_ERR_DIST)
+                    u32 dist;
+                    if (ds < 4u) {
+                        dist = 1u + ds;
+                    } else {
+                        const u32 eb = (ds >> 1) - 1u;
+                        dist = 1u + ((2u + (ds & 1u)) << eb) + br_take(r, eb);
+                    }
+                    if (dist > pos - pstart) INF_FAIL(INF_ERR_DIST)
+                    if (pos + len > pend) INF_FAIL(INF_ERR_OUTPUT)
+                    // the copy: lane i takes byte i of the match (a distance shorter than the match repeats with period dist);
+                    // every source byte lies below pos, every destination at or above it
+                    __syncthreads();
+                    if (dist <= INF_NEAR) {
+                        for (u32 i = lane; i < len; i += 64u) {
+                            const u32 j = dist >= len ? i : i % dist;
+                            S.ring[(pos + i) & (INF_RING - 1u)] = S.ring[(pos - dist + j) & (INF_RING - 1u)];
+                        }
+                    } else {
+                        // further back than the ring: from the member's output in HBM (flushed up to the last 256-byte boundary
+                        // by this wavefront's own, earlier stores; read past the first-level cache)
+                        const volatile u8 *src = ob + (pos - dist);
+                        for (u32 i = lane; i < len; i += 64u) S.ring[(pos + i) & (INF_RING - 1u)] = src[i];
+                    }
+                    pos += len;
+                    INF_FLUSH_TO(pos)
                 }
             }
         }
@@ -405,11 +413,13 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
     // the stream must end inside the member's bytes and fill ISIZE exactly
     const u64 used_bits = (u64)(r.ci * 64u + r.widx) * 32u - r.bc - 8u * skew;
     if (used_bits > 8ull * clen) INF_FAIL(INF_ERR_INPUT)
-    if (gpos != gend) INF_FAIL(INF_ERR_ISIZE)
-    while (flushed < gend) {
-        inf_flush(S.ring, out, flushed, gstart, gend, lane);
+    if (pos != pend) INF_FAIL(pos > pend ? INF_ERR_OUTPUT : INF_ERR_ISIZE)
+    while (flushed < pend) {
+        inf_flush(S.ring, ob, flushed, pstart, pend, lane);
         flushed += 256u;
     }
+#undef INF_REFILL
+#undef INF_FLUSH_TO
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -439,26 +449,53 @@ __device__ __forceinline__ u32 crc_xpow8(u32 nbytes)   // x^(8 nbytes) mod P
     return p;
 }
 
+// (first version: one byte load per step and lane, 1 KB apart between lanes: 34 ms for 2.1 GB.  Now 16-byte aligned loads
+// and four table lookups per dword -- slicing by 4, tables in LDS.)
 __global__ void __launch_bounds__(256)
 k_bgzf_crc(const u8 *__restrict__ out, const DMember *__restrict__ mem, u32 nmem, u32 *__restrict__ status)
 {
-    __shared__ u32 T[256];
+    __shared__ u32 T[4][256];
     {
         u32 c = threadIdx.x;
         for (u32 k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
-        T[threadIdx.x] = c;
+        T[0][threadIdx.x] = c;
+        __syncthreads();
+        for (u32 k = 1; k < 4; k++) {
+            c = (c >> 8) ^ T[0][c & 255u];
+            T[k][threadIdx.x] = c;
+        }
     }
     __syncthreads();
     const u32 m = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (m >= nmem) return;
-    const u32 isize = mem[m].isize;
-    const u8 *p = out + mem[m].out_off;
-    const u32 per = (isize + 63u) / 64u;
-    const u32 lo = lane * per < isize ? lane * per : isize, hi = lo + per < isize ? lo + per : isize;
+    const u64 A = mem[m].out_off, B = A + mem[m].isize, a0 = A & ~15ull;
+    const u32 nch = (u32)((B - a0 + 15u) >> 4), cpl = (nch + 63u) / 64u;
+    const u32 c0 = lane * cpl < nch ? lane * cpl : nch, c1 = c0 + cpl < nch ? c0 + cpl : nch;
+    u64 lo = a0 + 16ull * c0, hi = a0 + 16ull * c1;
+    lo = lo < A ? A : lo;
+    hi = hi > B ? B : hi;
+    if (c0 >= c1) lo = hi = B;
     u32 c = 0xffffffffu;
-    for (u32 i = lo; i < hi; i++) c = T[(c ^ p[i]) & 255u] ^ (c >> 8);
+    for (u32 ch = c0; ch < c1; ch++) {
+        const u64 base = a0 + 16ull * ch;
+        const uint4 v = *reinterpret_cast<const uint4 *>(out + base);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+        if (base >= A && base + 16u <= B) {
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                c ^= w[k];
+                c = T[3][c & 255u] ^ T[2][(c >> 8) & 255u] ^ T[1][(c >> 16) & 255u] ^ T[0][c >> 24];
+            }
+        } else {
+#pragma unroll
+            for (u32 k = 0; k < 16; k++) {
+                const u64 at = base + k;
+                if (at >= A && at < B) c = T[0][(c ^ (w[k >> 2] >> (8u * (k & 3u)))) & 255u] ^ (c >> 8);
+            }
+        }
+    }
     c = (lo < hi) ? ~c : 0u;
-    u32 x = crc_mulmod(crc_xpow8(isize - hi), c);
+    u32 x = crc_mulmod(crc_xpow8((u32)(B - hi)), c);
     for (u32 o = 32; o; o >>= 1) x ^= (u32)__shfl_xor((int)x, (int)o, 64);
     if (lane == 0 && x != mem[m].crc && status[m] == 0) status[m] = INF_ERR_CRC;
 }
@@ -731,11 +768,11 @@ Staging g_stage;
 const char *inf_err_text(u32 code)
 {
     switch (code) {
-    case INF_ERR_BTYPE: return "reserved DEFLATE block type";
-    case INF_ERR_STORED: return "stored block with LEN != ~NLEN";
-    case INF_ERR_TABLE: return "malformed Huffman code lengths";
-    case INF_ERR_CODE: return "bit pattern that is no Huffman code of its block";
-    case INF_ERR_DIST: return "match distance beyond the start of the block";
+    case INF_ERR_BTYPE: return "corrupt DEFLATE stream in a BGZF block: reserved block type";
+    case INF_ERR_STORED: return "corrupt DEFLATE stream in a BGZF block: stored block with LEN != ~NLEN";
+    case INF_ERR_TABLE: return "corrupt DEFLATE stream in a BGZF block: malformed Huffman code lengths";
+    case INF_ERR_CODE: return "corrupt DEFLATE stream in a BGZF block: bit pattern that is no Huffman code of its block";
+    case INF_ERR_DIST: return "corrupt DEFLATE stream in a BGZF block: match distance beyond the start of the block";
     case INF_ERR_OUTPUT: return "BGZF block does not inflate to its recorded size (more output than ISIZE)";
     case INF_ERR_INPUT: return "DEFLATE stream runs past the BGZF block";
     case INF_ERR_ISIZE: return "BGZF block does not inflate to its recorded size";

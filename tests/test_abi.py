@@ -51,6 +51,26 @@ def test_io_library_builds_and_exports_its_header():
         assert getattr(bam, k) == int(v, 16), k
 
 
+def test_ingest_library_builds_and_exports_its_header(tmp_path):
+    """libpymasc_ingest.so (device-side BGZF inflate + BAM decode, include/pymasc_amd_ingest.h): gfx950 code object, every
+    declared symbol exported, nothing undeclared bound; without a GPU opening a file fails loudly (no host inflate in it)."""
+    from pymasc_amd import bam, bam_device
+    path = build.build_ingest()
+    assert os.path.exists(path)
+    assert b"gfx950" in open(path, "rb").read()
+    L = bam_device.load_ingest_library()
+    syms = header_symbols("pymasc_amd_ingest.h")
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(bam_device.INGEST_EXPORTS) == syms
+    assert L.pmx_dbam_version() >= 1
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(bam.PmxIOError, match="GPU|device|HIP"):
+            bam_device.DeviceBamReader(os.path.join(ROOT, "tests", "golden", "ENCFF000RMB-test.bam"))
+
+
 def test_header_constants_match_binding():
     text = open(os.path.join(ROOT, "include", "pymasc_amd.h")).read()
     consts = dict(re.findall(r"#define\s+(PMX_[A-Z_0-9]+)\s+(-?\d+)u?\b", text))

@@ -89,6 +89,36 @@ def time_reader(path, threads, mapq):
             "compressed_GBps": round(c["bytes_in"] / dt / 1e9, 3)}
 
 
+def time_device_reader(path, mapq, check=None):
+    """The device path (libpymasc_ingest.so): file -> HBM -> inflate + CRC32 -> record chain -> filtered arrays IN HBM (what a
+    device-side feed consumes), and the same + the copy of the arrays to the host (what BamReader.batches hands out)."""
+    from pymasc_amd import bam_device as D
+    out = []
+    for rep in range(3):      # the first open also page-locks the staging buffers and loads the code object
+        t0 = time.time()
+        with D.DeviceBamReader(path) as r:
+            t1 = time.time()
+            kept = r.decode(mapq)
+            t2 = time.time()
+            n = 0
+            cs = 0
+            for ref, pos, _rl, rev in r.batches(mapq):
+                n += ref.size
+                cs += int(pos.astype(np.int64).sum()) + int(rev.sum())
+            t3 = time.time()
+            c, tm = r.counters(), r.timings()
+        assert n == kept
+        if check is not None:
+            assert (n, cs) == check, ((n, cs), check)
+        out.append({"rep": rep, "open_s": round(t1 - t0, 4), "decode_s": round(t2 - t1, 4), "resident_total_s": round(t2 - t0, 4),
+                    "decode_again_and_copy_to_host_s": round(t3 - t2, 4), "kept": kept, "records": c["records"], "members": c["members"],
+                    "pieces_rewalked": c["rewalked"], "phases_s": {k: round(v, 4) for k, v in tm.items()},
+                    "records_per_s": round(c["records"] / (t2 - t0)), "uncompressed_GBps": round(c["bytes_out"] / (t2 - t0) / 1e9, 3),
+                    "compressed_GBps": round(c["bytes_in"] / (t2 - t0) / 1e9, 3)})
+        print(json.dumps(out[-1]), flush=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=5_000_000)
@@ -97,6 +127,7 @@ def main():
     ap.add_argument("--threads", type=int, nargs="*", default=[1, 2, 4, 8, 16])
     ap.add_argument("--chroms", type=int, default=None)
     ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--device", action="store_true", help="time the device-side reader (BGZF inflate + decode as HIP kernels)")
     ap.add_argument("--pyloop", type=int, default=0, help="time a per-read Python feeding loop over this many reads")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -107,6 +138,18 @@ def main():
         if t <= (os.cpu_count() or 1):
             res["reader"].append(time_reader(a.path, t, a.mapq))
             print(json.dumps(res["reader"][-1]), flush=True)
+
+    if a.device:
+        with B.BamReader(a.path, threads=16) as r:       # the checker: same records, same fields
+            n = cs = 0
+            for ref, pos, _rl, rev in r.batches(a.mapq):
+                n += ref.size
+                cs += int(pos.astype(np.int64).sum()) + int(rev.sum())
+        res["device_reader"] = time_device_reader(a.path, a.mapq, check=(n, cs))
+        best = min(x["resident_total_s"] for x in res["device_reader"])
+        host = min(x["seconds"] for x in res["reader"]) if res["reader"] else None
+        res["device_vs_host_reader"] = {"device_resident_s": best, "host_best_s": host, "speedup": round(host / best, 2) if host else None}
+        print(json.dumps(res["device_vs_host_reader"]), flush=True)
 
     if a.pyloop:
         from tests.fake_context import FakeContext     # host-only stand-in: the loop never reaches a flush here
