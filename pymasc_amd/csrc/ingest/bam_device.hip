@@ -62,17 +62,21 @@ enum {
 
 #define INF_RING 4096u                      // bytes of recent output kept in LDS
 #define INF_NEAR (INF_RING - 258u - 64u)    // distances up to here are served from the ring
-#define INF_LP 10u                          // primary bits of the literal / length table
+#define INF_LP 11u                          // primary bits of the literal / length table (level-1 BAM: the 256 values of a packed
+                                            // sequence byte get 10- and 11-bit codes; at 10 bits 8 % of the symbols took the slow path)
 #define INF_DP 8u                           // ... of the distance table (and of the code-length code: 7 used)
 
 struct InfLds {
     u8 ring[INF_RING];
+    u8 dump[64];                            // where the lanes beyond the end of a match write (no branch around the store)
     u16 litT[1u << INF_LP];                 // entry: symbol | code length << 9; 0 = not a code of <= INF_LP bits
     u16 distT[1u << INF_DP];
     u16 symL[320];                          // symbols in canonical order (the slow path for longer codes)
     u16 symD[32];
     u32 cntL[16], cntD[16];                 // codes per length
-    u8 lens[352];                           // code lengths of the block (literal / length, then distance)
+    u32 fcL[16], fcD[16];                   // first code of every length
+    u32 ixL[16], ixD[16];                   // ... and its index in the canonical order
+    u8 lens[352];                           // code lengths of the block (literal / length, then distance); [351]: dump
     u8 cl[32];                              // lengths of the code-length code
 };
 
@@ -123,26 +127,32 @@ __device__ __forceinline__ u32 br_take(BitRd &r, u32 n)
     return v;
 }
 
-// 256 bytes of the ring -> the member's output (dword stores; the first and last group of a member byte by byte).
-// Positions are relative to `ob`, the member's first output byte rounded down to 256.
+// 256 bytes of the ring -> the member's output.  Positions are relative to `ob`, the member's first output byte rounded down to
+// 256.  The first and the last group of a member are stored byte by byte under a per-lane test -- in a function of its own:
+// ONE divergent branch anywhere inside the symbol loop makes the compiler structurize the whole loop (every uniform branch of
+// the decoder becomes exec-mask and flag handling, 52 scalar instructions per symbol instead of ~25).
+__device__ __noinline__ void inf_flush_edge(const u8 *ring, u8 *ob, u32 g0, u32 pstart, u32 pend, u32 lane)
+{
+    const u32 g = g0 + 4u * lane;
+    const u32 v = *reinterpret_cast<const u32 *>(ring + (g & (INF_RING - 1u)));
+    for (u32 b = 0; b < 4; b++)
+        if (g + b >= pstart && g + b < pend) ob[g + b] = (u8)(v >> (8u * b));
+}
 __device__ __forceinline__ void inf_flush(const u8 *ring, u8 *__restrict__ ob, u32 g0, u32 pstart, u32 pend, u32 lane)
 {
     __syncthreads();
-    const u32 g = g0 + 4u * lane;
-    const u32 v = *reinterpret_cast<const u32 *>(ring + (g & (INF_RING - 1u)));
-    if (g >= pstart && g + 4u <= pend) {
-        *reinterpret_cast<u32 *>(ob + g) = v;
+    if (g0 >= pstart && g0 + 256u <= pend) {   // (uniform)
+        const u32 g = g0 + 4u * lane;
+        *reinterpret_cast<u32 *>(ob + g) = *reinterpret_cast<const u32 *>(ring + (g & (INF_RING - 1u)));
     } else {
-#pragma unroll
-        for (u32 b = 0; b < 4; b++)
-            if (g + b >= pstart && g + b < pend) ob[g + b] = (u8)(v >> (8u * b));
+        inf_flush_edge(ring, ob, g0, pstart, pend, lane);
     }
 }
 
 // Canonical Huffman tables from code lengths (RFC 1951 3.2.2), built by the whole wavefront: counts per length with LDS
 // atomics, then every lane places its symbols -- the rank of a symbol among those of its length is a ballot + popcount.
 template <u32 P>
-__device__ __forceinline__ bool inf_build(const u8 *lens, u32 n, u16 *T, u32 *cnt, u16 *syms, u32 lane)
+__device__ __forceinline__ bool inf_build(const u8 *lens, u32 n, u16 *T, u32 *cnt, u32 *fc, u32 *ix, u16 *syms, u32 lane)
 {
     for (u32 i = lane; i < (1u << P); i += 64u) T[i] = 0;
     if (lane < 16u) cnt[lane] = 0;
@@ -161,6 +171,8 @@ __device__ __forceinline__ bool inf_build(const u8 *lens, u32 n, u16 *T, u32 *cn
         const u32 c = RFL(cnt[L]);
         nc[L] = code;
         run[L] = idx;
+        fc[L] = code;   // (every lane the same word)
+        ix[L] = idx;
         code = (code + c) << 1;
         idx += c;
         left = (left << 1) - (int)c;
@@ -193,21 +205,19 @@ __device__ __forceinline__ bool inf_build(const u8 *lens, u32 n, u16 *T, u32 *cn
     return true;
 }
 
-// a code longer than the primary table: canonical decoding one bit at a time
-__device__ __forceinline__ bool inf_slow(u64 bb, const u32 *cnt, const u16 *syms, u32 &sym, u32 &len)
+// a code longer than the primary table: its first L bits, as a number, lie in [first code of length L, + codes of length L)
+// for its own length L and above that range for every shorter one (canonical codes)
+template <u32 P>
+__device__ __forceinline__ bool inf_slow(u64 bb, const u32 *cnt, const u32 *fc, const u32 *ix, const u16 *syms, u32 &sym, u32 &len)
 {
-    u32 code = 0, first = 0, index = 0;
-    for (u32 l = 1; l <= 15u; l++) {
-        code |= (u32)(bb >> (l - 1u)) & 1u;
-        const u32 c = RFL(cnt[l]);
-        if (code < first + c) {
-            sym = RFL(syms[index + (code - first)]);
-            len = l;
+    const u32 rb = __brev((u32)bb);
+    for (u32 L = P + 1u; L <= 15u; L++) {
+        const u32 off = (rb >> (32u - L)) - RFL(fc[L]);
+        if (off < RFL(cnt[L])) {
+            sym = RFL(syms[RFL(ix[L]) + off]);
+            len = L;
             return true;
         }
-        index += c;
-        first = (first + c) << 1;
-        code <<= 1;
     }
     return false;
 }
@@ -215,8 +225,7 @@ __device__ __forceinline__ bool inf_slow(u64 bb, const u32 *cnt, const u16 *syms
 __constant__ u8 INF_CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // (every lane stores the same word: an `if (lane == 0)` in front of a return makes the compiler treat everything that
-// reaches the function's single exit as divergent, and the whole decoder state moves to vector registers -- 388 exec-mask
-// tests instead of 141 in the kernel)
+// reaches the function's single exit as divergent, and the whole decoder state moves to vector registers)
 #define INF_FAIL(code)        \
     {                         \
         status[m] = (code);   \
@@ -224,10 +233,11 @@ __constant__ u8 INF_CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12,
     }
 
 // The decoder is bound by SCALAR instruction issue (one per cycle and CU, shared by every resident wavefront), not by
-// latency: what counts is the number of scalar instructions per output byte.  Hence: the input-limit test only where the
-// reader takes a dword, no output-limit test per literal (the ring takes the byte anyway, the flush stores nothing beyond
-// ISIZE, and the count is checked at every flush and at the end), 32-bit positions relative to the member's 256-byte
-// aligned start, literal bytes written by all lanes (same address, same value: no exec-mask handling).
+// latency: what counts is the number of scalar instructions per output byte.  Hence: no divergent branch in the symbol loop
+// (lanes beyond a match's end write to a dump slot; literal bytes are written by all lanes to one address), one exit from it
+// (errors leave through `err`), the input-limit test only where the reader takes a dword, no output-limit test per literal
+// (the ring takes the byte anyway, a flush stores nothing beyond ISIZE, and the count is checked at every flush and at the
+// end), 32-bit positions relative to the member's 256-byte aligned start.
 __global__ void __launch_bounds__(64)
 k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *__restrict__ mem, u32 nmem, u32 *__restrict__ status)
 {
@@ -240,23 +250,18 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
     const u32 clen = mem[m].clen, isize = mem[m].isize;
     u8 *__restrict__ ob = out + (gstart & ~255ull);
     const u32 pstart = (u32)(gstart & 255ull), pend = pstart + isize;   // positions relative to ob
-    u32 pos = pstart, flushed = 0;
+    u32 pos = pstart;   // (what lies below pos & ~255 has been stored)
     BitRd r;
     r.base = reinterpret_cast<const u32 *>(in + (in_off & ~3ull));
     r.lane = lane;
     const u32 skew = (u32)(in_off & 3ull);
     br_seek(r, skew);
     const u32 wlimit = (skew + clen + 3u) / 4u + 2u;   // dwords the reader may have taken (it looks ahead up to 8 bytes)
-#define INF_REFILL()                                           \
-    if (r.bc < 32u) {                                          \
-        br_refill(r);                                          \
+    constexpr u32 M = INF_RING - 1u;
+#define INF_REFILL()                                              \
+    if (r.bc < 32u) {                                             \
+        br_refill(r);                                             \
         if (r.ci * 64u + r.widx > wlimit) INF_FAIL(INF_ERR_INPUT) \
-    }
-#define INF_FLUSH_TO(p)                                           \
-    while (flushed + 256u <= (p)) {                               \
-        if (flushed + 256u > pend + 255u) INF_FAIL(INF_ERR_OUTPUT) \
-        inf_flush(S.ring, ob, flushed, pstart, pend, lane);       \
-        flushed += 256u;                                          \
     }
 
     for (;;) {
@@ -277,9 +282,10 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
             const u8 *ib = reinterpret_cast<const u8 *>(r.base);
             for (u32 k = 0; k < LEN; k += 64u) {
                 const u32 n = LEN - k < 64u ? LEN - k : 64u;
-                if (lane < n) S.ring[(pos + lane) & (INF_RING - 1u)] = ib[bp + k + lane];
+                if (lane < n) S.ring[(pos + lane) & M] = ib[bp + k + lane];
+                const u32 g = pos & ~255u;
                 pos += n;
-                INF_FLUSH_TO(pos)
+                if ((pos & ~255u) != g) inf_flush(S.ring, ob, g, pstart, pend, lane);
             }
             __syncthreads();
             br_seek(r, bp + LEN);
@@ -302,7 +308,7 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                     S.cl[INF_CL_ORDER[i]] = (u8)br_take(r, 3);
                 }
                 __syncthreads();
-                if (!inf_build<7>(S.cl, 19u, S.distT, S.cntD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
+                if (!inf_build<7>(S.cl, 19u, S.distT, S.cntD, S.fcD, S.ixD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
                 const u32 total = hlit + hdist;
                 u32 i = 0, prev = 0;
                 while (i < total) {
@@ -327,7 +333,7 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                             rep = 11u + br_take(r, 7);
                         }
                         if (i + rep > total) INF_FAIL(INF_ERR_TABLE)
-                        for (u32 j = lane; j < rep; j += 64u) S.lens[i + j] = (u8)val;
+                        for (u32 k = 0; k < rep; k += 64u) S.lens[k + lane < rep ? i + k + lane : 351u] = (u8)val;
                         i += rep;
                         prev = val;
                     }
@@ -335,51 +341,62 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                 __syncthreads();
                 if (RFL(S.lens[256]) == 0u) INF_FAIL(INF_ERR_TABLE)   // no end-of-block code
             }
-            if (!inf_build<INF_LP>(S.lens, hlit, S.litT, S.cntL, S.symL, lane)) INF_FAIL(INF_ERR_TABLE)
-            if (!inf_build<INF_DP>(S.lens + hlit, hdist, S.distT, S.cntD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
+            if (!inf_build<INF_LP>(S.lens, hlit, S.litT, S.cntL, S.fcL, S.ixL, S.symL, lane)) INF_FAIL(INF_ERR_TABLE)
+            if (!inf_build<INF_DP>(S.lens + hlit, hdist, S.distT, S.cntD, S.fcD, S.ixD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
 
+            u32 err = 0;
             for (;;) {
-                INF_REFILL()
-                u32 sym, l;
+                if (r.bc < 32u) {
+                    br_refill(r);
+                    if (r.ci * 64u + r.widx > wlimit) {
+                        err = INF_ERR_INPUT;
+                        break;
+                    }
+                }
                 const u32 e = RFL(S.litT[(u32)r.bb & ((1u << INF_LP) - 1u)]);
-                if (e) {
-                    sym = e & 511u;
-                    l = e >> 9;
-                } else if (!inf_slow(r.bb, S.cntL, S.symL, sym, l)) {
-                    INF_FAIL(INF_ERR_CODE)
+                u32 sym = e & 511u, l = e >> 9;
+                if (!e && !inf_slow<INF_LP>(r.bb, S.cntL, S.fcL, S.ixL, S.symL, sym, l)) {
+                    err = INF_ERR_CODE;
+                    break;
                 }
                 r.bb >>= l;
                 r.bc -= l;
                 if (sym < 256u) {
-                    S.ring[pos & (INF_RING - 1u)] = (u8)sym;
+                    S.ring[pos & M] = (u8)sym;
                     pos++;
-                    if ((pos & 255u) == 0u) INF_FLUSH_TO(pos)
+                    if ((pos & 255u) == 0u) {
+                        if (pos > pend + 255u) {
+                            err = INF_ERR_OUTPUT;
+                            break;
+                        }
+                        inf_flush(S.ring, ob, pos - 256u, pstart, pend, lane);
+                    }
                 } else if (sym == 256u) {
                     break;
                 } else {
                     sym -= 257u;
-                    if (sym > 28u) INF_FAIL(INF_ERR_DIST)
                     u32 len;
                     if (sym < 8u) {
                         len = 3u + sym;
-                    } else if (sym == 28u) {
+                    } else if (sym >= 28u) {
                         len = 258u;
+                        if (sym > 28u) {
+                            err = INF_ERR_DIST;
+                            break;
+                        }
                     } else {
                         const u32 eb = (sym >> 2) - 1u;
                         len = 3u + ((4u + (sym & 3u)) << eb) + br_take(r, eb);
                     }
-                    INF_REFILL()
-                    u32 ds, dl;
+                    if (r.bc < 32u) br_refill(r);   // (the input limit is tested at the next symbol)
                     const u32 de = RFL(S.distT[(u32)r.bb & ((1u << INF_DP) - 1u)]);
-                    if (de) {
-                        ds = de & 511u;
-                        dl = de >> 9;
-                    } else if (!inf_slow(r.bb, S.cntD, S.symD, ds, dl)) {
-                        INF_FAIL(INF_ERR_CODE)
+                    u32 ds = de & 511u, dl = de >> 9;
+                    if (!de && !inf_slow<INF_DP>(r.bb, S.cntD, S.fcD, S.ixD, S.symD, ds, dl)) {
+                        err = INF_ERR_CODE;
+                        break;
                     }
                     r.bb >>= dl;
                     r.bc -= dl;
-                    if (ds > 29u) INF_FAIL(INF_ERR_DIST)
                     u32 dist;
                     if (ds < 4u) {
                         dist = 1u + ds;
@@ -387,26 +404,37 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                         const u32 eb = (ds >> 1) - 1u;
                         dist = 1u + ((2u + (ds & 1u)) << eb) + br_take(r, eb);
                     }
-                    if (dist > pos - pstart) INF_FAIL(INF_ERR_DIST)
-                    if (pos + len > pend) INF_FAIL(INF_ERR_OUTPUT)
+                    if (ds > 29u || dist > pos - pstart) {
+                        err = INF_ERR_DIST;
+                        break;
+                    }
+                    if (pos + len > pend) {
+                        err = INF_ERR_OUTPUT;
+                        break;
+                    }
                     // the copy: lane i takes byte i of the match (a distance shorter than the match repeats with period dist);
                     // every source byte lies below pos, every destination at or above it
                     __syncthreads();
-                    if (dist <= INF_NEAR) {
-                        for (u32 i = lane; i < len; i += 64u) {
-                            const u32 j = dist >= len ? i : i % dist;
-                            S.ring[(pos + i) & (INF_RING - 1u)] = S.ring[(pos - dist + j) & (INF_RING - 1u)];
-                        }
-                    } else {
-                        // further back than the ring: from the member's output in HBM (flushed up to the last 256-byte boundary
-                        // by this wavefront's own, earlier stores; read past the first-level cache)
-                        const volatile u8 *src = ob + (pos - dist);
-                        for (u32 i = lane; i < len; i += 64u) S.ring[(pos + i) & (INF_RING - 1u)] = src[i];
+                    const bool wrap = dist < len, near = dist <= INF_NEAR;
+                    // (further back than the ring: from the member's output in HBM, flushed up to the last 256-byte boundary by
+                    // this wavefront's own, earlier stores; read past the first-level cache)
+                    const volatile u8 *src = ob + (pos - dist);
+                    for (u32 k = 0; k < len; k += 64u) {
+                        const u32 i = k + lane;
+                        const bool act = i < len;
+                        u32 j = i;
+                        if (wrap) j = i % dist;
+                        u32 byte;
+                        if (near) byte = S.ring[(pos - dist + j) & M];
+                        else byte = src[act ? i : 0u];
+                        S.ring[act ? ((pos + i) & M) : (INF_RING + lane)] = (u8)byte;
                     }
+                    const u32 g = pos & ~255u;
                     pos += len;
-                    INF_FLUSH_TO(pos)
+                    for (u32 gg = g; gg != (pos & ~255u); gg += 256u) inf_flush(S.ring, ob, gg, pstart, pend, lane);
                 }
             }
+            if (err) INF_FAIL(err)
         }
         if (bfinal) break;
     }
@@ -414,12 +442,8 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
     const u64 used_bits = (u64)(r.ci * 64u + r.widx) * 32u - r.bc - 8u * skew;
     if (used_bits > 8ull * clen) INF_FAIL(INF_ERR_INPUT)
     if (pos != pend) INF_FAIL(pos > pend ? INF_ERR_OUTPUT : INF_ERR_ISIZE)
-    while (flushed < pend) {
-        inf_flush(S.ring, ob, flushed, pstart, pend, lane);
-        flushed += 256u;
-    }
+    for (u32 g = pos & ~255u; g < pend; g += 256u) inf_flush(S.ring, ob, g, pstart, pend, lane);
 #undef INF_REFILL
-#undef INF_FLUSH_TO
 }
 
 // ---------------------------------------------------------------------------------------------------------------
