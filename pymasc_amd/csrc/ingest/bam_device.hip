@@ -69,8 +69,9 @@ enum {
 struct InfLds {
     u8 ring[INF_RING];
     u8 dump[64];                            // where the lanes beyond the end of a match write (no branch around the store)
-    u16 litT[1u << INF_LP];                 // entry: symbol | code length << 9; 0 = not a code of <= INF_LP bits
-    u16 distT[1u << INF_DP];
+    u16 litT[1u << INF_LP];                 // a literal: byte | code length << 8.  Anything else has bit 15 set: a length / end-of-block
+                                            // symbol as (symbol - 256) | code length << 8, or 0x8000 = no code of <= INF_LP bits
+    u16 distT[1u << INF_DP];                // entry: symbol | code length << 9; 0 = not a code of <= INF_DP bits
     u16 symL[320];                          // symbols in canonical order (the slow path for longer codes)
     u16 symD[32];
     u32 cntL[16], cntD[16];                 // codes per length
@@ -151,10 +152,10 @@ __device__ __forceinline__ void inf_flush(const u8 *ring, u8 *__restrict__ ob, u
 
 // Canonical Huffman tables from code lengths (RFC 1951 3.2.2), built by the whole wavefront: counts per length with LDS
 // atomics, then every lane places its symbols -- the rank of a symbol among those of its length is a ballot + popcount.
-template <u32 P>
+template <u32 P, bool LIT>
 __device__ __forceinline__ bool inf_build(const u8 *lens, u32 n, u16 *T, u32 *cnt, u32 *fc, u32 *ix, u16 *syms, u32 lane)
 {
-    for (u32 i = lane; i < (1u << P); i += 64u) T[i] = 0;
+    for (u32 i = lane; i < (1u << P); i += 64u) T[i] = LIT ? 0x8000 : 0;
     if (lane < 16u) cnt[lane] = 0;
     __syncthreads();
     for (u32 s = lane; s < n; s += 64u) {
@@ -192,7 +193,8 @@ __device__ __forceinline__ bool inf_build(const u8 *lens, u32 n, u16 *T, u32 *cn
                     syms[run[L] + rk] = (u16)s;
                     if (L <= P) {
                         const u32 rev = __brev(nc[L] + rk) >> (32u - L);
-                        for (u32 k = rev; k < (1u << P); k += (1u << L)) T[k] = (u16)(s | (L << 9));
+                        const u32 ent = !LIT ? (s | (L << 9)) : s < 256u ? (s | (L << 8)) : (0x8000u | (s - 256u) | (L << 8));
+                        for (u32 k = rev; k < (1u << P); k += (1u << L)) T[k] = (u16)ent;
                     }
                 }
                 const u32 pc = (u32)__popcll(m);
@@ -308,7 +310,7 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                     S.cl[INF_CL_ORDER[i]] = (u8)br_take(r, 3);
                 }
                 __syncthreads();
-                if (!inf_build<7>(S.cl, 19u, S.distT, S.cntD, S.fcD, S.ixD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
+                if (!inf_build<7, false>(S.cl, 19u, S.distT, S.cntD, S.fcD, S.ixD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
                 const u32 total = hlit + hdist;
                 u32 i = 0, prev = 0;
                 while (i < total) {
@@ -341,10 +343,13 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                 __syncthreads();
                 if (RFL(S.lens[256]) == 0u) INF_FAIL(INF_ERR_TABLE)   // no end-of-block code
             }
-            if (!inf_build<INF_LP>(S.lens, hlit, S.litT, S.cntL, S.fcL, S.ixL, S.symL, lane)) INF_FAIL(INF_ERR_TABLE)
-            if (!inf_build<INF_DP>(S.lens + hlit, hdist, S.distT, S.cntD, S.fcD, S.ixD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
+            if (!inf_build<INF_LP, true>(S.lens, hlit, S.litT, S.cntL, S.fcL, S.ixL, S.symL, lane)) INF_FAIL(INF_ERR_TABLE)
+            if (!inf_build<INF_DP, false>(S.lens + hlit, hdist, S.distT, S.cntD, S.fcD, S.ixD, S.symD, lane)) INF_FAIL(INF_ERR_TABLE)
 
             u32 err = 0;
+            // (the ring addresses are formed on the vector unit, from a copy of pos the compiler takes for a per-lane value)
+            u32 vpos = pos;
+            asm volatile("" : "+v"(vpos));
             for (;;) {
                 if (r.bc < 32u) {
                     br_refill(r);
@@ -353,19 +358,47 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                         break;
                     }
                 }
-                const u32 e = RFL(S.litT[(u32)r.bb & ((1u << INF_LP) - 1u)]);
-                u32 sym = e & 511u, l = e >> 9;
-                if (!e && !inf_slow<INF_LP>(r.bb, S.cntL, S.fcL, S.ixL, S.symL, sym, l)) {
+                // A run of literals, as tight as the compiler makes it: every instruction of a wavefront's stream costs the same,
+                // whatever its type, and literals are most of a BAM file's symbols.  The byte goes to the ring straight from the
+                // register the lookup filled; the run ends at a symbol that is not a plain literal or when fewer than 15 bits are
+                // buffered (the lookups never see more than 15) -- at most 48 literals, so the 256-byte groups the run completed
+                // are stored behind it (the ring holds 4096 bytes).
+                const u32 g0 = pos & ~255u;
+                u32 e;
+                for (;;) {
+                    const u32 ev = S.litT[(u32)r.bb & ((1u << INF_LP) - 1u)];   // (the same word in every lane)
+                    e = RFL(ev);
+                    if (e & 0x8000u) break;
+                    S.ring[vpos & M] = (u8)ev;
+                    vpos++;
+                    pos++;
+                    const u32 l = e >> 8;
+                    r.bb >>= l;
+                    r.bc -= l;
+                    if (r.bc < 15u) break;
+                }
+                if ((pos & ~255u) != g0) {   // (one group at most)
+                    if (g0 >= pend) {
+                        err = INF_ERR_OUTPUT;
+                        break;
+                    }
+                    inf_flush(S.ring, ob, g0, pstart, pend, lane);
+                }
+                if (!(e & 0x8000u)) continue;   // out of bits: the next round refills
+                u32 sym = 256u + (e & 31u), l = (e >> 8) & 15u;
+                if (!l && !inf_slow<INF_LP>(r.bb, S.cntL, S.fcL, S.ixL, S.symL, sym, l)) {
                     err = INF_ERR_CODE;
                     break;
                 }
                 r.bb >>= l;
                 r.bc -= l;
-                if (sym < 256u) {
-                    S.ring[pos & M] = (u8)sym;
+                if (r.bc < 32u) br_refill(r);   // (the input limit is tested at the next symbol)
+                if (sym < 256u) {               // a literal whose code is longer than the table's index
+                    S.ring[vpos & M] = (u8)sym;
+                    vpos++;
                     pos++;
                     if ((pos & 255u) == 0u) {
-                        if (pos > pend + 255u) {
+                        if (pos - 256u >= pend) {
                             err = INF_ERR_OUTPUT;
                             break;
                         }
@@ -388,7 +421,7 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                         const u32 eb = (sym >> 2) - 1u;
                         len = 3u + ((4u + (sym & 3u)) << eb) + br_take(r, eb);
                     }
-                    if (r.bc < 32u) br_refill(r);   // (the input limit is tested at the next symbol)
+                    if (r.bc < 32u) br_refill(r);
                     const u32 de = RFL(S.distT[(u32)r.bb & ((1u << INF_DP) - 1u)]);
                     u32 ds = de & 511u, dl = de >> 9;
                     if (!de && !inf_slow<INF_DP>(r.bb, S.cntD, S.fcD, S.ixD, S.symD, ds, dl)) {
@@ -431,6 +464,7 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                     }
                     const u32 g = pos & ~255u;
                     pos += len;
+                    vpos += len;
                     for (u32 gg = g; gg != (pos & ~255u); gg += 256u) inf_flush(S.ring, ob, gg, pstart, pend, lane);
                 }
             }
