@@ -186,6 +186,13 @@ int pmx_feed_reads_ex(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits
 int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const uint16_t *h_words, uint64_t n,
                            const uint32_t *h_seg_start, const int32_t *h_seg_base, uint32_t nseg, const void *h_readlen,
                            uint32_t len_bytes, uint64_t reads_before, uint64_t *d_state, uint32_t flags);
+/* The same run of reads already IN DEVICE MEMORY (round 4: libpymasc_ingest.so inflates and decodes a BAM file on the GPU,
+ * include/pymasc_amd_ingest.h, and its kept records never visit the host): int32 1-based positions, int32 query lengths,
+ * uint8 strand.  The arrays must be complete when the call is made (the producer has synchronised its stream) and stay
+ * untouched until the next synchronising call on this context.  Same rules, same state words as pmx_feed_reads
+ * (mscc.pyx:370-418); flags: PMX_FEED_WHOLE_VECTORS or 0.  Asynchronous. */
+int pmx_feed_reads_dev(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const int32_t *d_pos, const int32_t *d_readlen,
+                       const uint8_t *d_is_reverse, uint64_t n, uint64_t reads_before, uint64_t *d_state, uint32_t flags);
 /* _load_mappability's loop (mscc.pyx:343-344): set(h_first[i] + first_offset, h_last[i]) for n intervals, ends inclusive
  * (BigWig (begin, end) pairs: first_offset = 1).  width_bytes: 4 (uint32) or 8 (int64).  An interval outside [0, nbits) is
  * clipped and recorded in d_state[PMX_FEED_FIRST_OUT_OF_RANGE] (d_state may be NULL).  Asynchronous. */

@@ -68,6 +68,13 @@ int pmx_dbam_device_arrays(const pmx_dbam *b, const int32_t **d_ref_id, const in
 /* ... and copied to host arrays: records [first, first + n). */
 int pmx_dbam_fetch(pmx_dbam *b, int64_t first, int64_t n, int32_t *ref_id, int32_t *pos1, int32_t *read_len, uint8_t *reverse);
 
+/* The kept records as RUNS of one reference each, in file order (a coordinate-sorted file: one run per chromosome):
+ * start[r] = index of the run's first record in the arrays above, ref_id[r], and the positions of its first and last record
+ * (what the calculator's order check needs on the host; everything inside a run is checked by the device feeders).
+ * Two-call protocol: with start == NULL returns the number of runs, else fills up to cap entries and returns the number
+ * written.  More than 65536 runs (an unsorted file): PMX_DBAM_ERR_INVALID -- take the arrays through pmx_dbam_fetch then. */
+int64_t pmx_dbam_runs(pmx_dbam *b, int64_t cap, int64_t *start, int32_t *ref_id, int32_t *first_pos1, int32_t *last_pos1);
+
 /* Counters: alignment records walked and records kept by the last decode, uncompressed / compressed bytes of the file,
  * BGZF members, and how many 16-KB pieces had to be walked again because their guessed first record was wrong. */
 int pmx_dbam_counters(const pmx_dbam *b, uint64_t *records, uint64_t *kept, uint64_t *bytes_out, uint64_t *bytes_in,

@@ -23,7 +23,7 @@ _LIB_NAME = "libpymasc_ingest.so"
 INGEST_EXPORTS = [
     "pmx_dbam_last_error", "pmx_dbam_version", "pmx_dbam_open", "pmx_dbam_close", "pmx_dbam_nref", "pmx_dbam_ref_name",
     "pmx_dbam_ref_len", "pmx_dbam_header_text", "pmx_dbam_decode", "pmx_dbam_device_arrays", "pmx_dbam_fetch",
-    "pmx_dbam_counters", "pmx_dbam_timings", "pmx_dbam_inflated",
+    "pmx_dbam_runs", "pmx_dbam_counters", "pmx_dbam_timings", "pmx_dbam_inflated",
 ]
 
 _lib = None
@@ -63,6 +63,8 @@ def load_ingest_library():
     L.pmx_dbam_device_arrays.restype = ctypes.c_int
     L.pmx_dbam_fetch.argtypes = [vp, i64, i64, vp, vp, vp, vp]
     L.pmx_dbam_fetch.restype = ctypes.c_int
+    L.pmx_dbam_runs.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.pmx_dbam_runs.restype = i64
     L.pmx_dbam_counters.argtypes = [vp] + [ctypes.POINTER(u64)] * 6
     L.pmx_dbam_counters.restype = ctypes.c_int
     L.pmx_dbam_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
@@ -165,6 +167,52 @@ class DeviceBamReader:
         if rc:
             _raise(rc)
         return tuple(int(x.value or 0) for x in v)
+
+    def device_runs(self):
+        """The kept records of the last decode as runs of one reference, in file order: a list of
+        (ref_id, start index, count, first pos, last pos) -- None when the file has more than 65536 runs (unsorted)."""
+        n = self._L.pmx_dbam_runs(self._h, 0, None, None, None, None)
+        if n == -3:
+            return None
+        if n < 0:
+            _raise(n)
+        start = np.empty(max(n, 1), dtype=np.int64)
+        ref = np.empty(max(n, 1), dtype=np.int32)
+        first = np.empty(max(n, 1), dtype=np.int32)
+        last = np.empty(max(n, 1), dtype=np.int32)
+        m = self._L.pmx_dbam_runs(self._h, n, start.ctypes.data, ref.ctypes.data, first.ctypes.data, last.ctypes.data)
+        if m < 0:
+            _raise(m)
+        total = self.counters()["kept"]
+        ends = list(start[1:m]) + [total]
+        return [(int(ref[r]), int(start[r]), int(ends[r] - start[r]), int(first[r]), int(last[r])) for r in range(m)]
+
+    def feed(self, calculator, mapq_criteria: int, references=None, finish: bool = True) -> int:
+        """handler/calc.py:131-161 with nothing on the host: decode + filter on the device, then every run of one chromosome is
+        handed to ``calculator.feed_reads_device`` as three device addresses (the same duplicate / order rules, mscc.pyx:351-418,
+        applied by the device feeders).  Falls back to ``pymasc_amd.bam.feed_bam`` (host arrays) for an unsorted file or a
+        calculator without the device entry point.  Returns the number of reads fed."""
+        from .bam import feed_bam
+        wanted = set(calculator.references if references is None else references)
+        if not hasattr(calculator, "feed_reads_device"):
+            return feed_bam(calculator, self, mapq_criteria, references, finish, use_index=False)
+        self.decode(mapq_criteria)
+        runs = self.device_runs()
+        if runs is None:
+            return feed_bam(calculator, self, mapq_criteria, references, finish, use_index=False)
+        d_ref, d_pos, d_len, d_rev = self.device_arrays()
+        fed = 0
+        for ref, start, count, first, last in runs:
+            name = self.references[ref]
+            if name not in wanted:
+                continue
+            calculator.feed_reads_device(name, d_pos + 4 * start, d_len + 4 * start, d_rev + start, count, first, last)
+            fed += count
+        if finish:
+            calculator.finishup_calculation()
+        else:
+            calculator._ctx.sync()      # the feeders read this reader's arrays: they must be done before it may be closed
+        return fed
 
     def _fetch(self, first: int, n: int):
         ref = np.empty(n, dtype=np.int32)

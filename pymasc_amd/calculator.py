@@ -368,6 +368,23 @@ class CCHipCalculator:
         last = int(pos[-1]) & top if packed else int(pos[-1])
         self._last_pos = max(self._last_pos, last)
 
+    def feed_reads_device(self, chrom: str, d_pos: int, d_readlen: int, d_is_reverse: int, n: int, first_pos: int, last_pos: int) -> None:
+        """feed_reads for a run of one chromosome that lies in DEVICE memory (addresses of int32 positions, int32 query lengths,
+        uint8 strands; `first_pos` / `last_pos`: the positions of its first and last read, for the order check against what was
+        fed before -- everything inside the run is checked by the device, as in feed_reads).  The producer is
+        pymasc_amd.bam_device.DeviceBamReader: a BAM file inflated, decoded and filtered on the GPU never visits the host.
+        The arrays must stay as they are until the results of the chromosome have been fetched."""
+        if n == 0:
+            return
+        self._check_pos(chrom, int(first_pos))
+        if self._buf.n:
+            self._to_device(*self._buf.take())
+        fresh = self._start_chromosome_on_device(clear=False)
+        self._ctx.feed_reads_dev(self._d_f, self._d_r, self._cur_nbits, d_pos, d_readlen, d_is_reverse, n, self._fed,
+                                 self._state_ptr(self._cur_slot), whole_vectors=fresh)
+        self._fed += int(n)
+        self._last_pos = max(self._last_pos, int(last_pos))
+
     # ---- per-chromosome calculation ---------------------------------------------------------------
     def _load_mappability(self, chrom: str, nbits: int, slot: int):
         """mscc.pyx:327-349 -> (device vector, pool capacity), queued, not waited for; None without a feeder; KeyError if

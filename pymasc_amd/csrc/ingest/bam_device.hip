@@ -791,6 +791,32 @@ __global__ void __launch_bounds__(1024) k_bam_scan(const u32 *__restrict__ kept,
     }
 }
 
+// runs of one reference among the kept records: one entry per place where the reference id changes
+struct RunEntry {
+    unsigned long long start;
+    int ref, first_pos, prev_pos, pad;
+};
+#define RUNS_MAX 65536u
+__global__ void __launch_bounds__(256) k_ref_runs(const int *__restrict__ ref, const int *__restrict__ pos, u64 n, RunEntry *__restrict__ runs,
+                                                 u32 *__restrict__ nruns)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int r = ref[i];
+    if (i == 0 || ref[i - 1] != r) {
+        const u32 slot = atomicAdd(nruns, 1u);
+        if (slot < RUNS_MAX) {
+            RunEntry e;
+            e.start = i;
+            e.ref = r;
+            e.first_pos = pos[i];
+            e.prev_pos = i ? pos[i - 1] : 0;
+            e.pad = 0;
+            runs[slot] = e;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 namespace {
@@ -1405,6 +1431,44 @@ int pmx_dbam_fetch(pmx_dbam *b, int64_t first, int64_t n, int32_t *ref_id, int32
     if (reverse) HIPOK(hipMemcpyAsync(reverse, b->d_rev + first, (size_t)n, hipMemcpyDeviceToHost, b->stream));
     HIPOK(hipStreamSynchronize(b->stream));
     return 0;
+}
+
+int64_t pmx_dbam_runs(pmx_dbam *b, int64_t cap, int64_t *start, int32_t *ref_id, int32_t *first_pos1, int32_t *last_pos1)
+{
+    if (!b) return fail(PMX_DBAM_ERR_INVALID, "null handle");
+    if (b->n_kept == 0) return 0;
+    HIPOK(hipSetDevice(b->device));
+    RunEntry *d_runs = nullptr;
+    u32 *d_n = nullptr;
+    HIPOK(hipMalloc((void **)&d_runs, sizeof(RunEntry) * RUNS_MAX));
+    HIPOK(hipMalloc((void **)&d_n, 4));
+    HIPOK(hipMemsetAsync(d_n, 0, 4, b->stream));
+    hipLaunchKernelGGL(k_ref_runs, dim3((unsigned)((b->n_kept + 255) / 256)), dim3(256), 0, b->stream, b->d_ref, b->d_pos, b->n_kept, d_runs, d_n);
+    u32 n = 0;
+    int last = 0;
+    std::vector<RunEntry> runs;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&last, b->d_pos + (b->n_kept - 1), 4, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e == hipSuccess && n <= RUNS_MAX) {
+        runs.resize(n);
+        e = hipMemcpy(runs.data(), d_runs, sizeof(RunEntry) * n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_runs);
+    (void)hipFree(d_n);
+    if (e != hipSuccess) return fail(PMX_DBAM_ERR_DEVICE, std::string("pmx_dbam_runs: ") + hipGetErrorString(e));
+    if (n > RUNS_MAX) return fail(PMX_DBAM_ERR_INVALID, "more than 65536 runs of one reference (unsorted file): use pmx_dbam_fetch");
+    if (!start) return (int64_t)n;
+    std::sort(runs.begin(), runs.end(), [](const RunEntry &x, const RunEntry &y) { return x.start < y.start; });
+    const int64_t m = std::min<int64_t>(cap, (int64_t)n);
+    for (int64_t r = 0; r < m; r++) {
+        start[r] = (int64_t)runs[(size_t)r].start;
+        if (ref_id) ref_id[r] = runs[(size_t)r].ref;
+        if (first_pos1) first_pos1[r] = runs[(size_t)r].first_pos;
+        if (last_pos1) last_pos1[r] = (size_t)r + 1 < runs.size() ? runs[(size_t)r + 1].prev_pos : last;
+    }
+    return m;
 }
 
 int pmx_dbam_counters(const pmx_dbam *b, uint64_t *records, uint64_t *kept, uint64_t *bytes_out, uint64_t *bytes_in,

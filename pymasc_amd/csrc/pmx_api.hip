@@ -960,6 +960,36 @@ int pmx_feed_reads_ex(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits
     return feed_release(ctx, slot);
 }
 
+int pmx_feed_reads_dev(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const int32_t *d_pos, const int32_t *d_readlen,
+                       const uint8_t *d_is_reverse, uint64_t n, uint64_t reads_before, uint64_t *d_state, uint32_t flags)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    const bool whole = (flags & PMX_FEED_WHOLE_VECTORS) != 0;
+    REQUIRE(!whole || reads_before == 0, "pmx_feed_reads_dev: PMX_FEED_WHOLE_VECTORS is for the first run of a chromosome (reads_before = 0)");
+    if (whole && n == 0) {
+        REQUIRE(ctx && d_F && d_R, "pmx_feed_reads_dev: NULL argument");
+        PMX_HIP(hipMemsetAsync(d_F, 0, words_for(nbits) * sizeof(uint64_t), ctx->stream));
+        PMX_HIP(hipMemsetAsync(d_R, 0, words_for(nbits) * sizeof(uint64_t), ctx->stream));
+        return PMX_OK;
+    }
+    REQUIRE(ctx && d_F && d_R && d_state, "pmx_feed_reads_dev: NULL argument");
+    REQUIRE(n == 0 || (d_pos && d_readlen && d_is_reverse), "pmx_feed_reads_dev: NULL read arrays");
+    REQUIRE(nbits >= 1 && nbits < (1ull << 40), "pmx_feed_reads_dev: nbits must be in [1, 2^40)");
+    if (n == 0) return PMX_OK;
+    // nothing to copy: the staging slot only holds the per-workgroup sums of the whole-vector builder
+    unsigned char *d = nullptr;
+    uint32_t slot = 0;
+    int rc = PMX_OK;
+    if (whole) {
+        rc = feed_acquire(ctx, (size_t)pmx_feed_build_blocks(nbits) * 64, &d, &slot);
+        if (rc) return rc;
+    }
+    rc = pmx_launch_feed_reads(ctx, d_F, d_R, nbits, d_pos, 4, d_readlen, 4, 0, d_is_reverse, n, reads_before, d_state,
+                               whole ? (uint64_t *)d : nullptr);
+    if (rc) return rc;
+    return whole ? feed_release(ctx, slot) : PMX_OK;
+}
+
 int pmx_feed_reads_delta16(pmx_ctx *ctx, uint64_t *d_F, uint64_t *d_R, uint64_t nbits, const uint16_t *h_words, uint64_t n,
                            const uint32_t *h_seg_start, const int32_t *h_seg_base, uint32_t nseg, const void *h_readlen,
                            uint32_t len_bytes, uint64_t reads_before, uint64_t *d_state, uint32_t flags)

@@ -57,7 +57,7 @@ EXPORTS = [
     "pmx_bits_alloc", "pmx_bits_free", "pmx_bits_clear", "pmx_bits_upload", "pmx_bits_download",
     "pmx_bits_set_positions", "pmx_bits_set_positions_dev", "pmx_bits_set_regions", "pmx_bits_set_regions_dev",
     "pmx_bits_count",
-    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_ex", "pmx_feed_reads_delta16", "pmx_bits_set_regions_async", "pmx_bits_set_regions_ex", "pmx_bits_build_batch",
+    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_ex", "pmx_feed_reads_delta16", "pmx_feed_reads_dev", "pmx_bits_set_regions_async", "pmx_bits_set_regions_ex", "pmx_bits_build_batch",
     "pmx_bits_build_status",
     "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_cc_batch_ranges_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
     "pmx_mappable_len_batch_dev",
@@ -109,6 +109,7 @@ def load_library(path: Optional[str] = None):
     L.pmx_feed_reads.argtypes = [vp, vp, vp, u64, vp, u32, vp, u32, vp, u64, u64, vp]
     L.pmx_feed_reads_delta16.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp, u32, vp, u32, u64, vp, u32]
     L.pmx_feed_reads_ex.argtypes = [vp, vp, vp, u64, vp, u32, vp, u32, vp, u64, u64, vp, u32]
+    L.pmx_feed_reads_dev.argtypes = [vp, vp, vp, u64, vp, vp, vp, u64, u64, vp, u32]
     L.pmx_bits_set_regions_async.argtypes = [vp, vp, u64, vp, vp, u32, u64, ctypes.c_int64, vp]
     L.pmx_bits_set_regions_ex.argtypes = [vp, vp, u64, vp, vp, u32, u64, ctypes.c_int64, vp, u32]
     L.pmx_bits_build_batch.argtypes = [vp, u32, vp, u32]
@@ -403,6 +404,14 @@ class Context:
                                                        readlen.ctypes.data, len_bytes, int(reads_before), ctypes.c_void_p(d_state),
                                                        PMX_FEED_WHOLE_VECTORS if whole_vectors else 0))
         return words, seg_start, seg_base, readlen
+
+    def feed_reads_dev(self, d_F: int, d_R: int, nbits: int, d_pos: int, d_readlen: int, d_is_reverse: int, n: int,
+                       reads_before: int, d_state: int, whole_vectors: bool = False):
+        """pmx_feed_reads_dev: a run of reads that is already in device memory (int32 positions, int32 lengths, uint8 strand:
+        what pymasc_amd.bam_device.DeviceBamReader leaves in HBM).  The arrays must stay untouched until the next synchronising call."""
+        _check(self._L, self._L.pmx_feed_reads_dev(self._h, ctypes.c_void_p(d_F), ctypes.c_void_p(d_R), int(nbits), ctypes.c_void_p(d_pos),
+                                                   ctypes.c_void_p(d_readlen), ctypes.c_void_p(d_is_reverse), int(n), int(reads_before),
+                                                   ctypes.c_void_p(d_state), PMX_FEED_WHOLE_VECTORS if whole_vectors else 0))
 
     def feed_reads(self, d_F: int, d_R: int, nbits: int, pos: np.ndarray, readlen: np.ndarray, is_reverse: np.ndarray,
                    reads_before: int, d_state: int, whole_vectors: bool = False):

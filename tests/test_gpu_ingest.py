@@ -263,17 +263,25 @@ def test_corrupt_input_is_reported(tmp_path):
 def test_files_to_tables_through_the_device_reader(tmp_path):
     """The reference's golden run (-d 300 -q 10 -r 36 -m bigwig) with the BAM inflated and decoded on the GPU: pymasc_amd.bam.feed_bam
     takes the device reader as it takes the host reader, and the output tables equal the reference's."""
-    import csv
-    from pymasc_amd import tables as T
     from pymasc_amd.bigwig import BigWigReader
     from pymasc_amd.calculator import CCHipCalculator
     from .test_io_readers import BIGWIG
-    with D.DeviceBamReader(BAM) as bam, BigWigReader(BIGWIG) as bw:
-        calc = CCHipCalculator(300, 36, bam.references, bam.lengths, bwfeeder=bw)
-        assert B.feed_bam(calc, bam, mapq_criteria=10) == 1292
-        whole = calc.get_whole_result()
-        calc.close()
-        names = bam.references
+    for device_feed in (False, True):
+        with D.DeviceBamReader(BAM) as bam, BigWigReader(BIGWIG) as bw:
+            calc = CCHipCalculator(300, 36, bam.references, bam.lengths, bwfeeder=bw)
+            # feed_bam: the kept records come back as host arrays; reader.feed: they stay in HBM (pmx_feed_reads_dev)
+            fed = bam.feed(calc, 10) if device_feed else B.feed_bam(calc, bam, mapq_criteria=10)
+            assert fed == 1292
+            whole = calc.get_whole_result()
+            calc.close()
+            names = bam.references
+        _check_tables(tmp_path / ("d%d" % device_feed), whole, names)
+
+
+def _check_tables(tmp_path, whole, names):
+    import csv
+    from pymasc_amd import tables as T
+    os.makedirs(tmp_path, exist_ok=True)
     for p in T.write_tables(tmp_path / "ENCFF000RMB-test.bam", whole, references=names):
         gold = os.path.join(fx.GOLDEN, p.name)
         if p.name.endswith("_nreads.tab"):
@@ -284,3 +292,31 @@ def test_files_to_tables_through_the_device_reader(tmp_path):
             assert g[0] == o[0] and len(g) == len(o)
             np.testing.assert_almost_equal(np.array([r[1:] for r in o[1:]], dtype=float),
                                            np.array([r[1:] for r in g[1:]], dtype=float), decimal=15)
+
+
+def test_device_feed_equals_host_feed(tmp_path):
+    """Several chromosomes (one of them left out by the caller), duplicates at one position, mixed read lengths: the rows after
+    DeviceBamReader.feed (records never leave HBM) equal the rows after feed_bam over the host reader, integer for integer."""
+    from pymasc_amd.calculator import CCHipCalculator
+    rng = np.random.default_rng(21)
+    refs = [("c1", 300000), ("c2", 150000), ("skipme", 50000), ("c4", 90000)]
+    recs, _meta = W.synth_bam_records(rng, refs, 4000)
+    recs += [W.bam_record(3, 89963, 30, 0, [("M", 36)])] * 3 + [W.bam_record(3, 89963, 30, 16, [("M", 36)]), W.bam_record(3, 89963, 30, 16, [("M", 30)])]
+    path = tmp_path / "f.bam"
+    W.write_bam(path, refs, recs, level=1)
+    want = ["c1", "c2", "c4"]
+    lens = {n: l for n, l in refs}
+    out = []
+    for dev in (False, True):
+        calc = CCHipCalculator(200, 36, want, [lens[n] for n in want])
+        if dev:
+            with D.DeviceBamReader(path) as r:
+                fed = r.feed(calc, 5, references=want)
+        else:
+            with B.BamReader(path, index=False) as r:
+                fed = B.feed_bam(calc, r, 5, references=want)
+        res = {n: calc.get_result(n) for n in want}
+        out.append((fed, {n: (int(v.chrom.forward_sum), int(v.chrom.reverse_sum), np.asarray(v.chrom.ccbins).tolist(),
+                              int(v.chrom.forward_read_len_sum), int(v.chrom.reverse_read_len_sum)) for n, v in res.items()}))
+        calc.close()
+    assert out[0] == out[1] and out[0][0] > 8000

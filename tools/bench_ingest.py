@@ -182,6 +182,20 @@ def main():
                              "forward_sum": int(whole.forward_sum), "reverse_sum": int(whole.reverse_sum)}
         calc.close()
         print(json.dumps(res["end_to_end"]), flush=True)
+        if a.device:      # the same file, inflated + decoded + filtered on the GPU, records handed to the feeders in HBM
+            from pymasc_amd import bam_device as D
+            res["end_to_end_device"] = []
+            for rep in range(3):
+                calc = CCHipCalculator(1000, 36, [n for n, _ in refs], [l for _, l in refs])
+                t0 = time.time()
+                with D.DeviceBamReader(a.path) as r:
+                    fed2 = r.feed(calc, a.mapq)
+                dt2 = time.time() - t0
+                w2 = calc.get_whole_result()
+                assert (fed2, int(w2.forward_sum), int(w2.reverse_sum)) == (fed, int(whole.forward_sum), int(whole.reverse_sum))
+                calc.close()
+                res["end_to_end_device"].append({"seconds": round(dt2, 3), "reads_fed": fed2, "reads_per_s": round(fed2 / dt2)})
+                print(json.dumps(res["end_to_end_device"][-1]), flush=True)
     if a.out:
         with open(a.out, "w") as fp:
             json.dump(res, fp, indent=1)
