@@ -19,10 +19,12 @@ from .sharding import run_sharded
 
 def run(bam_path, outdir, max_shift: int, read_len: int, mapq_criteria: int = 1, mappability_path=None,
         mappability_stats_path=None, skip_ncc: bool = False, references: Optional[Sequence[str]] = None,
-        device: Optional[int] = None, save_mappability_stats: bool = True, group=None, context=None):
+        device: Optional[int] = None, save_mappability_stats: bool = True, group=None, context=None,
+        device_ingest: Optional[bool] = None):
     """Returns (genome-wide result, [paths written]).  ``outdir/<bam stem>_{cc,mscc,nreads}.tab`` are written by
     rank 0 (every rank holds the result).  ``context``: an existing pymasc_amd.ffi.Context to run on (default: one per
-    call on ``device``)."""
+    call on ``device``).  ``device_ingest``: see sharding.run_sharded (default: the BAM file is inflated and decoded on the GPU
+    when there is one rank on a real GPU)."""
     import torch.distributed as dist
     on = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if on else 0
@@ -63,7 +65,7 @@ def run(bam_path, outdir, max_shift: int, read_len: int, mapq_criteria: int = 1,
         known = box[0]
     result = run_sharded(bam_path, max_shift, read_len, mapq_criteria, bigwig_path=mappability_path,
                          references=references, skip_ncc=skip_ncc, device=device, chrom2mappable_len=known,
-                         group=group, context=context)
+                         group=group, context=context, device_ingest=device_ingest)
     written: List[Path] = []
     if rank == 0:
         out = Path(outdir)

@@ -11,7 +11,7 @@ xGMI on the GPU box; the same code runs on "gloo" with CPU tensors in the tests.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple  # noqa: F401
+from typing import Dict, List, Optional, Sequence, Tuple  # noqa: F401
 
 import torch
 import torch.distributed as dist
@@ -179,7 +179,7 @@ def reconcile_chromosome_sizes(bam_sizes: Dict[str, int], external_sizes: Dict[s
 
 def run_sharded(bam_path, max_shift: int, read_len: int, mapq_criteria: int, bigwig_path=None,
                 references: Sequence[str] = None, skip_ncc: bool = False, device: int = None, context=None,
-                chrom2mappable_len=None, group=None):
+                chrom2mappable_len=None, group=None, device_ingest: Optional[bool] = None):
     """BAM (+ BigWig) -> genome-wide result on every rank; chromosomes LPT-sharded over the ranks by length.
 
     Launch: one process per GPU under ``torch.distributed`` (torchrun, or pymasc_amd.launch.spawn_ranks), the process
@@ -188,7 +188,10 @@ def run_sharded(bam_path, max_shift: int, read_len: int, mapq_criteria: int, big
     its multi-process mode, reader/bam.py:246-262), otherwise it streams the whole BAM through the native reader
     (~30 M records/s on 16 host threads) and keeps its share; the kernels see only the rank's chromosomes; one object
     all-gather at the end, then the reference's aggregation (result.py:301-464 -> pymasc_amd.result.aggregate_results).
-    A rank that fails reports through that same all-gather, so every rank raises instead of hanging."""
+    A rank that fails reports through that same all-gather, so every rank raises instead of hanging.
+    ``device_ingest``: inflate, walk and filter the BAM file on the GPU and hand the records to the feeders in HBM
+    (pymasc_amd.bam_device) -- default: when this is the only rank and it runs on a real GPU; with several
+    ranks each takes its own chromosomes through the host reader and the .bai instead of inflating the whole file N times."""
     from .bam import BamReader, feed_bam
     from .bigwig import BigWigReader
     from .calculator import CCHipCalculator
@@ -204,8 +207,25 @@ def run_sharded(bam_path, max_shift: int, read_len: int, mapq_criteria: int, big
     local: Dict[str, object] = {}
     names: List[str] = []
     error = None
+    if device_ingest is None:
+        from . import ffi
+        device_ingest = world == 1 and (context is None or isinstance(context, ffi.Context)) and ffi.device_count() > 0
+    if device_ingest:
+        from .bam_device import DeviceBamReader
+
+        def open_bam():
+            return DeviceBamReader(bam_path, device=(context.device if context is not None else (device or 0)))
+
+        def feed(calc, bam, mine):
+            return bam.feed(calc, mapq_criteria, references=mine)
+    else:
+        def open_bam():
+            return BamReader(bam_path)
+
+        def feed(calc, bam, mine):
+            return feed_bam(calc, bam, mapq_criteria, references=mine)
     try:
-        with BamReader(bam_path) as bam:
+        with open_bam() as bam:
             names = [n for n in bam.references if references is None or n in set(references)]
             lengths = dict(zip(bam.references, bam.lengths))
             bw = BigWigReader(bigwig_path) if bigwig_path is not None else None
@@ -222,7 +242,7 @@ def run_sharded(bam_path, max_shift: int, read_len: int, mapq_criteria: int, big
                     calc = CCHipCalculator(max_shift, read_len, mine, [lengths[n] for n in mine], bwfeeder=bw,
                                            skip_ncc=skip_ncc, chrom2mappable_len=chrom2mappable_len, **kw)
                     try:
-                        feed_bam(calc, bam, mapq_criteria, references=mine)
+                        feed(calc, bam, mine)
                         local = {c: calc.get_result(c) for c in mine}
                     finally:
                         if context is None:
