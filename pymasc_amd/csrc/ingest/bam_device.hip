@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -842,6 +843,7 @@ constexpr int NSTAGE = 3;
 constexpr size_t IN_PAD = 1024;               // the bit reader looks up to two 256-byte pieces ahead
 
 // page-locked staging buffers, kept for the life of the process (pinning them costs more than a small file's ingest)
+std::mutex g_stage_mu;   // (one open at a time goes through the staging buffers)
 struct Staging {
     u8 *buf[NSTAGE] = {nullptr, nullptr, nullptr};
     hipEvent_t ev[NSTAGE];
@@ -985,6 +987,7 @@ int read_and_upload(pmx_dbam &b, const char *path, int nthreads)
         ~Closer() { close(fd); }
     } closer{fd};
     if (b.fsize < 28) return fail(PMX_DBAM_ERR_FORMAT, "truncated BGZF block header");
+    std::lock_guard<std::mutex> stage_guard(g_stage_mu);
     if (!g_stage.ready) {
         for (int i = 0; i < NSTAGE; i++) {
             HIPOK(hipHostMalloc((void **)&g_stage.buf[i], STAGE_HEAD + STAGE_PAYLOAD, hipHostMallocDefault));
