@@ -1008,58 +1008,21 @@ int read_and_upload(pmx_dbam &b, const char *path, int nthreads)
         }
         g_stage.ready = true;
     }
+    const double tq0 = now_s();
     HIPOK(hipMalloc((void **)&b.d_in, b.fsize + IN_PAD));
     HIPOK(hipMemsetAsync(b.d_in + b.fsize, 0, IN_PAD, b.stream));
+    const double t_alloc_in = now_s() - tq0;
     const size_t npieces = (b.fsize + STAGE_PAYLOAD - 1) / STAGE_PAYLOAD;
-    double tw = 0, tr = 0, tc = 0, ts = 0, tl = 0, tq;   // PMX_DBAM_TIMING=1: waits for a staging buffer, reads, copy calls, scan, launches
+    double tw = 0, tr = 0, tc = 0, ts = 0, tl = 0, tq;
+    (void)tl;   // PMX_DBAM_TIMING=1: waits for a staging buffer, reads, copy calls, scan, launches
     u64 next_off = 0, out_off = 0;
     int prev = -1;
-    size_t prev_len = 0;
-    for (size_t k = 0; k < npieces; k++) {
-        const int j = (int)(k % NSTAGE);
-        tq = now_s();
-        if (g_stage.used[j]) HIPOK(hipEventSynchronize(g_stage.ev[j]));
-        tw += now_s() - tq;
-        tq = now_s();
-        u8 *buf = g_stage.buf[j];
-        const u64 a = (u64)k * STAGE_PAYLOAD;
-        const size_t len = (size_t)std::min<u64>(STAGE_PAYLOAD, b.fsize - a);
-        // the file -> the buffer, on several threads (a pread from the page cache is a kernel memcpy)
-        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, len >> 20));
-        std::vector<std::thread> th;
-        std::vector<int> bad((size_t)T, 0);
-        for (int ti = 0; ti < T; ti++)
-            th.emplace_back([&, ti] {
-                const size_t lo = len * (size_t)ti / (size_t)T, hi = len * (size_t)(ti + 1) / (size_t)T;
-                size_t done = lo;
-                while (done < hi) {
-                    const ssize_t r = pread(fd, buf + STAGE_HEAD + done, hi - done, (off_t)(a + done));
-                    if (r <= 0) {
-                        bad[(size_t)ti] = 1;
-                        return;
-                    }
-                    done += (size_t)r;
-                }
-            });
-        size_t head = 0;
-        if (prev >= 0) {   // the last 64 KB of the previous piece in front of this one (meanwhile, on this thread)
-            head = std::min(prev_len, STAGE_HEAD);
-            memcpy(buf + STAGE_HEAD - head, g_stage.buf[prev] + STAGE_HEAD + prev_len - head, head);
-        }
-        for (auto &x : th) x.join();
-        for (int v : bad)
-            if (v) return fail(PMX_DBAM_ERR_OPEN, std::string("read error on ") + path);
-        tr += now_s() - tq;
-        tq = now_s();
-        HIPOK(hipMemcpyAsync(b.d_in + a, buf + STAGE_HEAD, len, hipMemcpyHostToDevice, b.stream));
-        HIPOK(hipEventRecord(g_stage.ev[j], b.stream));
-        g_stage.used[j] = true;
-        tc += now_s() - tq;
-        tq = now_s();
-        // hop over the members that END in this piece (they lie whole in [a - head, a + len))
-        const u64 lo = a - head, hi = a + len;
-        const bool last = k + 1 == npieces;
-        const u8 *base = buf + STAGE_HEAD - head;   // file offset lo
+    size_t prev_len = 0, prev_head = 0;
+    u64 prev_a = 0;
+    double tq2;
+    // hop over the members that END in a piece (they lie whole in [lo, hi), the piece and the 64 KB in front of it at `base`);
+    // runs on this thread while the NEXT piece is being read
+    auto scan_piece = [&](const u8 *base, u64 lo, u64 hi, bool last) -> int {
         for (;;) {
             if (next_off == b.fsize) break;
             if (next_off + 18 > hi) {
@@ -1106,23 +1069,88 @@ int read_and_upload(pmx_dbam &b, const char *path, int nthreads)
             b.members.push_back(me);
             next_off += total;
         }
+        return 0;
+    };
+    for (size_t k = 0; k < npieces; k++) {
+        const int j = (int)(k % NSTAGE);
+        tq = now_s();
+        if (g_stage.used[j]) HIPOK(hipEventSynchronize(g_stage.ev[j]));
+        tw += now_s() - tq;
+        tq = now_s();
+        u8 *buf = g_stage.buf[j];
+        const u64 a = (u64)k * STAGE_PAYLOAD;
+        const size_t len = (size_t)std::min<u64>(STAGE_PAYLOAD, b.fsize - a);
+        // the file -> the buffer, on several threads (a pread from the page cache is a kernel memcpy)
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, len >> 20));
+        std::vector<std::thread> th;
+        std::vector<int> bad((size_t)T, 0);
+        for (int ti = 0; ti < T; ti++)
+            th.emplace_back([&, ti] {
+                const size_t lo = len * (size_t)ti / (size_t)T, hi = len * (size_t)(ti + 1) / (size_t)T;
+                size_t done = lo;
+                while (done < hi) {
+                    const ssize_t r = pread(fd, buf + STAGE_HEAD + done, hi - done, (off_t)(a + done));
+                    if (r <= 0) {
+                        bad[(size_t)ti] = 1;
+                        return;
+                    }
+                    done += (size_t)r;
+                }
+            });
+        size_t head = 0;
+        if (prev >= 0) {   // the last 64 KB of the previous piece in front of this one (meanwhile, on this thread)
+            head = std::min(prev_len, STAGE_HEAD);
+            memcpy(buf + STAGE_HEAD - head, g_stage.buf[prev] + STAGE_HEAD + prev_len - head, head);
+        }
+        if (prev >= 0) {   // the previous piece's members, while this piece is read
+            tq2 = now_s();
+            const size_t phead = prev_head;
+            const int rc = scan_piece(g_stage.buf[prev] + STAGE_HEAD - phead, prev_a - phead, prev_a + prev_len, false);
+            ts += now_s() - tq2;
+            if (rc) {
+                for (auto &x : th) x.join();
+                return rc;
+            }
+            if (b.pipelined) {
+                const int rc2 = launch_members(b, g_stage.ev[prev], out_off);
+                if (rc2) {
+                    for (auto &x : th) x.join();
+                    return rc2;
+                }
+            }
+        }
+        for (auto &x : th) x.join();
+        for (int v : bad)
+            if (v) return fail(PMX_DBAM_ERR_OPEN, std::string("read error on ") + path);
+        tr += now_s() - tq;
+        tq = now_s();
+        HIPOK(hipMemcpyAsync(b.d_in + a, buf + STAGE_HEAD, len, hipMemcpyHostToDevice, b.stream));
+        HIPOK(hipEventRecord(g_stage.ev[j], b.stream));
+        g_stage.used[j] = true;
+        tc += now_s() - tq;
+        tq = now_s();
         prev = j;
         prev_len = len;
-        ts += now_s() - tq;
+        prev_a = a;
+        prev_head = head;
+    }
+    if (prev >= 0) {   // the last piece
         tq = now_s();
-        if (b.pipelined) {   // this piece's members start inflating while the next piece is read and copied
-            const int rc = launch_members(b, g_stage.ev[j], out_off);
-            if (rc) return rc;
+        const int rc = scan_piece(g_stage.buf[prev] + STAGE_HEAD - prev_head, prev_a - prev_head, prev_a + prev_len, true);
+        ts += now_s() - tq;
+        if (rc) return rc;
+        if (b.pipelined) {
+            const int rc2 = launch_members(b, g_stage.ev[prev], out_off);
+            if (rc2) return rc2;
         }
-        tl += now_s() - tq;
     }
     if (next_off != b.fsize) return fail(PMX_DBAM_ERR_FORMAT, "truncated BGZF block");
     b.N = out_off;
     tq = now_s();
     HIPOK(hipStreamSynchronize(b.stream));
     if (getenv("PMX_DBAM_TIMING"))
-        fprintf(stderr, "[pmx_dbam] %zu pieces: buffer waits %.1f ms, reads %.1f, copy calls %.1f, member scan %.1f, launches %.1f, last copy %.1f\n",
-                npieces, tw * 1e3, tr * 1e3, tc * 1e3, ts * 1e3, tl * 1e3, (now_s() - tq) * 1e3);
+        fprintf(stderr, "[pmx_dbam] %zu pieces: buffer waits %.1f ms, reads %.1f, copy calls %.1f, member scan %.1f, last copy %.1f, hipMalloc of the file's copy %.1f\n",
+                npieces, tw * 1e3, tr * 1e3, tc * 1e3, ts * 1e3, (now_s() - tq) * 1e3, t_alloc_in * 1e3);
     return 0;
 }
 
@@ -1138,8 +1166,10 @@ int check_members(pmx_dbam &b)
             return fail(PMX_DBAM_ERR_FORMAT, std::string(inf_err_text(status[i])) + where);
         }
     // the compressed copy is not needed any more
+    const double tf = now_s();
     HIPOK(hipFree(b.d_in));
     b.d_in = nullptr;
+    if (getenv("PMX_DBAM_TIMING")) fprintf(stderr, "[pmx_dbam] hipFree of the file's copy %.1f ms\n", (now_s() - tf) * 1e3);
     return 0;
 }
 
@@ -1168,8 +1198,10 @@ int finish_pipeline(pmx_dbam &b)
 int inflate_all(pmx_dbam &b)
 {
     const u32 nmem = (u32)b.members.size();
+    const double ta = now_s();
     int rc = ensure_room(b, std::max<u32>(nmem, 1), b.N);
     if (rc) return rc;
+    if (getenv("PMX_DBAM_TIMING")) fprintf(stderr, "[pmx_dbam] member table + output buffer allocated in %.1f ms\n", (now_s() - ta) * 1e3);
     if (!nmem) return check_members(b);
     memcpy(b.h_mem, b.members.data(), sizeof(DMember) * nmem);
     double t0 = now_s();
