@@ -84,12 +84,17 @@ def ingest_sources():
 def build_ingest(force=False, verbose=False):
     """libpymasc_ingest.so (include/pymasc_amd_ingest.h): BGZF inflate + BAM record decode on the device, hipcc for gfx950.
     A library of its own: libpymasc_hip.so's build id (source_hash) covers the cross-correlation kernels only."""
-    deps = ingest_sources() + [os.path.join(HERE, "..", "include", "pymasc_amd_ingest.h")]
+    deps = ingest_sources() + [os.path.join(HERE, "..", "include", "pymasc_amd_ingest.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(INGEST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(INGEST_LIB) for d in deps):
         return INGEST_LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP", "-Wall", "-Wno-unused-function", "-pthread",
+           "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP",
+           # the inflate kernel's decoder is uniform control flow; left alone by the structurizer (the backend's default is to
+           # structurize uniform regions too: flags and exec-mask tests around scalar branches) it runs matches 40 -> 48 GB/s,
+           # BAM-like members 28 -> 33 GB/s (same-box A/B, tools/ingest_paths.py; no effect on libpymasc_hip.so's kernels)
+           "-mllvm", "-structurizecfg-skip-uniform-regions=1",
+           "-Wall", "-Wno-unused-function", "-pthread",
            "-o", INGEST_LIB] + ingest_sources()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
