@@ -216,6 +216,11 @@ int pmx_bits_set_regions_async(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, 
 #define PMX_REGIONS_SORTED 4u
 int pmx_bits_set_regions_ex(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
                             uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state, uint32_t flags);
+/* The same for intervals already IN DEVICE MEMORY (round 4: libpymasc_ingest.so decodes a BigWig file on the GPU, pmx_dbw_fetch):
+ * uint32 d_first[n], d_last[n], complete when the call is made and untouched until the next synchronising call.  flags:
+ * PMX_REGIONS_CLEAR, PMX_REGIONS_SORTED (not PMX_REGIONS_SIDE: nothing is copied, the kernel runs on the context's stream). */
+int pmx_bits_set_regions_dev_ex(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const uint32_t *d_first, const uint32_t *d_last,
+                                uint64_t n, int64_t first_offset, uint64_t *d_state, uint32_t flags);
 /* (The three feeders above and below stage their host arrays in one device slot, each array padded to 16 bytes.  Arrays
  * that lie in host memory in that same layout -- back to back in argument order, each padded to 16 bytes, ideally in
  * page-locked memory from pmx_host_alloc -- are copied in ONE piece; anything else array by array.) */

@@ -34,6 +34,7 @@ extern "C" {
 #define PMX_DBAM_ERR_OPEN     -1   /* cannot open / read the file, or out of (device) memory */
 #define PMX_DBAM_ERR_FORMAT   -2   /* not a BAM file, truncated or corrupt (gzip magic, DEFLATE, CRC32, ISIZE, records) */
 #define PMX_DBAM_ERR_INVALID  -3   /* bad argument */
+#define PMX_DBAM_ERR_NOTFOUND -4   /* unknown chromosome (pmx_dbw_fetch) */
 #define PMX_DBAM_ERR_DEVICE   -5   /* a HIP call failed */
 
 typedef struct pmx_dbam pmx_dbam;
@@ -85,6 +86,27 @@ int pmx_dbam_timings(const pmx_dbam *b, double t[6]);
 
 /* Test hook: the inflated stream (bytes [first, first + n)) copied to the host. */
 int pmx_dbam_inflated(pmx_dbam *b, uint64_t first, uint64_t n, uint8_t *dst);
+
+/* ---- BigWig (bbi) on the device -----------------------------------------------------------
+ * What pmx_bigwig_* (pymasc_amd_io.h) does with zlib on host threads, with the data blocks inflated (the BGZF kernel, for zlib
+ * streams of unknown length), Adler-32-checked and decoded by HIP kernels; the host reads the header, the chromosome B+ tree and
+ * the R-tree (a few KB per chromosome).  Replaces PyMaSC/reader/bigwig.pyx:129-177 (pyBigWig). */
+typedef struct pmx_dbw pmx_dbw;
+int pmx_dbw_open(const char *path, int device, int nthreads, pmx_dbw **out);
+void pmx_dbw_close(pmx_dbw *w);
+/* Chromosome dictionary = BigWigReader.chromsizes (reader/bigwig.pyx:60-75), in the file's B+ tree order. */
+int32_t pmx_dbw_nchrom(const pmx_dbw *w);
+const char *pmx_dbw_chrom_name(const pmx_dbw *w, int32_t i);
+int64_t pmx_dbw_chrom_len(const pmx_dbw *w, int32_t i);
+/* All intervals of `chrom` in index order (ascending position for a valid file) whose float32 value is >= threshold
+ * (threshold <= 0: every interval), as BigWigReader.fetch yields them (bigwig.pyx:147-177) -- the intervals, values and order
+ * of pmx_bigwig_fetch.  They stay in device memory (begin[n], end[n] uint32, value[n] float32; every fetch has arrays of its own,
+ * valid until close).  Returns n, PMX_DBAM_ERR_NOTFOUND for an unknown chromosome, or another negative error code. */
+int64_t pmx_dbw_fetch(pmx_dbw *w, const char *chrom, float threshold);
+int pmx_dbw_device_arrays(const pmx_dbw *w, const uint32_t **d_begin, const uint32_t **d_end, const float **d_value);
+/* 1 when the intervals of the last fetch are non-empty, ascending and disjoint (begin_i < end_i <= begin_(i+1): BigWig order) */
+int pmx_dbw_sorted(const pmx_dbw *w);
+int pmx_dbw_copy(pmx_dbw *w, int64_t first, int64_t n, uint32_t *begin, uint32_t *end, float *value);
 
 #ifdef __cplusplus
 }

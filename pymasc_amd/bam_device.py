@@ -24,6 +24,8 @@ INGEST_EXPORTS = [
     "pmx_dbam_last_error", "pmx_dbam_version", "pmx_dbam_open", "pmx_dbam_close", "pmx_dbam_nref", "pmx_dbam_ref_name",
     "pmx_dbam_ref_len", "pmx_dbam_header_text", "pmx_dbam_decode", "pmx_dbam_device_arrays", "pmx_dbam_fetch",
     "pmx_dbam_runs", "pmx_dbam_counters", "pmx_dbam_timings", "pmx_dbam_inflated",
+    "pmx_dbw_open", "pmx_dbw_close", "pmx_dbw_nchrom", "pmx_dbw_chrom_name", "pmx_dbw_chrom_len", "pmx_dbw_fetch", "pmx_dbw_device_arrays",
+    "pmx_dbw_sorted", "pmx_dbw_copy",
 ]
 
 _lib = None
@@ -71,6 +73,24 @@ def load_ingest_library():
     L.pmx_dbam_timings.restype = ctypes.c_int
     L.pmx_dbam_inflated.argtypes = [vp, u64, u64, vp]
     L.pmx_dbam_inflated.restype = ctypes.c_int
+    L.pmx_dbw_open.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    L.pmx_dbw_open.restype = ctypes.c_int
+    L.pmx_dbw_close.argtypes = [vp]
+    L.pmx_dbw_close.restype = None
+    L.pmx_dbw_nchrom.argtypes = [vp]
+    L.pmx_dbw_nchrom.restype = i32
+    L.pmx_dbw_chrom_name.argtypes = [vp, i32]
+    L.pmx_dbw_chrom_name.restype = ctypes.c_char_p
+    L.pmx_dbw_chrom_len.argtypes = [vp, i32]
+    L.pmx_dbw_chrom_len.restype = i64
+    L.pmx_dbw_fetch.argtypes = [vp, ctypes.c_char_p, ctypes.c_float]
+    L.pmx_dbw_fetch.restype = i64
+    L.pmx_dbw_device_arrays.argtypes = [vp] + [ctypes.POINTER(vp)] * 3
+    L.pmx_dbw_device_arrays.restype = ctypes.c_int
+    L.pmx_dbw_sorted.argtypes = [vp]
+    L.pmx_dbw_sorted.restype = ctypes.c_int
+    L.pmx_dbw_copy.argtypes = [vp, i64, i64, vp, vp, vp]
+    L.pmx_dbw_copy.restype = ctypes.c_int
     _lib = L
     return L
 

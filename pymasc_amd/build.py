@@ -84,7 +84,8 @@ def ingest_sources():
 def build_ingest(force=False, verbose=False):
     """libpymasc_ingest.so (include/pymasc_amd_ingest.h): BGZF inflate + BAM record decode on the device, hipcc for gfx950.
     A library of its own: libpymasc_hip.so's build id (source_hash) covers the cross-correlation kernels only."""
-    deps = ingest_sources() + [os.path.join(HERE, "..", "include", "pymasc_amd_ingest.h"), os.path.abspath(__file__)]
+    deps = ingest_sources() + glob.glob(os.path.join(CSRC, "ingest", "*.inc")) + [os.path.join(HERE, "..", "include", "pymasc_amd_ingest.h"),
+                                                                                     os.path.abspath(__file__)]
     if not force and os.path.exists(INGEST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(INGEST_LIB) for d in deps):
         return INGEST_LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -45,7 +45,8 @@ typedef uint64_t u64;
 struct DMember {
     u64 in_off;    // byte offset of the raw DEFLATE stream in the device copy of the file
     u64 out_off;   // byte offset of the member's output in the inflated stream
-    u32 clen, isize, crc, pad;
+    u32 clen, isize, crc;
+    u32 open_size;   // 1: `isize` is only a bound (a zlib stream of unknown length: BigWig data blocks); the kernel reports the length
 };
 
 // status word of a member (0 = fine)
@@ -243,7 +244,8 @@ __constant__ u8 INF_CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12,
 // (the ring takes the byte anyway, a flush stores nothing beyond ISIZE, and the count is checked at every flush and at the
 // end), 32-bit positions relative to the member's 256-byte aligned start.
 __global__ void __launch_bounds__(64)
-k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *__restrict__ mem, u32 nmem, u32 *__restrict__ status)
+k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *__restrict__ mem, u32 nmem, u32 *__restrict__ status,
+               u32 *__restrict__ out_size)
 {
     __shared__ __align__(16) InfLds S;
     const u32 m = blockIdx.x;
@@ -477,8 +479,10 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
     // the stream must end inside the member's bytes and fill ISIZE exactly
     const u64 used_bits = (u64)(r.ci * 64u + r.widx) * 32u - r.bc - 8u * skew;
     if (used_bits > 8ull * clen) INF_FAIL(INF_ERR_INPUT)
-    if (pos != pend) INF_FAIL(pos > pend ? INF_ERR_OUTPUT : INF_ERR_ISIZE)
-    for (u32 g = pos & ~255u; g < pend; g += 256u) inf_flush(S.ring, ob, g, pstart, pend, lane);
+    const bool open_size = mem[m].open_size != 0;
+    if (pos > pend || (!open_size && pos != pend)) INF_FAIL(pos > pend ? INF_ERR_OUTPUT : INF_ERR_ISIZE)
+    if (open_size) out_size[m] = pos - pstart;
+    for (u32 g = pos & ~255u; g < pos; g += 256u) inf_flush(S.ring, ob, g, pstart, pos, lane);
 #undef INF_REFILL
 }
 
@@ -967,7 +971,7 @@ int launch_members(pmx_dbam &b, hipEvent_t after, u64 out_end)
     hipStream_t ks = (turn == 0 || !b.kmore[turn - 1]) ? b.kstream : b.kmore[turn - 1];
     HIPOK(hipStreamWaitEvent(ks, after, 0));
     const u32 n = m1 - m0;
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n), dim3(64), 0, ks, b.d_in, b.d_out, b.d_hmem + m0, n, b.d_status + m0);
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n), dim3(64), 0, ks, b.d_in, b.d_out, b.d_hmem + m0, n, b.d_status + m0, (u32 *)nullptr);
     HIPOK(hipGetLastError());
     hipLaunchKernelGGL(k_bgzf_crc, dim3((n + 3) / 4), dim3(256), 0, ks, b.d_out, b.d_hmem + m0, n, b.d_status + m0);
     HIPOK(hipGetLastError());
@@ -1063,7 +1067,7 @@ int read_and_upload(pmx_dbam &b, const char *path, int nthreads)
             me.crc = h32(p + total - 8);
             me.isize = h32(p + total - 4);
             me.out_off = out_off;
-            me.pad = 0;
+            me.open_size = 0;
             if (me.isize > 65536) return fail(PMX_DBAM_ERR_FORMAT, "BGZF block larger than 64 KiB");
             out_off += me.isize;
             b.members.push_back(me);
@@ -1205,7 +1209,7 @@ int inflate_all(pmx_dbam &b)
     if (!nmem) return check_members(b);
     memcpy(b.h_mem, b.members.data(), sizeof(DMember) * nmem);
     double t0 = now_s();
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(nmem), dim3(64), 0, b.kstream, b.d_in, b.d_out, b.d_hmem, nmem, b.d_status);
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(nmem), dim3(64), 0, b.kstream, b.d_in, b.d_out, b.d_hmem, nmem, b.d_status, (u32 *)nullptr);
     HIPOK(hipGetLastError());
     HIPOK(hipStreamSynchronize(b.kstream));
     double t1 = now_s();
@@ -1549,3 +1553,5 @@ int pmx_dbam_inflated(pmx_dbam *b, uint64_t first, uint64_t n, uint8_t *dst)
 }
 
 }  // extern "C"
+
+#include "bigwig_device.inc"

@@ -1075,6 +1075,23 @@ int pmx_bits_set_regions_ex(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, con
     return pmx_bits_set_regions_async(ctx, d_words, nbits, h_first, h_last, width_bytes, n, first_offset, d_state);
 }
 
+int pmx_bits_set_regions_dev_ex(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const uint32_t *d_first, const uint32_t *d_last,
+                                uint64_t n, int64_t first_offset, uint64_t *d_state, uint32_t flags)
+{
+    if (ctx) (void)hipSetDevice(ctx->device);
+    REQUIRE(ctx && d_words && ((d_first && d_last) || n == 0), "pmx_bits_set_regions_dev_ex: NULL argument");
+    REQUIRE(!(flags & ~(PMX_REGIONS_CLEAR | PMX_REGIONS_SORTED)), "pmx_bits_set_regions_dev_ex: unknown flag (PMX_REGIONS_SIDE is for host arrays)");
+    REQUIRE(!(flags & PMX_REGIONS_SORTED) || d_state, "pmx_bits_set_regions_dev_ex: PMX_REGIONS_SORTED needs d_state (order violations are recorded there)");
+    PMX_JOIN_SIDE(ctx);
+    if (flags & PMX_REGIONS_SORTED)
+        return pmx_launch_regions_build_on(ctx, ctx->stream, d_words, nbits, d_first, d_last, 4, n, first_offset,
+                                           d_state + PMX_FEED_FIRST_OUT_OF_RANGE, d_state + PMX_FEED_REGIONS_UNSORTED);
+    if (flags & PMX_REGIONS_CLEAR) PMX_HIP(hipMemsetAsync(d_words, 0, ((nbits + 63) / 64) * sizeof(uint64_t), ctx->stream));
+    if (n == 0) return PMX_OK;
+    return pmx_launch_set_regions_w(ctx, d_words, nbits, d_first, d_last, 4, n, first_offset,
+                                    d_state ? d_state + PMX_FEED_FIRST_OUT_OF_RANGE : nullptr);
+}
+
 int pmx_bits_set_regions_async(pmx_ctx *ctx, uint64_t *d_words, uint64_t nbits, const void *h_first, const void *h_last,
                                uint32_t width_bytes, uint64_t n, int64_t first_offset, uint64_t *d_state)
 {

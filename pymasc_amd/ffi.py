@@ -57,7 +57,7 @@ EXPORTS = [
     "pmx_bits_alloc", "pmx_bits_free", "pmx_bits_clear", "pmx_bits_upload", "pmx_bits_download",
     "pmx_bits_set_positions", "pmx_bits_set_positions_dev", "pmx_bits_set_regions", "pmx_bits_set_regions_dev",
     "pmx_bits_count",
-    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_ex", "pmx_feed_reads_delta16", "pmx_feed_reads_dev", "pmx_bits_set_regions_async", "pmx_bits_set_regions_ex", "pmx_bits_build_batch",
+    "pmx_host_alloc", "pmx_host_free", "pmx_feed_reads", "pmx_feed_reads_ex", "pmx_feed_reads_delta16", "pmx_feed_reads_dev", "pmx_bits_set_regions_async", "pmx_bits_set_regions_ex", "pmx_bits_set_regions_dev_ex", "pmx_bits_build_batch",
     "pmx_bits_build_status",
     "pmx_cc_dev", "pmx_cc_batch_dev", "pmx_cc_batch_ranges_dev", "pmx_calc_correlation", "pmx_mappable_len_dev", "pmx_mappable_len",
     "pmx_mappable_len_batch_dev",
@@ -112,6 +112,7 @@ def load_library(path: Optional[str] = None):
     L.pmx_feed_reads_dev.argtypes = [vp, vp, vp, u64, vp, vp, vp, u64, u64, vp, u32]
     L.pmx_bits_set_regions_async.argtypes = [vp, vp, u64, vp, vp, u32, u64, ctypes.c_int64, vp]
     L.pmx_bits_set_regions_ex.argtypes = [vp, vp, u64, vp, vp, u32, u64, ctypes.c_int64, vp, u32]
+    L.pmx_bits_set_regions_dev_ex.argtypes = [vp, vp, u64, vp, vp, u64, ctypes.c_int64, vp, u32]
     L.pmx_bits_build_batch.argtypes = [vp, u32, vp, u32]
     L.pmx_bits_build_status.argtypes = [vp]
     L.pmx_mappable_len_batch_dev.argtypes = [vp, u32, vp, vp, u32, u32, vp]
@@ -448,6 +449,15 @@ class Context:
                                                   pos.size, int(reads_before), ctypes.c_void_p(d_state),
                                                   PMX_FEED_WHOLE_VECTORS if whole_vectors else 0))
         return pos, readlen, rev
+
+    def bits_set_regions_dev(self, d_words: int, nbits: int, d_first: int, d_last: int, n: int, first_offset: int = 0,
+                             d_state: Optional[int] = None, clear: bool = False, sorted_disjoint: bool = False):
+        """pmx_bits_set_regions_dev_ex: set(first + first_offset, last) per interval for uint32 arrays that are already in device memory
+        (pymasc_amd.bigwig_device.DeviceBigWigReader.fetch_device); clear / sorted_disjoint as in bits_set_regions_async."""
+        flags = (PMX_REGIONS_CLEAR if clear else 0) | (PMX_REGIONS_SORTED if sorted_disjoint else 0)
+        _check(self._L, self._L.pmx_bits_set_regions_dev_ex(self._h, ctypes.c_void_p(d_words), int(nbits), ctypes.c_void_p(d_first),
+                                                            ctypes.c_void_p(d_last), int(n), int(first_offset),
+                                                            ctypes.c_void_p(d_state) if d_state else None, flags))
 
     def bits_set_regions_async(self, d_words: int, nbits: int, first: np.ndarray, last: np.ndarray, first_offset: int = 0,
                                d_state: Optional[int] = None, clear: bool = False, side: bool = False, sorted_disjoint: bool = False):

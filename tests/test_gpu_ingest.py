@@ -324,3 +324,94 @@ def test_device_feed_equals_host_feed(tmp_path):
                               int(v.chrom.forward_read_len_sum), int(v.chrom.reverse_read_len_sum)) for n, v in res.items()}))
         calc.close()
     assert out[0] == out[1] and out[0][0] > 8000
+
+
+# ---------------------------------------------------------------- BigWig on the device --------------------------------
+def _same_intervals(a, b):
+    return all((x == y).all() and x.dtype == y.dtype for x, y in zip(a, b)) and len(a[0]) == len(b[0])
+
+
+def test_reference_bigwig_on_the_device_matches_host_reader_and_bedgraph_twin():
+    """The reference's test track: chromosome dictionary and every chromosome's intervals at three thresholds == the host reader
+    (zlib), whose own test pins it to the bedGraph twin (tests/test_io_readers.py)."""
+    from pymasc_amd.bigwig import BigWigReader
+    from pymasc_amd.bigwig_device import DeviceBigWigReader
+    from .test_io_readers import BIGWIG
+    with BigWigReader(BIGWIG) as h, DeviceBigWigReader(BIGWIG) as d:
+        assert d.chromsizes == h.chromsizes and list(d.chromsizes) == list(h.chromsizes)
+        total = 0
+        for thr in (1, 0, 0.5):
+            for c in h.chromsizes:
+                a, b = h.fetch_arrays(thr, c), d.fetch_arrays(thr, c)
+                assert _same_intervals(a, b), (thr, c)
+                total += a[0].size
+                assert list(d.fetch(thr, c))[:5] == list(h.fetch(thr, c))[:5]
+        assert total > 1970
+        with pytest.raises(KeyError):
+            d.fetch_arrays(1, "chrNope")
+
+
+@pytest.mark.parametrize("kind,compress", [("bedgraph", True), ("bedgraph", False), ("varstep", True), ("fixedstep", True), ("fixedstep", False)])
+def test_synthetic_bigwig_sections_on_the_device(tmp_path, kind, compress):
+    """Every section type, compressed and not, several R-tree levels, chromosomes sharing index entries, values around the
+    threshold, an interval beyond the chromosome's end: device == host reader."""
+    from pymasc_amd.bigwig import BigWigReader
+    from pymasc_amd.bigwig_device import DeviceBigWigReader
+    from .test_io_readers import _tracks
+    rng = np.random.default_rng(31)
+    chromsizes = {"chr1": 500000, "chr2": 120000, "chrX_random_with_a_long_name": 40000, "chrM": 16571}
+    span, step = (25, 40) if kind != "bedgraph" else (None, None)
+    tracks = _tracks(rng, chromsizes, span=span, step=step)
+    path = tmp_path / "t.bw"
+    kw = {} if kind == "bedgraph" else {"span": span, "step": step}
+    W.write_bigwig(path, chromsizes, tracks, kind=kind, compress=compress, items_per_block=37, rtree_block=3, bpt_block=2, **kw)
+    with BigWigReader(path) as h, DeviceBigWigReader(path) as d:
+        assert d.chromsizes == h.chromsizes
+        for thr in (1, 0, 0.25):
+            for c in chromsizes:
+                assert _same_intervals(h.fetch_arrays(thr, c), d.fetch_arrays(thr, c)), (thr, c)
+        _b, _e, n, in_order = d.fetch_device(1, "chr1")
+        a = h.fetch_arrays(1, "chr1")
+        assert n == a[0].size and in_order == bool((a[0] < a[1]).all() and (a[0][1:] >= a[1][:-1]).all())
+
+
+def test_bigwig_corrupt_input_on_the_device(tmp_path):
+    from pymasc_amd.bigwig_device import DeviceBigWigReader
+    from .test_io_readers import _tracks
+    rng = np.random.default_rng(5)
+    chromsizes = {"c1": 100000}
+    path = tmp_path / "g.bw"
+    W.write_bigwig(path, chromsizes, _tracks(rng, chromsizes), items_per_block=64)
+    raw = bytearray(open(path, "rb").read())
+    with pytest.raises(B.PmxIOError, match="magic"):
+        p = tmp_path / "m.bw"
+        p.write_bytes(b"\0\0\0\0" + bytes(raw[4:]))
+        DeviceBigWigReader(p)
+    with pytest.raises(IOError):
+        DeviceBigWigReader(tmp_path / "missing.bw")
+    # a flipped byte inside the first data block: the DEFLATE decoder or the Adler-32 check reports it
+    with DeviceBigWigReader(path) as d:
+        d.fetch_arrays(1, "c1")
+    data_off = struct.unpack("<Q", raw[16:24])[0]
+    bad = bytearray(raw)
+    bad[data_off + 4 + 40] ^= 0x10
+    p = tmp_path / "f.bw"
+    p.write_bytes(bytes(bad))
+    with pytest.raises(B.PmxIOError, match="inflate"):
+        with DeviceBigWigReader(p) as d:
+            d.fetch_arrays(1, "c1")
+
+
+def test_golden_run_with_both_inputs_on_the_device(tmp_path):
+    """-d 300 -q 10 -r 36 -m bigwig with the BAM file AND the mappability track decoded on the GPU, records and intervals handed to the
+    calculator in HBM: the reference's golden tables."""
+    from pymasc_amd.bigwig_device import DeviceBigWigReader
+    from pymasc_amd.calculator import CCHipCalculator
+    from .test_io_readers import BIGWIG
+    with D.DeviceBamReader(BAM) as bam, DeviceBigWigReader(BIGWIG) as bw:
+        calc = CCHipCalculator(300, 36, bam.references, bam.lengths, bwfeeder=bw)
+        assert bam.feed(calc, 10) == 1292
+        whole = calc.get_whole_result()
+        calc.close()
+        names = bam.references
+    _check_tables(tmp_path / "both", whole, names)
