@@ -228,7 +228,13 @@ def run_sharded(bam_path, max_shift: int, read_len: int, mapq_criteria: int, big
         with open_bam() as bam:
             names = [n for n in bam.references if references is None or n in set(references)]
             lengths = dict(zip(bam.references, bam.lengths))
-            bw = BigWigReader(bigwig_path) if bigwig_path is not None else None
+            if bigwig_path is None:
+                bw = None
+            elif device_ingest:      # the track decoded on the GPU too: its intervals reach the calculator in HBM
+                from .bigwig_device import DeviceBigWigReader
+                bw = DeviceBigWigReader(bigwig_path, device=(context.device if context is not None else (device or 0)))
+            else:
+                bw = BigWigReader(bigwig_path)
             try:
                 if bw is not None:      # the track's chromosome sizes win where they are longer (handler/calc.py:100-115)
                     lengths.update(reconcile_chromosome_sizes({n: lengths[n] for n in names}, bw.chromsizes))

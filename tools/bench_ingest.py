@@ -119,6 +119,45 @@ def time_device_reader(path, mapq, check=None):
     return out
 
 
+def time_bigwig(path_bw, chroms_per_call=None):
+    """A synthetic hg38-shaped mappability track (runs of ~500 bp every ~1250 bp, bedGraph sections of 1024 items, zlib) read
+    chromosome by chromosome: the host reader (zlib on threads) against the device reader (intervals left in HBM), same intervals."""
+    from pymasc_amd.bigwig import BigWigReader
+    from pymasc_amd.bigwig_device import DeviceBigWigReader
+    rng = np.random.default_rng(3)
+    sizes = {n: l for n, l in HG38}
+    tracks = {}
+    t0 = time.time()
+    for n, l in sizes.items():
+        k = l // 1250
+        starts = np.arange(k, dtype=np.int64) * 1250 + rng.integers(0, 600, k)
+        ends = starts + rng.integers(200, 640, k)
+        tracks[n] = list(zip(starts.tolist(), ends.tolist(), [1.0] * k))
+    W.write_bigwig(path_bw, sizes, tracks, items_per_block=1024, rtree_block=256)
+    out = {"intervals": sum(map(len, tracks.values())), "file_bytes": os.path.getsize(path_bw), "generate_s": round(time.time() - t0, 1)}
+    del tracks
+    host = []
+    for _ in range(3):
+        t0 = time.time()
+        with BigWigReader(path_bw) as bw:
+            chk = [(a.size, int(a.sum()) + int(b.sum())) for a, b, _v in (bw.fetch_arrays(1, c) for c in sizes)]
+        host.append(round(time.time() - t0, 4))
+    dev, dev_open = [], []
+    for _ in range(3):
+        t0 = time.time()
+        with DeviceBigWigReader(path_bw) as bw:
+            t1 = time.time()
+            ns = [bw.fetch_device(1, c)[2] for c in sizes]
+            dev.append(round(time.time() - t0, 4))
+            dev_open.append(round(t1 - t0, 4))
+    with DeviceBigWigReader(path_bw) as bw:     # parity of the whole track
+        chk2 = [(a.size, int(a.sum()) + int(b.sum())) for a, b, _v in (bw.fetch_arrays(1, c) for c in sizes)]
+    assert chk == chk2 and ns == [c[0] for c in chk]
+    out.update({"host_reader_s": host, "device_reader_s": dev, "device_open_s": dev_open, "speedup": round(min(host) / min(dev), 2)})
+    os.unlink(path_bw)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=5_000_000)
@@ -128,6 +167,7 @@ def main():
     ap.add_argument("--chroms", type=int, default=None)
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--device", action="store_true", help="time the device-side reader (BGZF inflate + decode as HIP kernels)")
+    ap.add_argument("--bigwig", action="store_true", help="also time the mappability track: host reader against device reader")
     ap.add_argument("--pyloop", type=int, default=0, help="time a per-read Python feeding loop over this many reads")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -196,6 +236,9 @@ def main():
                 calc.close()
                 res["end_to_end_device"].append({"seconds": round(dt2, 3), "reads_fed": fed2, "reads_per_s": round(fed2 / dt2)})
                 print(json.dumps(res["end_to_end_device"][-1]), flush=True)
+    if a.bigwig:
+        res["bigwig"] = time_bigwig(a.path + ".bw")
+        print(json.dumps(res["bigwig"]), flush=True)
     if a.out:
         with open(a.out, "w") as fp:
             json.dump(res, fp, indent=1)
