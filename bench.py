@@ -531,7 +531,11 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        assert torch.equal(host_rows, rows.cpu()), "end-to-end rows differ from the resident-vector rows"
+        if not torch.equal(host_rows, rows.cpu()):
+            bad = (host_rows != rows.cpu()).nonzero()
+            raise AssertionError("end-to-end rows differ from the resident-vector rows: %d cells, first %s (e2e %s, resident %s); shape %s"
+                                 % (bad.shape[0], bad[0].tolist(), host_rows[tuple(bad[0].tolist())].item(),
+                                    rows.cpu()[tuple(bad[0].tolist())].item(), tuple(host_rows.shape)))
         h2d = sum(h[0].nbytes + h[1].nbytes + ((h[2].nbytes + h[3].nbytes) if with_m else 0) for h in host)
         end_to_end = {"value": work_per_step / dt, "unit": "shifts*bp/s", "ms_per_step": dt * 1e3, "steps": n_e2e,
                       "h2d_bytes_this_rank": h2d, "d2h_bytes": int(host_rows.numel() * 8),

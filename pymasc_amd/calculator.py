@@ -392,15 +392,15 @@ class CCHipCalculator:
         if not self._bwfeeder:
             return None
         on_device = getattr(self._bwfeeder, "fetch_device", None)
-        if on_device is not None and hasattr(self._ctx, "bits_set_regions_dev"):
+        if on_device is not None and hasattr(self._ctx, "bits_set_regions_dev_ex"):
             # pymasc_amd.bigwig_device.DeviceBigWigReader: the file was decoded on the GPU and the chromosome's intervals are in HBM
             # already -- set(begin + 1, end) (mscc.pyx:343-344) straight from there; sorted, disjoint intervals (BigWig order, checked
             # by the reader on the device) BUILD the vector as below
             d_first, d_last, n, in_order = on_device(self.MAPPABILITY_THRESHOLD, chrom)
             self._logging_info("Loading {} mappability to bit array...".format(chrom))
             vec = self._vector(nbits, clear=False)
-            self._ctx.bits_set_regions_dev(vec[0], nbits, d_first, d_last, n, 1, self._state_ptr(slot), clear=True,
-                                           sorted_disjoint=self.track_builder and in_order and n > 0)
+            self._ctx.bits_set_regions_dev_ex(vec[0], nbits, d_first, d_last, n, 1, self._state_ptr(slot), clear=True,
+                                              sorted_disjoint=self.track_builder and in_order and n > 0)
             self._n_runs = int(n)
             return vec
         bulk = getattr(self._bwfeeder, "fetch_arrays", None)

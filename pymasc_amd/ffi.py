@@ -450,8 +450,8 @@ class Context:
                                                   PMX_FEED_WHOLE_VECTORS if whole_vectors else 0))
         return pos, readlen, rev
 
-    def bits_set_regions_dev(self, d_words: int, nbits: int, d_first: int, d_last: int, n: int, first_offset: int = 0,
-                             d_state: Optional[int] = None, clear: bool = False, sorted_disjoint: bool = False):
+    def bits_set_regions_dev_ex(self, d_words: int, nbits: int, d_first: int, d_last: int, n: int, first_offset: int = 0,
+                                d_state: Optional[int] = None, clear: bool = False, sorted_disjoint: bool = False):
         """pmx_bits_set_regions_dev_ex: set(first + first_offset, last) per interval for uint32 arrays that are already in device memory
         (pymasc_amd.bigwig_device.DeviceBigWigReader.fetch_device); clear / sorted_disjoint as in bits_set_regions_async."""
         flags = (PMX_REGIONS_CLEAR if clear else 0) | (PMX_REGIONS_SORTED if sorted_disjoint else 0)

@@ -101,3 +101,17 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.lower() or f == "__init__.py" and False, os.path.join(dirpath, f)
+
+
+def test_no_method_is_defined_twice_in_a_class():
+    """A second `def` of the same name silently replaces the first (round 4: a new Context.bits_set_regions_dev for uint32 arrays
+    shadowed the int64 one the benchmark's vector builder calls -- the bench's own end-to-end check caught it, no test did)."""
+    import ast
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "pymasc_amd", "*.py")):
+        tree = ast.parse(open(f).read())
+        for c in [n for n in ast.walk(tree) if isinstance(n, ast.ClassDef)]:
+            names = [n.name for n in c.body if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]
+            props = {n.name for n in c.body if isinstance(n, ast.FunctionDef) and n.decorator_list}
+            dup = {x for x in names if names.count(x) > 1 and x not in props}
+            assert not dup, (f, c.name, dup)
