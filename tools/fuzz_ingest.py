@@ -6,7 +6,7 @@ random distances up to 32 KB, runs, BAM-like records), zlib level 0..9, strategy
 fixed), memLevel 1..9 (short blocks: several DEFLATE blocks per member), window 2^9..2^15, sync-flushed mixtures -- behind a
 BAM header, and checks the inflated stream byte for byte; every other round is a BAM file of random records (record sizes from
 tens of bytes to beyond a 16-KB piece, random flags / mapq / CIGARs / tags, member sizes 40 .. 65280) checked against the host
-reader's records for two filters.  usage: tools/fuzz_ingest.py --seconds 300 --seed 1"""
+reader's records for two filters, and a random BigWig track (device reader == host reader, three thresholds).  usage: tools/fuzz_ingest.py --seconds 300 --seed 1"""
 import argparse
 import os
 import struct
@@ -128,6 +128,40 @@ def round_records(rng, path):
     return len(recs), c["rewalked"]
 
 
+def round_bigwig(rng, path):
+    """A random track (bedGraph / variableStep / fixedStep sections, compressed or not, block and tree sizes, values around the
+    thresholds): every chromosome at three thresholds, device reader == host reader."""
+    from pymasc_amd.bigwig import BigWigReader
+    from pymasc_amd.bigwig_device import DeviceBigWigReader
+    kind = str(rng.choice(["bedgraph", "varstep", "fixedstep"]))
+    chromsizes = {"c%d" % i: int(rng.integers(2000, 300000)) for i in range(int(rng.integers(1, 7)))}
+    span = None if kind == "bedgraph" else int(rng.integers(1, 60))
+    step = int(rng.integers(1, 80)) if kind == "fixedstep" else None
+    tracks = {}
+    for name, size in chromsizes.items():
+        if rng.random() < 0.15:
+            continue
+        iv, p = [], int(rng.integers(0, 50))
+        while p < size - 300:
+            ln = int(rng.integers(1, 400)) if span is None else span
+            iv.append((p, p + ln, float(rng.choice([0.0, 0.25, 0.5, 1.0, 1.0, 3.5]))))
+            p += step if (step is not None and rng.random() < 0.8) else ln + int(rng.integers(0, 300))
+        tracks[name] = iv
+    if not tracks:
+        return 0
+    W.write_bigwig(path, chromsizes, tracks, kind=kind, compress=bool(rng.random() < 0.8), items_per_block=int(rng.choice([1, 5, 64, 1024])),
+                   rtree_block=int(rng.choice([2, 4, 64])), bpt_block=int(rng.choice([2, 3, 16])), span=span or 1, step=step or 1)
+    n = 0
+    with BigWigReader(path) as h, DeviceBigWigReader(path) as d:
+        assert d.chromsizes == h.chromsizes
+        for thr in (1, 0, 0.5):
+            for c in chromsizes:
+                a, b = h.fetch_arrays(thr, c), d.fetch_arrays(thr, c)
+                assert all((x == y).all() for x, y in zip(a, b)) and a[0].size == b[0].size, (kind, thr, c)
+                n += a[0].size
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -136,7 +170,7 @@ def main():
     rng = np.random.default_rng(a.seed)
     path = "/tmp/fuzz_ingest_%d.bam" % os.getpid()
     t0 = time.time()
-    rounds = members = nbytes = nrecs = rewalked = 0
+    rounds = members = nbytes = nrecs = rewalked = nivs = 0
     last = t0
     while time.time() - t0 < a.seconds:
         m, n = round_members(rng, path)
@@ -145,13 +179,16 @@ def main():
         k, rw = round_records(rng, path)
         nrecs += k
         rewalked += rw
+        nivs += round_bigwig(rng, path + ".bw")
         rounds += 1
         if time.time() - last > 30:
             last = time.time()
-            print("[fuzz_ingest] %d rounds: %d members (%.1f MB inflated), %d records, %d pieces rewalked, 0 bad" % (rounds, members, nbytes / 1e6, nrecs, rewalked), flush=True)
-    print("[fuzz_ingest] done (seed %d): %d rounds, %d members, %.1f MB inflated == zlib, %d records == host reader, %d pieces rewalked, 0 bad"
-          % (a.seed, rounds, members, nbytes / 1e6, nrecs, rewalked), flush=True)
+            print("[fuzz_ingest] %d rounds: %d members (%.1f MB inflated), %d records, %d pieces rewalked, %d BigWig intervals, 0 bad" % (rounds, members, nbytes / 1e6, nrecs, rewalked, nivs), flush=True)
+    print("[fuzz_ingest] done (seed %d): %d rounds, %d members, %.1f MB inflated == zlib, %d records == host reader, %d pieces rewalked, "
+          "%d BigWig intervals == host reader, 0 bad" % (a.seed, rounds, members, nbytes / 1e6, nrecs, rewalked, nivs), flush=True)
     os.unlink(path)
+    if os.path.exists(path + ".bw"):
+        os.unlink(path + ".bw")
 
 
 if __name__ == "__main__":
