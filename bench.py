@@ -70,7 +70,60 @@ def parse():
     ap.add_argument("--cpu-sample-mbp", type=float, default=128.0, help="bp per CPU-baseline slice, in Mbp")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-positions -> rows leg (SURVEY 8d)")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the BAM-file leg (SURVEY 8 row f1: device ingest against the host reader)")
+    ap.add_argument("--ingest-reads", type=int, default=2_000_000, help="reads of the synthetic BAM file of that leg")
     return ap.parse_args()
+
+
+def ingest_leg(n_reads, mapq=10):
+    """The row in front of the path, outside the timed region and never part of `value`: a synthetic coordinate-sorted
+    BAM file of n_reads 36-bp reads over hg38 (BGZF level 1) -> the filtered records of the reference's read loop
+    (handler/calc.py:140-153, handler/read.py:62-155), through the HOST reader (zlib on the threads this process may use) and through
+    the DEVICE reader (libpymasc_ingest.so: inflate, CRC32, record chain and filter as HIP kernels, records left in HBM); best of
+    three each, same records (count and position checksum).  tools/bench_ingest.py is the full-size version (20 M reads)."""
+    import tempfile
+    from pymasc_amd import bam as B
+    from pymasc_amd import bam_device as D
+    from tools.bench_ingest import synth_bam
+    path = os.path.join(tempfile.gettempdir(), "pymasc_bench_ingest_%d.bam" % os.getpid())
+    try:
+        synth_bam(path, n_reads)
+        cores, _q = usable_cores()
+
+        def host():
+            t0 = time.perf_counter()
+            n = cs = 0
+            with B.BamReader(path, threads=cores) as r:
+                for _ref, pos, _rl, rev in r.batches(mapq):
+                    n += pos.size
+                    cs += int(pos.astype(np.int64).sum()) + int(rev.sum())
+            return time.perf_counter() - t0, (n, cs)
+
+        def device():
+            t0 = time.perf_counter()
+            with D.DeviceBamReader(path) as r:
+                n = r.decode(mapq)
+                dt = time.perf_counter() - t0      # the filtered records are in HBM (what the device feed consumes)
+                cs = 0
+                for _ref, pos, _rl, rev in r.batches(mapq):
+                    cs += int(pos.astype(np.int64).sum()) + int(rev.sum())
+                tm = r.timings()
+            return dt, (n, cs), tm
+        device()                                   # (the first open page-locks the staging buffers and loads the code object)
+        th = [host() for _ in range(3)]
+        td = [device() for _ in range(3)]
+        assert all(x[1] == th[0][1] for x in th + td), "device ingest and host reader disagree"
+        h, d = min(x[0] for x in th), min(x[0] for x in td)
+        return {"reads": n_reads, "kept": th[0][1][0], "file_bytes": os.path.getsize(path), "host_reader_s": round(h, 4), "host_threads": cores,
+                "device_reader_s": round(d, 4), "speedup": round(h / d, 2),
+                "device_phases_s": {k: round(v, 4) for k, v in min(td, key=lambda x: x[0])[2].items()},
+                "what": "BAM file -> filtered (ref, pos, read length, strand) records: zlib host reader vs libpymasc_ingest.so "
+                        "(records left in HBM); same records; not part of `value`"}
+    except Exception as e:          # the contract line must not depend on this leg
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
 
 
 def cpu_baseline(ctx, vecs, S, L, with_m, sample_bp, threads, budget_s=14.0):
@@ -780,6 +833,8 @@ def main():
         result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
     else:
         result["cpu_baseline"] = None
+
+    result["ingest"] = ingest_leg(args.ingest_reads) if (rank == 0 and world == 1 and not args.no_ingest) else None
 
     if rank == 0:
         print(json.dumps(result))

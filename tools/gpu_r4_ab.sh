@@ -12,6 +12,6 @@ for rep in 1 2 3; do
   i=0
   for flags in "$@"; do
     i=$((i+1))
-    PYMASC_AMD_LIB=/tmp/libvar$i.so python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-end-to-end ${BENCH_ARGS} 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$flags]', round(d['ms_per_step'],4), d['kernel_ms_per_step'])"
+    PYMASC_AMD_LIB=/tmp/libvar$i.so python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-end-to-end --no-ingest ${BENCH_ARGS} 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$flags]', round(d['ms_per_step'],4), d['kernel_ms_per_step'])"
   done
 done

@@ -9,10 +9,10 @@ tools/tools_r4_profile.sh r4/prof_stress --workload stress > gpurun_out/r4/prof_
 tail -n 1 gpurun_out/r4/prof_default.log | cut -c1-300
 tail -n 1 gpurun_out/r4/prof_stress.log | cut -c1-300
 python bench.py > gpurun_out/r4/bench_default.json 2> gpurun_out/r4/bench_default.err || { tail -n 5 gpurun_out/r4/bench_default.err; exit 1; }
-python bench.py --mode ncc --no-cpu-baseline --no-end-to-end > gpurun_out/r4/bench_ncc.json 2> /dev/null
-python bench.py --workload stress --no-cpu-baseline --no-end-to-end > gpurun_out/r4/bench_stress.json 2> /dev/null
-python bench.py --workload stress --mode ncc --no-cpu-baseline --no-end-to-end > gpurun_out/r4/bench_stress_ncc.json 2> /dev/null
-python bench.py --no-hint --no-cpu-baseline --no-end-to-end > gpurun_out/r4/bench_nohint.json 2> /dev/null
+python bench.py --mode ncc --no-cpu-baseline --no-end-to-end --no-ingest > gpurun_out/r4/bench_ncc.json 2> /dev/null
+python bench.py --workload stress --no-cpu-baseline --no-end-to-end --no-ingest > gpurun_out/r4/bench_stress.json 2> /dev/null
+python bench.py --workload stress --mode ncc --no-cpu-baseline --no-end-to-end --no-ingest > gpurun_out/r4/bench_stress_ncc.json 2> /dev/null
+python bench.py --no-hint --no-cpu-baseline --no-end-to-end --no-ingest > gpurun_out/r4/bench_nohint.json 2> /dev/null
 for f in default ncc stress stress_ncc nohint; do
   python -c "
 import json; d=json.load(open('gpurun_out/r4/bench_$f.json')); print('$f', round(d['ms_per_step'],4), d['kernel_ms_per_step'], round(d['roofline']['frac'],4), d.get('repetitions'))"

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 tag=$1
 mkdir -p gpurun_out/r4
-B="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --no-hint"
+B="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --no-ingest --no-hint"
 pick='import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({"ms_per_step": round(d["ms_per_step"],4), "kernels": d["kernel_ms_per_step"], "edges_per_64kbit": d["config"]["run_edges_per_64kbit"]}))'
 pickh='import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({"ms_per_step": round(d["ms_per_step"],4), "kernels": d["kernel_ms_per_step"], "hint": "window_only" if d["config"]["window_only_hint"] else ("deep_lists" if d["config"]["deep_lists_hint"] else None)}))'
 : > gpurun_out/r4/${tag}_sweep_density.json

@@ -10,7 +10,7 @@ out=$R/gpurun_out/$1; shift
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-end-to-end"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-end-to-end --no-ingest"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $BENCH --steps 20 --warmup 5 "$@" > $out/bench_under_rocprof.json 2> $out/stats.err
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 i=0
