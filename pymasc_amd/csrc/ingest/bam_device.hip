@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -369,6 +370,44 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                 // are stored behind it (the ring holds 4096 bytes).
                 const u32 g0 = pos & ~255u;
                 u32 e;
+#ifndef INF_NO_ASM_LITERALS
+                {
+                    // ... written out: the compiler's version of this loop is 23 instructions per literal (it keeps the two exit
+                    // conditions as lane masks and forms the LDS address on the scalar unit); here the bit buffer lives in vector
+                    // registers for the length of the run (every lane holds the same words), so the table index, the 64-bit shift
+                    // (v_alignbit_b32) and the count are vector instructions and nothing goes through the scalar unit: 15 per literal.
+                    // All LDS traffic of the block has landed when it ends (s_waitcnt), the compiler's own counting is not disturbed.
+                    u32 lo = (u32)r.bb, hi = (u32)(r.bb >> 32), bc = r.bc, ev, a, l;
+                    const u32 vlit = (u32)(uintptr_t)S.litT, vring = (u32)(uintptr_t)S.ring;   // (low halves of the flat addresses: LDS offsets)
+                    asm volatile("1:\n\t"
+                                 "v_and_b32 %[a], 0x7ff, %[lo]\n\t"
+                                 "v_lshl_add_u32 %[a], %[a], 1, %[vlit]\n\t"
+                                 "ds_read_i16 %[ev], %[a]\n\t"
+                                 "s_waitcnt lgkmcnt(0)\n\t"
+                                 "v_cmp_gt_i32 vcc, 0, %[ev]\n\t"
+                                 "s_cbranch_vccnz 2f\n\t"
+                                 "v_and_b32 %[a], 0xfff, %[vpos]\n\t"
+                                 "v_add_u32 %[a], %[a], %[vring]\n\t"
+                                 "ds_write_b8 %[a], %[ev]\n\t"
+                                 "v_add_u32 %[vpos], 1, %[vpos]\n\t"
+                                 "v_lshrrev_b32 %[l], 8, %[ev]\n\t"
+                                 "v_alignbit_b32 %[lo], %[hi], %[lo], %[l]\n\t"
+                                 "v_lshrrev_b32 %[hi], %[l], %[hi]\n\t"
+                                 "v_sub_u32 %[bc], %[bc], %[l]\n\t"
+                                 "v_cmp_lt_u32 vcc, 14, %[bc]\n\t"
+                                 "s_cbranch_vccnz 1b\n"
+                                 "2:\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : [lo] "+v"(lo), [hi] "+v"(hi), [bc] "+v"(bc), [vpos] "+v"(vpos), [ev] "=&v"(ev), [a] "=&v"(a), [l] "=&v"(l)
+                                 : [vlit] "v"(vlit), [vring] "v"(vring)
+                                 : "vcc", "memory");
+                    static_assert(INF_LP == 11u && INF_RING == 4096u, "the masks of the literal loop");
+                    r.bb = ((u64)RFL(hi) << 32) | RFL(lo);
+                    r.bc = RFL(bc);
+                    e = RFL(ev) & 0xffffu;   // (the entry that ended the run, or the last literal's: bit 15 tells)
+                    pos = RFL(vpos);
+                }
+#else
                 for (;;) {
                     const u32 ev = S.litT[(u32)r.bb & ((1u << INF_LP) - 1u)];   // (the same word in every lane)
                     e = RFL(ev);
@@ -381,6 +420,7 @@ k_bgzf_inflate(const u8 *__restrict__ in, u8 *__restrict__ out, const DMember *_
                     r.bc -= l;
                     if (r.bc < 15u) break;
                 }
+#endif
                 if ((pos & ~255u) != g0) {   // (one group at most)
                     if (g0 >= pend) {
                         err = INF_ERR_OUTPUT;
