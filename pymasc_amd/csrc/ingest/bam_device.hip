@@ -1317,7 +1317,16 @@ extern "C" {
 const char *pmx_dbam_last_error(void) { return g_err.c_str(); }
 int pmx_dbam_version(void) { return 1; }
 
+static int dbam_open_impl(const char *path, int device, int nthreads, pmx_dbam **out);
 int pmx_dbam_open(const char *path, int device, int nthreads, pmx_dbam **out)
+{
+    try {   // (std::bad_alloc, std::system_error from a thread that cannot be started: an exception must not leave the C ABI)
+        return dbam_open_impl(path, device, nthreads, out);
+    } catch (const std::exception &e) {
+        return fail(PMX_DBAM_ERR_OPEN, std::string("pmx_dbam_open: ") + e.what());
+    }
+}
+static int dbam_open_impl(const char *path, int device, int nthreads, pmx_dbam **out)
 {
     if (!path || !out) return fail(PMX_DBAM_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -1398,7 +1407,16 @@ const char *pmx_dbam_header_text(const pmx_dbam *b, uint32_t *len)
     return b->text.c_str();
 }
 
+static int64_t dbam_decode_impl(pmx_dbam *b, uint32_t mapq_min, uint32_t flag_exclude, int32_t want_ref);
 int64_t pmx_dbam_decode(pmx_dbam *b, uint32_t mapq_min, uint32_t flag_exclude, int32_t want_ref)
+{
+    try {
+        return dbam_decode_impl(b, mapq_min, flag_exclude, want_ref);
+    } catch (const std::exception &e) {
+        return fail(PMX_DBAM_ERR_OPEN, std::string("pmx_dbam_decode: ") + e.what());
+    }
+}
+static int64_t dbam_decode_impl(pmx_dbam *b, uint32_t mapq_min, uint32_t flag_exclude, int32_t want_ref)
 {
     if (!b) return fail(PMX_DBAM_ERR_INVALID, "null handle");
     HIPOK(hipSetDevice(b->device));
@@ -1409,7 +1427,15 @@ int64_t pmx_dbam_decode(pmx_dbam *b, uint32_t mapq_min, uint32_t flag_exclude, i
     const u8 *D = b->d_out + b->data_beg;
     double t0 = now_s();
     if (!b->d_spec) {
-        HIPOK(hipMalloc((void **)&b->d_spec, 8 * np));
+        // (all of the chain's tables or none: a failed allocation must not leave a handle that skips this block next time)
+        struct Undo {
+            pmx_dbam *b;
+            bool keep = false;
+            ~Undo()
+            {
+                if (!keep) free_chain(*b);
+            }
+        } undo{b};
         HIPOK(hipMalloc((void **)&b->d_end, 8 * np));
         HIPOK(hipMalloc((void **)&b->d_kept_base, 8 * np));
         HIPOK(hipMalloc((void **)&b->d_totals, 16));
@@ -1417,6 +1443,8 @@ int64_t pmx_dbam_decode(pmx_dbam *b, uint32_t mapq_min, uint32_t flag_exclude, i
         HIPOK(hipMalloc((void **)&b->d_kept, 4 * np));
         HIPOK(hipMalloc((void **)&b->d_nmis, 4));
         HIPOK(hipMalloc((void **)&b->d_first_error, 8));
+        HIPOK(hipMalloc((void **)&b->d_spec, 8 * np));
+        undo.keep = true;
         hipLaunchKernelGGL(k_bam_spec, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, b->stream, D, N, (int)b->ref_names.size(), np, b->d_spec);
         HIPOK(hipGetLastError());
         b->chain_ready = false;
@@ -1525,7 +1553,16 @@ int pmx_dbam_fetch(pmx_dbam *b, int64_t first, int64_t n, int32_t *ref_id, int32
     return 0;
 }
 
+static int64_t dbam_runs_impl(pmx_dbam *b, int64_t cap, int64_t *start, int32_t *ref_id, int32_t *first_pos1, int32_t *last_pos1);
 int64_t pmx_dbam_runs(pmx_dbam *b, int64_t cap, int64_t *start, int32_t *ref_id, int32_t *first_pos1, int32_t *last_pos1)
+{
+    try {
+        return dbam_runs_impl(b, cap, start, ref_id, first_pos1, last_pos1);
+    } catch (const std::exception &e) {
+        return fail(PMX_DBAM_ERR_OPEN, std::string("pmx_dbam_runs: ") + e.what());
+    }
+}
+static int64_t dbam_runs_impl(pmx_dbam *b, int64_t cap, int64_t *start, int32_t *ref_id, int32_t *first_pos1, int32_t *last_pos1)
 {
     if (!b) return fail(PMX_DBAM_ERR_INVALID, "null handle");
     if (b->n_kept == 0) return 0;
