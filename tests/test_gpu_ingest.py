@@ -415,3 +415,45 @@ def test_golden_run_with_both_inputs_on_the_device(tmp_path):
         calc.close()
         names = bam.references
     _check_tables(tmp_path / "both", whole, names)
+
+
+def test_pipelined_open_gives_the_same_stream(tmp_path, monkeypatch):
+    """PMX_DBAM_PIPELINE=1 (inflate launches behind the copies of the pieces, four streams, growing tables): same bytes, same records."""
+    rng = np.random.default_rng(41)
+    refs = [("c1", 3_000_000), ("c2", 1_000_000)]
+    recs, meta = W.synth_bam_records(rng, refs, 20000)
+    path = tmp_path / "p.bam"
+    W.write_bam(path, refs, recs, block=700, level=1)         # ~ 6000 members: the member table grows
+    with D.DeviceBamReader(path) as r:
+        a, ra = r.inflated(), _all_reads(r, 7)
+    monkeypatch.setenv("PMX_DBAM_PIPELINE", "1")
+    with D.DeviceBamReader(path) as r:
+        b, rb = r.inflated(), _all_reads(r, 7)
+        assert r.counters()["members"] > 4096
+    assert a == b and ra == rb == _expected(meta, refs, 7)
+
+
+def test_unsorted_file_falls_back_to_host_arrays_and_is_refused_alike(tmp_path):
+    """More than 65536 runs of one reference (records alternating between two chromosomes): DeviceBamReader.feed has no run table to
+    hand over, takes the records through host arrays like feed_bam, and the calculator refuses the file as it refuses it from the host
+    reader (ReadUnsortedError, mscc.pyx:351-364)."""
+    from pymasc_amd.calculator import CCHipCalculator
+    from pymasc_amd.exceptions import ReadUnsortedError
+    refs = [("c1", 500000), ("c2", 500000)]
+    recs = [W.bam_record(i & 1, 10 + i, 30, 0, [("M", 36)], b"u%d" % i) for i in range(66000)]
+    path = tmp_path / "u.bam"
+    W.write_bam(path, refs, recs, level=1)
+    with D.DeviceBamReader(path) as r:
+        assert r.decode(0) == len(recs) and r.device_runs() is None
+    for dev in (False, True):
+        calc = CCHipCalculator(100, 36, [n for n, _ in refs], [l for _, l in refs])
+        try:
+            with pytest.raises(ReadUnsortedError):
+                if dev:
+                    with D.DeviceBamReader(path) as r:
+                        r.feed(calc, 0)
+                else:
+                    with B.BamReader(path, index=False) as r:
+                        B.feed_bam(calc, r, 0)
+        finally:
+            calc.close()
