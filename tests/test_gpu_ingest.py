@@ -457,3 +457,16 @@ def test_unsorted_file_falls_back_to_host_arrays_and_is_refused_alike(tmp_path):
                         B.feed_bam(calc, r, 0)
         finally:
             calc.close()
+
+
+def test_header_larger_than_the_first_read_back(tmp_path):
+    """A reference dictionary of 2 MB (60000 contigs) spans many BGZF members and more than the first megabyte the header parser
+    copies back: dictionary and records == the host reader."""
+    refs = [("contig_%05d_with_a_fairly_long_name" % i, 1000 + i) for i in range(60000)]
+    recs = [W.bam_record(i * 7, 5, 30, 16 * (i & 1), [("M", 20)], b"h%d" % i) for i in range(300)]
+    path = tmp_path / "big_header.bam"
+    W.write_bam(path, refs, recs, level=1)
+    with B.BamReader(path, index=False) as h, D.DeviceBamReader(path) as d:
+        assert d.references == h.references and d.lengths == h.lengths and len(d.references) == 60000
+        assert d.header_text == h.header_text
+        assert _all_reads(d, 0) == _all_reads(h, 0)
