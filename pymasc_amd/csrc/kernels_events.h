@@ -453,6 +453,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
     u32 cntM = 0, cntU = 0;                       // DO_MLEN: popcount(M), runs starting in them
     u32 accF = 0, accR = 0, accE = 0;             // (uniform) listed forward / reverse reads / run edges since the histograms' last flush
     bool seg_written = false;                     // (uniform) this (workgroup, job) segment already holds a flush
+    bool seg_gr_written = false;                  // (uniform) ... and its GR row (BIG: that row is also flushed alone, below)
 #ifdef EV_STAMPS
     unsigned long long stamp_acc[EV_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last;
@@ -984,7 +985,37 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
             xch[14] = 0;
             xch[15] = 0;
         }
-        if (leaving || risk) {
+        // BIG (round 4, late): the GR row reaches its bound four times as often as the others (three events per listed reverse read and
+        // shift against one per forward read), and a flush of everything is 8 rows' worth of read-modify-write (config 5: 0.47 GB of
+        // writes per step).  When GR alone is at risk, GR alone is flushed.
+#ifndef EV_NO_GR_FLUSH
+        const bool risk_gr_only = BIG && HAS_M && !leaving && risk && !(accF + NSG * EV_CAPF > 32767u) &&
+                                  !(EE_LDS && accE + NSG * L::POOL > 32767u);
+#else
+        const bool risk_gr_only = false;
+#endif
+        if (risk_gr_only) {
+            __syncthreads();
+            u32 *seg = slab + (size_t)(blockIdx.x + ji) * EV_SEG_ROWS * HN;
+            const bool add = seg_gr_written;
+#pragma nounroll
+            for (u32 k = gt; k < (HN >> 1); k += NT) {
+                const u32 w = hGR[k];
+                hGR[k] = 0;
+                const int32_t lo16 = (int32_t)(short)(w & 0xffffu);
+                const int32_t hi16 = (int32_t)(short)((w - (u32)lo16) >> 16);
+                uint2 *dst = reinterpret_cast<uint2 *>(seg + (size_t)3 * HN + 2 * k);
+                uint2 v = make_uint2((u32)lo16, (u32)hi16);
+                if (add) {
+                    const uint2 o = *dst;
+                    v.x += o.x;
+                    v.y += o.y;
+                }
+                *dst = v;
+            }
+            accR = 0;
+            seg_gr_written = true;
+        } else if (leaving || risk) {
             // histograms of this (workgroup, job) -> its slab segment (added to it from the second flush on); cleared
             __syncthreads();
             u32 *seg = slab + (size_t)(blockIdx.x + ji) * EV_SEG_ROWS * HN;
@@ -1013,7 +1044,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                         const int32_t hi16 = (int32_t)(short)((w - (u32)lo16) >> 16);
                         uint2 *dst = reinterpret_cast<uint2 *>(seg + (size_t)(row ? 3 : 1) * HN + 2 * k);
                         uint2 v = make_uint2((u32)lo16, (u32)hi16);
-                        if (add) {
+                        if (row ? seg_gr_written : add) {
                             const uint2 o = *dst;
                             v.x += o.x;
                             v.y += o.y;
@@ -1148,6 +1179,7 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
             accR = 0;
             accE = 0;
             seg_written = true;
+            seg_gr_written = true;
             if (leaving && !(!BIG && HAS_M)) {   // (max_shift <= 1023 with a track: written with every flush, above)
                 // scalars: |F|, |R|, Bf, R0, popcount(M), runs -> row 4 of the segment
                 u32 v[6] = {0, 0, cntB, cnt0, cntM, cntU};
@@ -1174,7 +1206,10 @@ k_cc_events(const JT jobs, u32 njobs, u32 total_tiles, u32 tiles_per_wg, u32 c, 
                 cntM = 0;
                 cntU = 0;
             }
-            if (leaving) seg_written = false;
+            if (leaving) {
+                seg_written = false;
+                seg_gr_written = false;
+            }
         }
         if (jn != ji) {
             if (BIG && DO_MLEN && !EE_LDS) ev_zero_row5(slab, blockIdx.x + jn, HN, gt, NT);   // (the barrier at the top of the loop follows)
