@@ -126,6 +126,21 @@ def ingest_leg(n_reads, mapq=10):
             os.unlink(path)
 
 
+def ingest_leg_isolated(n_reads):
+    """ingest_leg in a child process (started fresh: `python bench.py --ingest-child N`, not an exec of this one): whatever happens to
+    that leg -- an exception, a device fault that ends its process -- the contract line of this process is still printed."""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--ingest-child", str(int(n_reads))], capture_output=True, text=True,
+                           timeout=240)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": "the ingest leg's process ended with code %d: %s" % (p.returncode, (p.stderr or "").strip().splitlines()[-1:] or "")}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def cpu_baseline(ctx, vecs, S, L, with_m, sample_bp, threads, budget_s=14.0):
     """Times the oracle (C restatement of the reference's per-shift full-vector passes) on host cores:
     one chromosome slice per thread, like `pymasc -p <threads>` (threads = the cores this process
@@ -834,7 +849,7 @@ def main():
     else:
         result["cpu_baseline"] = None
 
-    result["ingest"] = ingest_leg(args.ingest_reads) if (rank == 0 and world == 1 and not args.no_ingest) else None
+    result["ingest"] = ingest_leg_isolated(args.ingest_reads) if (rank == 0 and world == 1 and not args.no_ingest) else None
 
     if rank == 0:
         print(json.dumps(result))
@@ -842,6 +857,10 @@ def main():
     if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 
+
+if __name__ == "__main__" and len(sys.argv) == 3 and sys.argv[1] == "--ingest-child":
+    print(json.dumps(ingest_leg(int(sys.argv[2]))))
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()
